@@ -1,0 +1,954 @@
+// gm_api.cpp — the C ABI of libgnumap_hip.so (include/gnumap_hip.h): index residency in HBM, batch staging,
+// the kernel pipeline, and the host-side mirror of the reference's per-read bookkeeping
+// (unique-sequence map, denominator, posterior, MAPQ: src/Driver.cpp:432-753, inc/align_seq2_raw.cpp:102-165,
+// inc/ScoredSeq.h:293-404).  There is NO CPU fallback for the device work: without a usable gfx950 device every
+// compute entry point fails with GM_E_NO_DEVICE.
+#include "gm_host.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <set>
+
+static thread_local std::string g_err;
+void gm_set_error(const std::string& s) { g_err = s; }
+extern "C" const char* gm_last_error(void) { return g_err.c_str(); }
+extern "C" const char* gm_version(void) { return "gnumap-mi355x 0.1 (gfx950)"; }
+
+#define HIPCHK(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) {                                                                               \
+            gm_set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                                  \
+            return GM_E_HIP;                                                                                  \
+        }                                                                                                     \
+    } while (0)
+#define KCHK(expr)                                                                                            \
+    do {                                                                                                      \
+        int e_ = (expr);                                                                                      \
+        if (e_ != 0) {                                                                                        \
+            gm_set_error(std::string(#expr) + ": " + hipGetErrorString((hipError_t)e_));                      \
+            return GM_E_HIP;                                                                                  \
+        }                                                                                                     \
+    } while (0)
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return GM_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { gm_set_error(std::string("hipMalloc: ") + hipGetErrorString(e)); p = nullptr; return GM_E_NOMEM; }
+        cap = want;
+        return GM_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace
+
+struct gm_index {
+    GmHostIndex h;
+    int device = -1;
+    bool host_only = false;
+    bool full_sa = false;
+    DevBuf d_bwt, d_sa, d_full, d_pac, d_contig, d_cov, d_ptab;
+    GmDevIndex dev{};
+    uint64_t cov_bins = 0;
+    uint32_t cov_bin_size = 0;
+    // parameter tables resident in HBM: S256 (256x4 floats) + lut (512 float2)
+    std::vector<float> ptab_host;
+    std::mutex mu;
+    uint64_t hbm_bytes = 0;
+};
+
+struct gm_batch {
+    gm_index* ix = nullptr;
+    uint32_t max_reads = 0, max_len = 0;
+    uint32_t n = 0, stride = 0, max_seeds = 0, illumina_until = 0;
+    DevBuf bases, quals, len, status, self_score, min_score, top_score, seeds, n_seeds, n_entries, entry_off, coords,
+        rs_overflow, retry_list, retry_off, gtab_keys, gtab_vals, cands, hit_count, hit_begin, hit_cursor, raw_hits, counters, small,
+        tb_items, tb_ops, tb_len, dep_pos, dep_span, dep_w;
+    uint32_t cand_cap = 0;
+    uint64_t raw_cap = 0;
+    uint32_t n_cands = 0;
+    uint64_t n_raw = 0;
+    bool mapped = false;
+    unsigned long long counters_host[GMK_N] = { 0 };
+    GmDevBatch dev{};
+    std::vector<uint16_t> len_host;
+    // HIP-event profiling of the kernels of gm_map_batch_device
+    bool profiling = false;
+    struct Ev { int which; hipEvent_t a, b; };
+    std::vector<Ev> pending;
+    std::vector<hipEvent_t> pool;
+    double k_ms[GM_K_COUNT] = { 0 };
+    uint64_t k_launches[GM_K_COUNT] = { 0 };
+};
+
+namespace {
+struct KTimer {     // brackets one kernel (or one small group of launches) with events on its stream
+    gm_batch* b; int which; hipStream_t st; hipEvent_t a = nullptr, e = nullptr; bool on;
+    KTimer(gm_batch* b_, int w, hipStream_t s) : b(b_), which(w), st(s), on(b_->profiling) {
+        if (!on) return;
+        auto get = [&]() { hipEvent_t ev = nullptr; if (!b->pool.empty()) { ev = b->pool.back(); b->pool.pop_back(); } else if (hipEventCreate(&ev) != hipSuccess) ev = nullptr; return ev; };
+        a = get(); e = get();
+        if (!a || !e) { on = false; return; }
+        (void)hipEventRecord(a, st);
+    }
+    ~KTimer() {
+        if (!on) return;
+        (void)hipEventRecord(e, st);
+        b->pending.push_back({ which, a, e });
+    }
+};
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// parameters (const_define.h:29-131, a_matrices.c:55-83, Driver.cpp:1206,1260-1313,2805-2816)
+// ------------------------------------------------------------------------------------------------
+extern "C" void gm_params_default(gm_params* p) {
+    memset(p, 0, sizeof *p);
+    p->mer = 10; p->jump = 0; p->min_seed_hits = 2; p->max_kmer_hits = 0; p->max_matches = 1000; p->max_gap = 3;
+    p->nw = 1; p->fast = 0; p->unique_only = 0; p->pos_strand = 1; p->neg_strand = 1; p->mode = GM_MODE_NORMAL;
+    p->align_score = 0.9f; p->align_is_fraction = 1; p->cutoff = 0.0f;
+    p->adjust = 0.25f; p->match = 3; p->transition = -2; p->transversion = -3; p->gap = -4;
+    p->bin_size = 8; p->print_all_sam = 0; p->illumina = 0; p->finalized = 0;
+}
+
+extern "C" int gm_params_finalize(gm_params* p) {
+    if (!p) return GM_E_ARG;
+    if (p->finalized) return GM_OK;
+    if (p->mer < 1 || p->mer > 32) { gm_set_error("-m/--mer_size: must be 1..32 (MAX_MER_SIZE)"); return GM_E_ARG; }
+    if (p->min_seed_hits < 1) { gm_set_error("-k/--num_seed: Invalid matching seed number"); return GM_E_ARG; }
+    if (p->max_gap != 3) { gm_set_error("-M/--max_gap: this build's kernels implement the default band (3)"); return GM_E_UNSUPPORTED; }
+    if (p->jump <= 0) p->jump = p->mer / 2;
+    if (p->jump < 1) p->jump = 1;
+    p->match *= p->adjust; p->transition *= p->adjust; p->transversion *= p->adjust; p->gap *= p->adjust;
+    for (int i = 0; i < 256; ++i) for (int j = 0; j < 4; ++j) p->S[i][j] = p->transversion;
+    static const char lo[4] = { 'a', 'c', 'g', 't' }, up[4] = { 'A', 'C', 'G', 'T' };
+    for (int g = 0; g < 4; ++g)
+        for (int b = 0; b < 4; ++b) {
+            float v = g == b ? p->match : ((g ^ b) == 2 ? p->transition : p->transversion);
+            p->S[(int)lo[g]][b] = v;
+            p->S[(int)up[g]][b] = v;
+        }
+    if (p->mode == GM_MODE_BS) p->S['c'][3] = p->match;
+    if (p->mode == GM_MODE_BS2) p->S['g'][0] = p->match;
+    if (p->mode == GM_MODE_ATOG) p->S['a'][2] = p->match;
+    if (p->mode == GM_MODE_ATOG2) p->S['t'][1] = p->match;
+    if (p->mode != GM_MODE_NORMAL) p->bin_size = 1;
+    if (p->bin_size < 1) { gm_set_error("--bin_size: must be >= 1"); return GM_E_ARG; }
+    p->finalized = 1;
+    return GM_OK;
+}
+
+// Q -> (p, (1-p)/3) in fp32 exactly as SeqReader::get_more_fastq computes them (fp64 libm, then one cast):
+// Q2Prb_std src/SeqReader.cpp:623-627, Q2Prb_ill :618-622.  Negative p is stored as NaN.
+static void build_lut(float* lut /* 512 x 2 */) {
+    for (int which = 0; which < 2; ++which)
+        for (int ch = 0; ch < 256; ++ch) {
+            double p;
+            if (which == 0) { int Q = ch - 33; p = 1 - exp((-(double)Q / 10.0) * log(10.0)); }
+            else { int Q = ch - 64; p = 1.0 - 1.0 / (pow(10.0, ((double)Q / 10.0))); }
+            if (p > 1.0) p = 1.0;
+            double other = (1 - p) / 3;
+            float* o = lut + ((size_t)which * 256 + ch) * 2;
+            if (p < 0) { o[0] = NAN; o[1] = NAN; } else { o[0] = (float)p; o[1] = (float)other; }
+        }
+}
+
+static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStream_t st) {
+    std::vector<float> tab(256 * 4 + 512 * 2);
+    memcpy(tab.data(), p->S, sizeof(float) * 1024);
+    build_lut(tab.data() + 1024);
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        if (ix->ptab_host != tab) {
+            int rc = ix->d_ptab.ensure(tab.size() * sizeof(float));
+            if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(ix->d_ptab.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+            ix->ptab_host = tab;
+        }
+    }
+    dp.mer = p->mer; dp.jump = p->jump; dp.kmin = p->min_seed_hits; dp.nw = p->nw; dp.fast = p->fast;
+    dp.pos_strand = p->pos_strand; dp.neg_strand = p->neg_strand; dp.align_is_fraction = p->align_is_fraction;
+    dp.hcap = p->max_kmer_hits; dp.gap = p->gap; dp.align_score = p->align_score; dp.cutoff = p->cutoff;
+    dp.S256 = ix->d_ptab.as<float>();
+    dp.lut = reinterpret_cast<const float2*>(ix->d_ptab.as<float>() + 1024);
+    return GM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// index
+// ------------------------------------------------------------------------------------------------
+extern "C" int gm_index_build(const char* fasta_path) {
+    if (!fasta_path) return GM_E_ARG;
+    std::string err;
+    int rc = gm_host_index_build(fasta_path, err);
+    if (rc) gm_set_error(err);
+    return rc;
+}
+
+extern "C" int gm_index_open(const char* fasta_path, int device_id, int flags, gm_index** out) {
+    if (!fasta_path || !out) return GM_E_ARG;
+    *out = nullptr;
+    std::string fa = fasta_path, err;
+    if (!gm_host_index_files_exist(fa)) {
+        if (!(flags & GM_INDEX_BUILD)) { gm_set_error("fail to locate the index files for " + fa); return GM_E_IO; }
+        int rc = gm_host_index_build(fa, err);                       // GenomeBwt::LoadGenome: "Could not find reference genome index! Building now."
+        if (rc) { gm_set_error(err); return rc; }
+    }
+    gm_index* ix = new gm_index();
+    int rc = gm_host_index_load(fa, ix->h, err);
+    if (rc) { gm_set_error(err); delete ix; return rc; }
+    if (ix->h.seq_len >= 0xFFFFFFFEull) {
+        gm_set_error("reference too long for 32-bit ranks");
+        delete ix;
+        return GM_E_UNSUPPORTED;
+    }
+    ix->host_only = (flags & GM_INDEX_HOST_ONLY) != 0;
+    if (ix->host_only) { *out = ix; return GM_OK; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) {
+        gm_set_error("no usable HIP device (libgnumap_hip needs an MI355X / gfx950; there is no CPU fallback)");
+        delete ix;
+        return GM_E_NO_DEVICE;
+    }
+    ix->device = device_id;
+    auto fail = [&](int code) { gm_index_close(ix); return code; };
+    if (hipSetDevice(device_id) != hipSuccess) { gm_set_error("hipSetDevice failed"); return fail(GM_E_NO_DEVICE); }
+    const GmHostIndex& h = ix->h;
+    // stage the index into HBM once
+    if (ix->d_bwt.ensure(h.bwt.size() * 4)) return fail(GM_E_NOMEM);
+    if (hipMemcpy(ix->d_bwt.p, h.bwt.data(), h.bwt.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { gm_set_error("bwt upload failed"); return fail(GM_E_HIP); }
+    std::vector<uint32_t> sa32(h.n_sa);
+    for (uint64_t i = 0; i < h.n_sa; ++i) sa32[i] = (uint32_t)h.sa[i];      // sa[0] = (u64)-1 -> 0xFFFFFFFF
+    if (ix->d_sa.ensure(sa32.size() * 4)) return fail(GM_E_NOMEM);
+    if (hipMemcpy(ix->d_sa.p, sa32.data(), sa32.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { gm_set_error("sa upload failed"); return fail(GM_E_HIP); }
+    if (ix->d_pac.ensure(h.pac.size())) return fail(GM_E_NOMEM);
+    if (hipMemcpy(ix->d_pac.p, h.pac.data(), h.pac.size(), hipMemcpyHostToDevice) != hipSuccess) { gm_set_error("pac upload failed"); return fail(GM_E_HIP); }
+    std::vector<uint32_t> coff(h.contigs.size() + 1);
+    for (size_t i = 0; i < h.contigs.size(); ++i) coff[i] = (uint32_t)h.contigs[i].offset;
+    coff[h.contigs.size()] = (uint32_t)h.l_pac;
+    if (ix->d_contig.ensure(coff.size() * 4)) return fail(GM_E_NOMEM);
+    if (hipMemcpy(ix->d_contig.p, coff.data(), coff.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { gm_set_error("contig upload failed"); return fail(GM_E_HIP); }
+    GmDevIndex& d = ix->dev;
+    d.bwt = ix->d_bwt.as<uint32_t>(); d.sa_samples = ix->d_sa.as<uint32_t>(); d.full_sa = nullptr;
+    d.pac = ix->d_pac.as<uint8_t>(); d.contig_off = ix->d_contig.as<uint32_t>();
+    d.seq_len = (uint32_t)h.seq_len; d.primary = (uint32_t)h.primary; d.l_pac = (uint32_t)h.l_pac; d.n_seqs = (uint32_t)h.contigs.size();
+    d.sa_mask = h.sa_intv - 1; d.sa_shift = 0;
+    while ((1u << d.sa_shift) < h.sa_intv) ++d.sa_shift;
+    for (int i = 0; i < 5; ++i) d.L2[i] = (uint32_t)h.L2[i];
+    if (flags & GM_INDEX_FULL_SA) {
+        if (ix->d_full.ensure(((size_t)h.seq_len + 1) * 4)) return fail(GM_E_NOMEM);
+        int e = gmk_expand_full_sa(d, ix->d_full.as<uint32_t>(), nullptr);
+        if (e || hipDeviceSynchronize() != hipSuccess) { gm_set_error("full SA expansion failed"); return fail(GM_E_HIP); }
+        d.full_sa = ix->d_full.as<uint32_t>();
+        ix->full_sa = true;
+    }
+    ix->hbm_bytes = ix->d_bwt.cap + ix->d_sa.cap + ix->d_pac.cap + ix->d_contig.cap + ix->d_full.cap;
+    *out = ix;
+    return GM_OK;
+}
+
+extern "C" void gm_index_close(gm_index* ix) {
+    if (!ix) return;
+    if (!ix->host_only && ix->device >= 0) {
+        (void)hipSetDevice(ix->device);
+        ix->d_bwt.release(); ix->d_sa.release(); ix->d_full.release(); ix->d_pac.release(); ix->d_contig.release();
+        ix->d_cov.release(); ix->d_ptab.release();
+    }
+    delete ix;
+}
+
+extern "C" int gm_index_get_info(const gm_index* ix, gm_index_info* o) {
+    if (!ix || !o) return GM_E_ARG;
+    o->l_pac = ix->h.l_pac; o->seq_len = ix->h.seq_len; o->primary = ix->h.primary; o->bwt_words = ix->h.bwt_words; o->n_sa = ix->h.n_sa;
+    o->sa_intv = ix->h.sa_intv; o->n_seqs = (uint32_t)ix->h.contigs.size(); o->device_id = ix->device; o->full_sa = ix->full_sa;
+    o->hbm_bytes = ix->hbm_bytes;
+    return GM_OK;
+}
+
+extern "C" const char* gm_index_contig_name(const gm_index* ix, uint32_t i) {
+    if (!ix || i >= ix->h.contigs.size()) return nullptr;
+    return ix->h.contigs[i].name.c_str();
+}
+
+extern "C" uint64_t gm_index_contig_offset(const gm_index* ix, uint32_t i) {
+    if (!ix) return 0;
+    if (i >= ix->h.contigs.size()) return ix->h.l_pac;
+    return ix->h.contigs[i].offset;
+}
+
+static uint32_t host_pos2rid(const GmHostIndex& h, uint64_t pos) {      // bns_pos2rid src/bntseq.c:349-363
+    uint32_t lo = 0, hi = (uint32_t)h.contigs.size() - 1;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi + 1) >> 1;
+        if (pos >= h.contigs[mid].offset) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+static bool host_window(const GmHostIndex& h, uint64_t begin, uint32_t L, char* out) {   // GenomeBwt::GetString src/GenomeBwt.cpp:384-415
+    if (L == 0 || begin >= h.l_pac || begin + L > h.l_pac) return false;
+    if (host_pos2rid(h, begin) != host_pos2rid(h, begin + L - 1)) return false;
+    for (uint32_t t = 0; t < L; ++t) {
+        uint64_t p = begin + t;
+        out[t] = "acgt"[(h.pac[p >> 2] >> ((~p & 3) << 1)) & 3];
+    }
+    return true;
+}
+
+extern "C" int gm_index_window(const gm_index* ix, uint64_t begin, uint32_t L, char* out) {
+    if (!ix || !out) return 0;
+    out[0] = 0;
+    if (!host_window(ix->h, begin, L, out)) return 0;
+    out[L] = 0;
+    return (int)L;
+}
+
+// ------------------------------------------------------------------------------------------------
+// batches
+// ------------------------------------------------------------------------------------------------
+extern "C" int gm_batch_create(gm_index* ix, uint32_t max_reads, uint32_t max_len, gm_batch** out) {
+    if (!ix || !out || max_reads == 0 || max_len == 0 || max_len > 4096) return GM_E_ARG;
+    if (ix->host_only) { gm_set_error("index opened host-only"); return GM_E_NO_DEVICE; }
+    HIPCHK(hipSetDevice(ix->device));
+    gm_batch* b = new gm_batch();
+    b->ix = ix; b->max_reads = max_reads; b->max_len = max_len;
+    *out = b;
+    return GM_OK;
+}
+
+extern "C" void gm_batch_destroy(gm_batch* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->ix->device);
+    DevBuf* all[] = { &b->bases, &b->quals, &b->len, &b->status, &b->self_score, &b->min_score, &b->top_score, &b->seeds, &b->n_seeds,
+                      &b->n_entries, &b->entry_off, &b->coords, &b->rs_overflow, &b->retry_list, &b->retry_off, &b->gtab_keys, &b->gtab_vals,
+                      &b->cands, &b->hit_count, &b->hit_begin, &b->hit_cursor, &b->raw_hits, &b->counters, &b->small, &b->tb_items, &b->tb_ops,
+                      &b->tb_len, &b->dep_pos, &b->dep_span, &b->dep_w };
+    for (DevBuf* d : all) d->release();
+    for (auto& ev : b->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    for (auto ev : b->pool) (void)hipEventDestroy(ev);
+    delete b;
+}
+
+static int ensure_batch_buffers(gm_batch* b, const gm_params* p) {
+    const size_t n = b->n, n2 = 2 * (size_t)b->n;
+    uint32_t last = b->stride > (uint32_t)p->mer ? b->stride - (uint32_t)p->mer : 0;
+    b->max_seeds = last / (uint32_t)p->jump + 2;
+    int rc = 0;
+    rc |= b->status.ensure(n); rc |= b->self_score.ensure(n * 4); rc |= b->min_score.ensure(n * 8); rc |= b->top_score.ensure(n * 4);
+    rc |= b->seeds.ensure(n2 * b->max_seeds * sizeof(GmSeed)); rc |= b->n_seeds.ensure(n2 * 2); rc |= b->n_entries.ensure(n2 * 4);
+    rc |= b->entry_off.ensure((n2 + 1) * 8); rc |= b->rs_overflow.ensure(n2); rc |= b->retry_list.ensure(n2 * 4);
+    rc |= b->retry_off.ensure((n2 + 1024) * 8);
+    rc |= b->hit_count.ensure(n * 4); rc |= b->hit_begin.ensure((n + 1) * 8); rc |= b->hit_cursor.ensure(n * 4);
+    rc |= b->counters.ensure(GMK_N * 8); rc |= b->small.ensure(64);
+    if (b->cand_cap < 32 * n + 1024) { b->cand_cap = (uint32_t)std::min<size_t>(32 * n + 1024, 0x7FFFFFFF); }
+    rc |= b->cands.ensure((size_t)b->cand_cap * sizeof(GmCand));
+    return rc ? GM_E_NOMEM : GM_OK;
+}
+
+static void fill_dev_batch(gm_batch* b) {
+    GmDevBatch& d = b->dev;
+    d.n = b->n; d.stride = b->stride; d.max_seeds = b->max_seeds; d.illumina_until = b->illumina_until;
+    d.bases = b->bases.as<uint8_t>(); d.quals = b->quals.as<uint8_t>(); d.len = b->len.as<uint16_t>();
+    d.status = b->status.as<int8_t>(); d.self_score = b->self_score.as<float>(); d.min_score = b->min_score.as<double>();
+    d.top_score = b->top_score.as<float>(); d.seeds = b->seeds.as<GmSeed>(); d.n_seeds = b->n_seeds.as<uint16_t>();
+    d.n_entries = b->n_entries.as<uint32_t>(); d.entry_off = b->entry_off.as<uint64_t>(); d.coords = b->coords.as<uint32_t>();
+    d.rs_overflow = b->rs_overflow.as<uint8_t>(); d.retry_list = b->retry_list.as<uint32_t>(); d.retry_off = b->retry_off.as<uint64_t>();
+    d.gtab_keys = b->gtab_keys.as<uint32_t>(); d.gtab_vals = b->gtab_vals.as<uint32_t>();
+    d.cands = b->cands.as<GmCand>(); d.cand_cap = b->cand_cap;
+    d.hit_count = b->hit_count.as<uint32_t>(); d.hit_begin = b->hit_begin.as<uint64_t>(); d.hit_cursor = b->hit_cursor.as<uint32_t>();
+    d.raw_hits = b->raw_hits.as<GmRawHit>(); d.raw_cap = b->raw_cap;
+    d.counters = b->counters.as<unsigned long long>();
+    d.n_cands = b->small.as<uint32_t>(); d.n_retry = b->small.as<uint32_t>() + 1;
+}
+
+extern "C" int gm_batch_upload(gm_batch* b, const gm_params* p, const gm_reads* r, void* stream) {
+    if (!b || !p || !r || !p->finalized) return GM_E_ARG;
+    if (r->n > b->max_reads || r->stride > 4096) { gm_set_error("batch larger than gm_batch_create allowed"); return GM_E_ARG; }
+    HIPCHK(hipSetDevice(b->ix->device));
+    hipStream_t st = S_(stream);
+    b->n = r->n; b->stride = r->stride; b->mapped = false;
+    size_t bytes = (size_t)r->n * r->stride;
+    if (b->bases.ensure(bytes + 16) || b->quals.ensure(bytes + 16) || b->len.ensure((size_t)r->n * 2 + 16)) return GM_E_NOMEM;
+    b->len_host.assign(r->len, r->len + r->n);
+    for (uint32_t i = 0; i < r->n; ++i)
+        if (r->len[i] > r->stride) { gm_set_error("read longer than stride"); return GM_E_ARG; }
+    // --illumina with automatic fallback (SeqReader.cpp:1171-1180): reads before the first one that shows a
+    // quality below '@' keep Phred+64, that read and all later ones use Phred+33
+    b->illumina_until = 0;
+    if (p->illumina) {
+        uint32_t until = r->n;
+        for (uint32_t i = 0; i < r->n && until == r->n; ++i) {
+            const uint8_t* q = r->quals + (size_t)i * r->stride;
+            for (uint32_t t = 0; t < r->len[i]; ++t) if (q[t] < 64) { until = i; break; }
+        }
+        b->illumina_until = until;
+    }
+    if (bytes) {
+        HIPCHK(hipMemcpyAsync(b->bases.p, r->bases, bytes, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(b->quals.p, r->quals, bytes, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(b->len.p, r->len, (size_t)r->n * 2, hipMemcpyHostToDevice, st));
+    }
+    int rc = ensure_batch_buffers(b, p);
+    if (rc) return rc;
+    fill_dev_batch(b);
+    return GM_OK;
+}
+
+extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b, void* stream) {
+    if (!ix || !p || !b || !p->finalized || b->ix != ix) return GM_E_ARG;
+    HIPCHK(hipSetDevice(ix->device));
+    hipStream_t st = S_(stream);
+    GmDevParams dp;
+    int rc = sync_params(ix, p, dp, st);
+    if (rc) return rc;
+    b->mapped = false;
+    if (b->n == 0) { b->n_cands = 0; b->n_raw = 0; b->mapped = true; memset(b->counters_host, 0, sizeof b->counters_host); return GM_OK; }
+    const int use_full = ix->full_sa ? 1 : 0;
+    fill_dev_batch(b);
+    HIPCHK(hipMemsetAsync(b->counters.p, 0, GMK_N * 8, st));
+    { KTimer t(b, GM_K_PREP, st); KCHK(gmk_prep(ix->dev, dp, b->dev, st)); }
+    { KTimer t(b, GM_K_SEED, st); KCHK(gmk_seed(ix->dev, dp, b->dev, st)); }
+    unsigned long long ctr[GMK_N];
+    if (!use_full) {
+        // faithful mode: locate every SA hit by LF walks into coords[] first (exact size from the seed kernel)
+        HIPCHK(hipMemcpyAsync(ctr, b->counters.p, sizeof ctr, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (b->coords.ensure((size_t)ctr[GMK_SA_HITS] * 4 + 64)) return GM_E_NOMEM;
+        fill_dev_batch(b);
+        KCHK(gmk_scan_entries(b->dev, st));
+        { KTimer t(b, GM_K_LOCATE, st); KCHK(gmk_locate_sampled(ix->dev, b->dev, st)); }
+    }
+    for (int attempt = 0;; ++attempt) {
+        HIPCHK(hipMemsetAsync(b->small.p, 0, 64, st));
+        HIPCHK(hipMemsetAsync(b->rs_overflow.p, 0, 2 * (size_t)b->n, st));
+        HIPCHK(hipMemsetAsync(b->counters.as<unsigned long long>() + GMK_HEAVY_SLOTS, 0, 8, st));
+        HIPCHK(hipMemsetAsync(b->counters.as<unsigned long long>() + GMK_OVERFLOW_RS, 0, 8, st));
+        { KTimer t(b, GM_K_VOTE, st); KCHK(gmk_vote(ix->dev, dp, b->dev, use_full, st)); }
+        uint32_t small[2];
+        HIPCHK(hipMemcpyAsync(small, b->small.p, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(ctr, b->counters.p, sizeof ctr, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (ctr[GMK_BAD_QUAL]) { gm_set_error("Invalid Fastq Character? (negative base probability)"); return GM_E_BAD_QUAL; }
+        uint32_t n_cands = small[0], n_retry = small[1];
+        if (n_retry && n_cands <= b->cand_cap) {
+            size_t slots = (size_t)ctr[GMK_HEAVY_SLOTS];
+            if (b->gtab_keys.ensure(slots * 4) || b->gtab_vals.ensure(slots * 4)) return GM_E_NOMEM;
+            fill_dev_batch(b);
+            HIPCHK(hipMemsetAsync(b->gtab_keys.p, 0xFF, slots * 4, st));
+            HIPCHK(hipMemsetAsync(b->gtab_vals.p, 0, slots * 4, st));
+            { KTimer t(b, GM_K_VOTE_RETRY, st); KCHK(gmk_vote_retry(ix->dev, dp, b->dev, use_full, n_retry, st)); }
+            HIPCHK(hipMemcpyAsync(small, b->small.p, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            n_cands = small[0];
+        }
+        if (n_cands > b->cand_cap) {                    // candidate list too small: grow and vote again
+            if (attempt > 8) { gm_set_error("candidate list keeps overflowing"); return GM_E_NOMEM; }
+            size_t want = std::min<size_t>((size_t)n_cands + n_cands / 4 + 1024, 0x7FFFFFFFu);
+            if ((size_t)n_cands > 0x7FFFFFFFu) { gm_set_error("too many candidates in one batch; use smaller batches"); return GM_E_CAPACITY; }
+            b->cand_cap = (uint32_t)want;
+            if (b->cands.ensure((size_t)b->cand_cap * sizeof(GmCand))) return GM_E_NOMEM;
+            fill_dev_batch(b);
+            continue;
+        }
+        b->n_cands = n_cands;
+        break;
+    }
+    if (b->raw_cap < b->n_cands + 16ull) b->raw_cap = b->n_cands + 16ull;
+    if (b->raw_hits.ensure(b->raw_cap * sizeof(GmRawHit))) return GM_E_NOMEM;
+    fill_dev_batch(b);
+    { KTimer t(b, GM_K_NW, st); KCHK(gmk_nw(ix->dev, dp, b->dev, st)); }
+    { KTimer t(b, GM_K_COMPACT, st); KCHK(gmk_compact(b->dev, st)); }
+    b->mapped = true;
+    return GM_OK;
+}
+
+extern "C" int gm_batch_counters(gm_batch* b, gm_counters* o) {
+    if (!b || !o) return GM_E_ARG;
+    HIPCHK(hipSetDevice(b->ix->device));
+    unsigned long long c[GMK_N];
+    HIPCHK(hipMemcpy(c, b->counters.p, sizeof c, hipMemcpyDeviceToHost));
+    memset(o, 0, sizeof *o);
+    o->reads = b->n; o->kmers_searched = c[GMK_KMERS]; o->occ_calls = c[GMK_OCC]; o->occ_blocks = c[GMK_OCC_BLOCKS];
+    o->seeds_used = c[GMK_SEEDS]; o->sa_hits = c[GMK_SA_HITS];
+    o->lf_steps = c[GMK_LF_STEPS]; o->candidates = b->n_cands; o->nw_cells = c[GMK_NW_CELLS]; o->accepted = c[GMK_ACCEPTED];
+    o->vote_retries = c[GMK_OVERFLOW_RS];
+    return GM_OK;
+}
+
+extern "C" const char* gm_kernel_name(int which) {
+    static const char* names[GM_K_COUNT] = { "k_prep", "k_seed", "k_locate_sampled", "k_vote", "k_vote_retry", "k_nw", "k_compact(scan+scatter)" };
+    return which >= 0 && which < GM_K_COUNT ? names[which] : "?";
+}
+
+extern "C" int gm_batch_set_profiling(gm_batch* b, int on) {
+    if (!b) return GM_E_ARG;
+    b->profiling = on != 0;
+    return GM_OK;
+}
+
+extern "C" int gm_batch_kernel_times(gm_batch* b, double* ms, uint64_t* launches) {
+    if (!b || !ms || !launches) return GM_E_ARG;
+    HIPCHK(hipSetDevice(b->ix->device));
+    for (auto& ev : b->pending) {
+        HIPCHK(hipEventSynchronize(ev.b));
+        float t = 0;
+        HIPCHK(hipEventElapsedTime(&t, ev.a, ev.b));
+        b->k_ms[ev.which] += t; b->k_launches[ev.which] += 1;
+        b->pool.push_back(ev.a); b->pool.push_back(ev.b);
+    }
+    b->pending.clear();
+    for (int i = 0; i < GM_K_COUNT; ++i) { ms[i] = b->k_ms[i]; launches[i] = b->k_launches[i]; b->k_ms[i] = 0; b->k_launches[i] = 0; }
+    return GM_OK;
+}
+
+static bool raw_less(const GmRawHit& a, const GmRawHit& b) {
+    if (a.strand != b.strand) return a.strand < b.strand;       // POS pass first (Driver.cpp:506-556)
+    if (a.step != b.step) return a.step < b.step;               // seed order (align_sequence loop)
+    return a.pos < b.pos;                                       // std::map<unsigned long,int> order (process_hits)
+}
+
+struct RawDownload {
+    std::vector<GmRawHit> hits;
+    std::vector<uint64_t> begin;
+    std::vector<int8_t> status;
+    std::vector<float> self_score, top;
+};
+
+static int download_raw(gm_batch* b, RawDownload& r, hipStream_t st, bool no_nw) {
+    if (!b->mapped) { gm_set_error("batch has not been mapped"); return GM_E_ARG; }
+    const uint32_t n = b->n;
+    r.begin.assign(n + 1, 0); r.status.assign(n, 0); r.self_score.assign(n, 0); r.top.assign(n, 0);
+    if (n == 0) return GM_OK;
+    HIPCHK(hipMemcpyAsync(r.begin.data(), b->hit_begin.p, (n + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(r.status.data(), b->status.p, n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(r.self_score.data(), b->self_score.p, n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(r.top.data(), b->top_score.p, n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    uint64_t total = r.begin[n];
+    if (total > b->raw_cap) { gm_set_error("internal: raw hit buffer too small"); return GM_E_CAPACITY; }
+    r.hits.resize(total);
+    if (total) HIPCHK(hipMemcpy(r.hits.data(), b->raw_hits.p, total * sizeof(GmRawHit), hipMemcpyDeviceToHost));
+    b->n_raw = total;
+    for (uint32_t i = 0; i < n; ++i) {
+        auto first = r.hits.begin() + (ptrdiff_t)r.begin[i], last = r.hits.begin() + (ptrdiff_t)r.begin[i + 1];
+        if (no_nw) std::sort(first, last, [](const GmRawHit& a, const GmRawHit& c) { return a.strand != c.strand ? a.strand < c.strand : a.pos < c.pos; });
+        else std::sort(first, last, raw_less);
+    }
+    return GM_OK;
+}
+
+extern "C" int gm_batch_raw_hits(gm_batch* b, gm_raw_hit* out, uint64_t cap, uint64_t* n_out, int8_t* status, float* self_score, float* top_score) {
+    if (!b || !n_out) return GM_E_ARG;
+    HIPCHK(hipSetDevice(b->ix->device));
+    RawDownload r;
+    int rc = download_raw(b, r, nullptr, false);
+    if (rc) return rc;
+    *n_out = r.hits.size();
+    if (status) memcpy(status, r.status.data(), b->n);
+    if (self_score) memcpy(self_score, r.self_score.data(), (size_t)b->n * 4);
+    if (top_score) memcpy(top_score, r.top.data(), (size_t)b->n * 4);
+    if (r.hits.size() > cap) return GM_E_CAPACITY;
+    static_assert(sizeof(gm_raw_hit) == sizeof(GmRawHit), "layout");
+    if (out && !r.hits.empty()) memcpy(out, r.hits.data(), r.hits.size() * sizeof(GmRawHit));
+    return GM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gm_map_batch: kernels + the reference's unique-map bookkeeping (process_hits :102-165, set_top_matches :506-610)
+// ------------------------------------------------------------------------------------------------
+static inline char comp_base(char c) {      // reverse_comp SequenceOperations.h:56-96 on a lowercase acgt window
+    switch (c) { case 'a': return 't'; case 't': return 'a'; case 'c': return 'g'; case 'g': return 'c'; default: return 'n'; }
+}
+
+struct HostMatch {
+    float score; uint64_t first_pos; uint8_t first_strand;
+    std::set<std::pair<uint64_t, int>> positions;
+};
+
+extern "C" int gm_map_batch(gm_index* ix, const gm_params* p, gm_batch* b, const gm_reads* reads, gm_hits* out, void* stream) {
+    if (!ix || !p || !b || !reads || !out) return GM_E_ARG;
+    int rc = gm_batch_upload(b, p, reads, stream);
+    if (rc) return rc;
+    rc = gm_map_batch_device(ix, p, b, stream);
+    if (rc) return rc;
+    RawDownload r;
+    rc = download_raw(b, r, S_(stream), !p->nw);
+    if (rc) return rc;
+    const uint32_t n = b->n;
+    out->n = n;
+    std::vector<gm_match> matches;
+    std::vector<gm_pos> positions;
+    std::vector<uint64_t> mbegin(n + 1, 0);
+    std::string w, key;
+    for (uint32_t i = 0; i < n; ++i) {
+        mbegin[i] = matches.size();
+        out->status[i] = r.status[i];
+        out->self_score[i] = r.self_score[i];
+        out->denominator[i] = 0;
+        out->top_score[i] = r.status[i] == GM_READ_TOO_SHORT ? -2.0 : r.status[i] == GM_READ_TOO_POOR ? -3.0 : 0.0;
+        if (r.status[i] != 0) continue;
+        const uint32_t L = b->len_host[i];
+        std::map<std::string, HostMatch> uniq;
+        double den = 0.0;
+        bool too_many = false;
+        w.resize(L); key.resize(L);
+        int cur_strand = -1; bool strand_stopped = false;
+        for (uint64_t hidx = r.begin[i]; hidx < r.begin[i + 1] && !too_many; ++hidx) {
+            const GmRawHit& h = r.hits[hidx];
+            if ((int)h.strand != cur_strand) { cur_strand = h.strand; strand_stopped = false; }
+            if (strand_stopped) continue;
+            if (!host_window(ix->h, h.pos, L, &w[0])) continue;       // cannot happen: the kernel checked it
+            if (h.strand == GM_NEG_STRAND) { for (uint32_t t = 0; t < L; ++t) key[t] = comp_base(w[L - 1 - t]); }
+            else key = w;
+            auto it = uniq.find(key);
+            if (it == uniq.end()) {
+                HostMatch m; m.score = h.score; m.first_pos = h.pos; m.first_strand = h.strand;
+                m.positions.insert({ h.pos, (int)h.strand });
+                uniq.emplace(key, std::move(m));
+                den += exp((double)h.score);
+            } else {
+                if (p->unique_only) {
+                    if (p->nw) too_many = true;                       // align_sequence returns false -> READ_TOO_MANY
+                    else strand_stopped = true;                       // --no_nw ignores the return value (:317-325)
+                    continue;
+                }
+                if (it->second.positions.insert({ h.pos, (int)h.strand }).second) den += exp((double)h.score);
+            }
+        }
+        if (p->nw && uniq.size() > p->max_matches) too_many = true;   // :299-306 (the map only grows, so the last check decides)
+        if (too_many) { out->status[i] = GM_READ_TOO_MANY; out->top_score[i] = 999999.0; continue; }
+        if (uniq.empty()) { out->status[i] = GM_READ_NONE; continue; }
+        out->denominator[i] = den;
+        out->top_score[i] = (double)r.top[i];
+        for (auto& kv : uniq) {
+            gm_match m;
+            m.read = i; m.score = kv.second.score; m.first_pos = kv.second.first_pos; m.first_strand = kv.second.first_strand;
+            m.pos_begin = (uint32_t)positions.size();
+            for (auto& ps : kv.second.positions) { gm_pos q; q.pos = ps.first; q.strand = (uint8_t)ps.second; positions.push_back(q); }
+            m.pos_end = (uint32_t)positions.size();
+            matches.push_back(m);
+        }
+    }
+    mbegin[n] = matches.size();
+    uint64_t need_m = matches.size(), need_p = positions.size();
+    bool fits = need_m <= out->matches_cap && need_p <= out->positions_cap;
+    if (!fits) { out->matches_cap = need_m; out->positions_cap = need_p; gm_set_error("output buffers too small"); return GM_E_CAPACITY; }
+    memcpy(out->match_begin, mbegin.data(), (n + 1) * 8);
+    if (need_m) memcpy(out->matches, matches.data(), need_m * sizeof(gm_match));
+    if (need_p) memcpy(out->positions, positions.data(), need_p * sizeof(gm_pos));
+    return GM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gm_output_batch: traceback on the device, posterior / MAPQ / CIGAR on the host, coverage deposit on the device
+// ------------------------------------------------------------------------------------------------
+static std::string ops_to_cigar(const uint8_t* ops, uint32_t n) {     // run lengths, as bin_seq.cpp:578-698 builds them
+    std::string s;
+    uint32_t i = 0;
+    while (i < n) {
+        uint32_t j = i;
+        while (j < n && ops[j] == ops[i]) ++j;
+        s += std::to_string(j - i);
+        s += (char)ops[i];
+        i = j;
+    }
+    return s;
+}
+
+static void fix_cigar_for_deletions(std::string& c) {                  // SequenceOperations.h:32-42
+    if (c.empty() || c.back() != 'D') return;
+    int i;
+    for (i = (int)c.size() - 2; i >= 0; --i) if (!isdigit((unsigned char)c[i])) break;
+    c = c.substr(0, (size_t)(i + 1));
+}
+
+extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, const gm_reads* reads, const gm_hits* hits, gm_sam_out* out, void* stream) {
+    if (!ix || !p || !b || !reads || !hits || !out) return GM_E_ARG;
+    if (hits->n != b->n) { gm_set_error("hits do not belong to the batch"); return GM_E_ARG; }
+    HIPCHK(hipSetDevice(ix->device));
+    hipStream_t st = S_(stream);
+    GmDevParams dp;
+    int rc = sync_params(ix, p, dp, st);
+    if (rc) return rc;
+    const uint32_t n = hits->n;
+    const uint64_t n_m = hits->match_begin[n];
+    out->n_recs = 0; out->cigar_len = 0;
+    if (n_m == 0) return GM_OK;
+    // one traceback per ScoredSeq, oriented by its first strand (NormalScoredSeq::score, ScoredSeq::get_SAM)
+    std::vector<GmCand> items(n_m);
+    for (uint64_t m = 0; m < n_m; ++m) {
+        const gm_match& mm = hits->matches[m];
+        items[m].rs = mm.read * 2 + mm.first_strand; items[m].b = (uint32_t)mm.first_pos; items[m].step = 0; items[m].flags = 0; items[m].pad = 0; items[m].score = 0;
+    }
+    const uint32_t ops_stride = 2 * ((b->stride + 7u) & ~7u) + 8;
+    if (b->tb_items.ensure(n_m * sizeof(GmCand)) || b->tb_ops.ensure(n_m * ops_stride) || b->tb_len.ensure(n_m * 2)) return GM_E_NOMEM;
+    HIPCHK(hipMemcpyAsync(b->tb_items.p, items.data(), n_m * sizeof(GmCand), hipMemcpyHostToDevice, st));
+    fill_dev_batch(b);
+    KCHK(gmk_traceback(ix->dev, dp, b->dev, b->tb_items.as<GmCand>(), (uint32_t)n_m, b->tb_ops.as<uint8_t>(), ops_stride, b->tb_len.as<uint16_t>(), st));
+    std::vector<uint8_t> ops(n_m * ops_stride);
+    std::vector<uint16_t> ops_len(n_m);
+    HIPCHK(hipMemcpyAsync(ops.data(), b->tb_ops.p, ops.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(ops_len.data(), b->tb_len.p, n_m * 2, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<gm_sam_rec> recs;
+    std::string pool;
+    std::vector<uint64_t> dpos; std::vector<uint32_t> dspan; std::vector<float> dw;
+    uint32_t max_span = 0;
+    auto emit = [&](uint32_t read, const gm_match& mm, uint64_t midx, double den) {
+        double total = exp((double)mm.score) / den;                    // ScoredSeq.h:300
+        int mapq;
+        if (total == 1) mapq = 30; else mapq = (int)round(-10 * log(1 - total) / log(10));
+        if (mapq > 30) mapq = 30;
+        std::string cigar;
+        if (p->nw) {
+            cigar = ops_to_cigar(&ops[midx * ops_stride], ops_len[midx]);
+            if (cigar.empty()) cigar = "*"; else fix_cigar_for_deletions(cigar);
+        } else {
+            cigar = std::to_string(b->len_host[read]) + "M";
+        }
+        uint32_t off = (uint32_t)pool.size();
+        pool += cigar; pool.push_back('\0');
+        for (uint32_t q = mm.pos_begin; q < mm.pos_end; ++q) {
+            gm_sam_rec s;
+            memset(&s, 0, sizeof s);
+            s.read = read; s.pos = hits->positions[q].pos; s.strand = hits->positions[q].strand;
+            s.contig = host_pos2rid(ix->h, s.pos);
+            int base = (int)(s.pos - ix->h.contigs[s.contig].offset);     // int chr_base_pos, GenomeBwt.cpp:632
+            s.chr_pos = (uint64_t)(unsigned long)base + 1;
+            s.mapq = mapq; s.a_score = mm.score; s.post_prob = (float)total; s.sim_matches = (int32_t)(mm.pos_end - mm.pos_begin);
+            s.cigar_off = off;
+            recs.push_back(s);
+        }
+    };
+    for (uint32_t i = 0; i < n; ++i) {
+        if (hits->status[i] != GM_READ_OK) continue;
+        const double den = hits->denominator[i];
+        int64_t best = -1;
+        double best_log = exp(-1.0);                                   // the empty NormalScoredSeq, ScoredSeq.h:117-120
+        for (uint64_t m = hits->match_begin[i]; m < hits->match_begin[i + 1]; ++m) {
+            const gm_match& mm = hits->matches[m];
+            double lg = exp((double)mm.score);
+            float wgt = (float)(lg / den);                             // AddScore(const float& amt), NormalScoredSeq.cpp:70
+            for (uint32_t q = mm.pos_begin; q < mm.pos_end; ++q) {
+                dpos.push_back(hits->positions[q].pos); dspan.push_back(ops_len[m]); dw.push_back(wgt);
+                max_span = std::max<uint32_t>(max_span, ops_len[m]);
+            }
+            if (p->print_all_sam) emit(i, mm, m, den);
+            if (lg > best_log) { best = (int64_t)m; best_log = lg; }  // is_greater: strict, first in key order wins
+        }
+        if (!p->print_all_sam && best >= 0 && (double)hits->matches[best].score > hits->top_score[i] - 0.00001)   // Driver.cpp:695
+            emit(i, hits->matches[best], (uint64_t)best, den);
+    }
+    if (ix->cov_bins && !dpos.empty()) {
+        size_t nd = dpos.size();
+        if (b->dep_pos.ensure(nd * 8) || b->dep_span.ensure(nd * 4) || b->dep_w.ensure(nd * 4)) return GM_E_NOMEM;
+        HIPCHK(hipMemcpyAsync(b->dep_pos.p, dpos.data(), nd * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(b->dep_span.p, dspan.data(), nd * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(b->dep_w.p, dw.data(), nd * 4, hipMemcpyHostToDevice, st));
+        KCHK(gmk_coverage_add(ix->d_cov.as<float>(), ix->cov_bins, ix->cov_bin_size, b->dep_pos.as<uint64_t>(), b->dep_span.as<uint32_t>(),
+                              b->dep_w.as<float>(), (uint32_t)nd, max_span, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    bool fits = recs.size() <= out->recs_cap && pool.size() <= out->cigar_cap;
+    out->n_recs = recs.size(); out->cigar_len = pool.size();
+    if (!fits) { out->recs_cap = recs.size(); out->cigar_cap = pool.size(); gm_set_error("output buffers too small"); return GM_E_CAPACITY; }
+    if (!recs.empty()) memcpy(out->recs, recs.data(), recs.size() * sizeof(gm_sam_rec));
+    if (!pool.empty()) memcpy(out->cigar_pool, pool.data(), pool.size());
+    return GM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// unit-level device entry points
+// ------------------------------------------------------------------------------------------------
+extern "C" int gm_dev_sa_interval(gm_index* ix, const char* kmers, uint32_t n, uint32_t m, uint64_t* start, uint64_t* end) {
+    if (!ix || !kmers || !start || !end || m == 0) return GM_E_ARG;
+    if (ix->host_only) return GM_E_NO_DEVICE;
+    HIPCHK(hipSetDevice(ix->device));
+    DevBuf dk, ds, de;
+    if (dk.ensure((size_t)n * m) || ds.ensure((size_t)n * 4) || de.ensure((size_t)n * 4)) return GM_E_NOMEM;
+    int rc = GM_OK;
+    std::vector<uint32_t> s(n), e(n);
+    do {
+        if (hipMemcpy(dk.p, kmers, (size_t)n * m, hipMemcpyHostToDevice) != hipSuccess) { rc = GM_E_HIP; break; }
+        if (gmk_sa_interval(ix->dev, dk.as<uint8_t>(), n, m, ds.as<uint32_t>(), de.as<uint32_t>(), nullptr)) { rc = GM_E_HIP; break; }
+        if (hipMemcpy(s.data(), ds.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = GM_E_HIP; break; }
+        if (hipMemcpy(e.data(), de.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = GM_E_HIP; break; }
+    } while (0);
+    dk.release(); ds.release(); de.release();
+    if (rc) { gm_set_error("gm_dev_sa_interval: HIP failure"); return rc; }
+    for (uint32_t i = 0; i < n; ++i) { start[i] = s[i]; end[i] = e[i]; }
+    return GM_OK;
+}
+
+extern "C" int gm_dev_locate(gm_index* ix, const uint64_t* ranks, uint32_t n, int use_full_sa, uint64_t* out) {
+    if (!ix || !ranks || !out) return GM_E_ARG;
+    if (ix->host_only) return GM_E_NO_DEVICE;
+    if (use_full_sa && !ix->full_sa) { gm_set_error("index was opened without GM_INDEX_FULL_SA"); return GM_E_ARG; }
+    HIPCHK(hipSetDevice(ix->device));
+    std::vector<uint32_t> r32(n), o32(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (ranks[i] == 0 || ranks[i] > ix->h.seq_len) { gm_set_error("rank out of range"); return GM_E_ARG; }
+        r32[i] = (uint32_t)ranks[i];
+    }
+    DevBuf dr, dout;
+    if (dr.ensure((size_t)n * 4) || dout.ensure((size_t)n * 4)) return GM_E_NOMEM;
+    int rc = GM_OK;
+    do {
+        if (hipMemcpy(dr.p, r32.data(), (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = GM_E_HIP; break; }
+        if (gmk_locate(ix->dev, dr.as<uint32_t>(), n, use_full_sa, dout.as<uint32_t>(), nullptr)) { rc = GM_E_HIP; break; }
+        if (hipMemcpy(o32.data(), dout.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = GM_E_HIP; break; }
+    } while (0);
+    dr.release(); dout.release();
+    if (rc) { gm_set_error("gm_dev_locate: HIP failure"); return rc; }
+    for (uint32_t i = 0; i < n; ++i) out[i] = o32[i];
+    return GM_OK;
+}
+
+static int unit_batch(gm_index* ix, const gm_params* p, const gm_reads* reads, gm_batch** bo, GmDevParams& dp) {
+    gm_batch* b = nullptr;
+    int rc = gm_batch_create(ix, reads->n ? reads->n : 1, reads->stride ? reads->stride : 1, &b);
+    if (rc) return rc;
+    rc = gm_batch_upload(b, p, reads, nullptr);
+    if (!rc) rc = sync_params(ix, p, dp, nullptr);
+    if (!rc) {
+        if (hipMemsetAsync(b->counters.p, 0, GMK_N * 8, nullptr) != hipSuccess || hipMemsetAsync(b->small.p, 0, 64, nullptr) != hipSuccess ||
+            hipMemsetAsync(b->rs_overflow.p, 0, 2 * (size_t)b->n, nullptr) != hipSuccess || gmk_prep(ix->dev, dp, b->dev, nullptr)) rc = GM_E_HIP;
+    }
+    if (rc) { gm_batch_destroy(b); return rc; }
+    *bo = b;
+    return GM_OK;
+}
+
+extern "C" int gm_dev_nw_score(gm_index* ix, const gm_params* p, const gm_reads* reads, const uint32_t* read_idx, const uint8_t* strand,
+                               const uint64_t* pos, uint32_t n, float* score, uint8_t* valid) {
+    if (!ix || !p || !reads || !read_idx || !strand || !pos || !score || !p->finalized) return GM_E_ARG;
+    if (ix->host_only) return GM_E_NO_DEVICE;
+    HIPCHK(hipSetDevice(ix->device));
+    gm_batch* b; GmDevParams dp;
+    int rc = unit_batch(ix, p, reads, &b, dp);
+    if (rc) return rc;
+    std::vector<GmCand> c(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (read_idx[i] >= reads->n || pos[i] > 0xFFFFFFFFull) { gm_batch_destroy(b); return GM_E_ARG; }
+        c[i].rs = read_idx[i] * 2 + (strand[i] ? 1 : 0); c[i].b = (uint32_t)pos[i]; c[i].step = 0; c[i].flags = 0; c[i].pad = 0; c[i].score = 0;
+    }
+    do {
+        b->cand_cap = std::max<uint32_t>(b->cand_cap, n);
+        if (b->cands.ensure((size_t)b->cand_cap * sizeof(GmCand))) { rc = GM_E_NOMEM; break; }
+        fill_dev_batch(b);
+        if (n && hipMemcpy(b->cands.p, c.data(), (size_t)n * sizeof(GmCand), hipMemcpyHostToDevice) != hipSuccess) { rc = GM_E_HIP; break; }
+        if (hipMemcpy(b->small.p, &n, 4, hipMemcpyHostToDevice) != hipSuccess) { rc = GM_E_HIP; break; }
+        if (gmk_nw(ix->dev, dp, b->dev, nullptr)) { rc = GM_E_HIP; break; }
+        if (n && hipMemcpy(c.data(), b->cands.p, (size_t)n * sizeof(GmCand), hipMemcpyDeviceToHost) != hipSuccess) { rc = GM_E_HIP; break; }
+    } while (0);
+    gm_batch_destroy(b);
+    if (rc) { gm_set_error("gm_dev_nw_score: HIP failure"); return rc; }
+    for (uint32_t i = 0; i < n; ++i) { score[i] = c[i].score; if (valid) valid[i] = (c[i].flags & GMC_VALID) ? 1 : 0; }
+    return GM_OK;
+}
+
+extern "C" int gm_dev_traceback(gm_index* ix, const gm_params* p, const gm_reads* reads, const uint32_t* read_idx, const uint8_t* strand,
+                                const uint64_t* pos, uint32_t n, char* ops, uint32_t ops_stride, uint16_t* ops_len) {
+    if (!ix || !p || !reads || !read_idx || !strand || !pos || !ops || !ops_len || !p->finalized) return GM_E_ARG;
+    if (ix->host_only) return GM_E_NO_DEVICE;
+    HIPCHK(hipSetDevice(ix->device));
+    gm_batch* b; GmDevParams dp;
+    int rc = unit_batch(ix, p, reads, &b, dp);
+    if (rc) return rc;
+    std::vector<GmCand> c(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (read_idx[i] >= reads->n || pos[i] > 0xFFFFFFFFull) { gm_batch_destroy(b); return GM_E_ARG; }
+        c[i].rs = read_idx[i] * 2 + (strand[i] ? 1 : 0); c[i].b = (uint32_t)pos[i]; c[i].step = 0; c[i].flags = 0; c[i].pad = 0; c[i].score = 0;
+    }
+    do {
+        if (b->tb_items.ensure((size_t)n * sizeof(GmCand) + 16) || b->tb_ops.ensure((size_t)n * ops_stride + 16) || b->tb_len.ensure((size_t)n * 2 + 16)) { rc = GM_E_NOMEM; break; }
+        if (n && hipMemcpy(b->tb_items.p, c.data(), (size_t)n * sizeof(GmCand), hipMemcpyHostToDevice) != hipSuccess) { rc = GM_E_HIP; break; }
+        if (n && hipMemset(b->tb_ops.p, 0, (size_t)n * ops_stride) != hipSuccess) { rc = GM_E_HIP; break; }
+        if (gmk_traceback(ix->dev, dp, b->dev, b->tb_items.as<GmCand>(), n, b->tb_ops.as<uint8_t>(), ops_stride, b->tb_len.as<uint16_t>(), nullptr)) { rc = GM_E_HIP; break; }
+        if (n && hipMemcpy(ops, b->tb_ops.p, (size_t)n * ops_stride, hipMemcpyDeviceToHost) != hipSuccess) { rc = GM_E_HIP; break; }
+        if (n && hipMemcpy(ops_len, b->tb_len.p, (size_t)n * 2, hipMemcpyDeviceToHost) != hipSuccess) { rc = GM_E_HIP; break; }
+    } while (0);
+    gm_batch_destroy(b);
+    if (rc) { gm_set_error("gm_dev_traceback: HIP failure"); return rc; }
+    return GM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// coverage track
+// ------------------------------------------------------------------------------------------------
+extern "C" int gm_coverage_reset(gm_index* ix, uint32_t bin_size) {
+    if (!ix || bin_size == 0) return GM_E_ARG;
+    if (ix->host_only) return GM_E_NO_DEVICE;
+    HIPCHK(hipSetDevice(ix->device));
+    uint64_t bins = ix->h.l_pac / bin_size + 64;        // the reference allocates l_pac/gGEN_SIZE floats and writes a little past it
+    if (ix->d_cov.ensure(bins * 4)) return GM_E_NOMEM;
+    HIPCHK(hipMemset(ix->d_cov.p, 0, bins * 4));
+    ix->cov_bins = bins; ix->cov_bin_size = bin_size;
+    return GM_OK;
+}
+
+extern "C" uint64_t gm_coverage_bins(const gm_index* ix) { return ix ? ix->cov_bins : 0; }
+extern "C" void* gm_coverage_device_ptr(gm_index* ix) { return ix ? ix->d_cov.p : nullptr; }
+
+extern "C" int gm_coverage_add(gm_index* ix, const uint64_t* pos, const uint32_t* span, const float* w, uint32_t n, void* stream) {
+    if (!ix || !pos || !span || !w) return GM_E_ARG;
+    if (!ix->cov_bins) { gm_set_error("coverage track not initialised (gm_coverage_reset)"); return GM_E_ARG; }
+    HIPCHK(hipSetDevice(ix->device));
+    if (n == 0) return GM_OK;
+    DevBuf dp_, ds_, dw_;
+    if (dp_.ensure((size_t)n * 8) || ds_.ensure((size_t)n * 4) || dw_.ensure((size_t)n * 4)) return GM_E_NOMEM;
+    uint32_t max_span = 0;
+    for (uint32_t i = 0; i < n; ++i) max_span = std::max(max_span, span[i]);
+    int rc = GM_OK;
+    hipStream_t st = S_(stream);
+    do {
+        if (hipMemcpyAsync(dp_.p, pos, (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess) { rc = GM_E_HIP; break; }
+        if (hipMemcpyAsync(ds_.p, span, (size_t)n * 4, hipMemcpyHostToDevice, st) != hipSuccess) { rc = GM_E_HIP; break; }
+        if (hipMemcpyAsync(dw_.p, w, (size_t)n * 4, hipMemcpyHostToDevice, st) != hipSuccess) { rc = GM_E_HIP; break; }
+        if (gmk_coverage_add(ix->d_cov.as<float>(), ix->cov_bins, ix->cov_bin_size, dp_.as<uint64_t>(), ds_.as<uint32_t>(), dw_.as<float>(), n, max_span, st)) { rc = GM_E_HIP; break; }
+        if (hipStreamSynchronize(st) != hipSuccess) { rc = GM_E_HIP; break; }
+    } while (0);
+    dp_.release(); ds_.release(); dw_.release();
+    if (rc) gm_set_error("gm_coverage_add: HIP failure");
+    return rc;
+}
+
+extern "C" int gm_coverage_download(gm_index* ix, float* host) {
+    if (!ix || !host || !ix->cov_bins) return GM_E_ARG;
+    HIPCHK(hipSetDevice(ix->device));
+    HIPCHK(hipMemcpy(host, ix->d_cov.p, ix->cov_bins * 4, hipMemcpyDeviceToHost));
+    return GM_OK;
+}
+
+extern "C" int gm_coverage_write_sgr(gm_index* ix, const float* bins, const char* path, int append) {
+    // GenomeBwt::PrintFinalSGR src/GenomeBwt.cpp:1212-1273: bins run over the CONCATENATED coordinate
+    if (!ix || !bins || !path || !ix->cov_bin_size) return GM_E_ARG;
+    FILE* f = fopen(path, append ? "a" : "w");
+    if (!f) { gm_set_error(std::string("cannot write ") + path); return GM_E_IO; }
+    const GmHostIndex& h = ix->h;
+    const uint64_t bs = ix->cov_bin_size;
+    uint64_t count = 0;
+    for (size_t i = 0; i < h.contigs.size(); ++i) {
+        uint64_t next = i + 1 < h.contigs.size() ? h.contigs[i + 1].offset : h.l_pac;
+        for (; count < next; count += bs)
+            if ((double)bins[count / bs] > 0.001)     // MIN_PRINT, GenomeBwt.cpp:928
+                fprintf(f, "%s\t%ld\t%.5f\n", h.contigs[i].name.c_str(), (long)(count - h.contigs[i].offset) + 1, bins[count / bs]);
+    }
+    fclose(f);
+    return GM_OK;
+}

@@ -1,0 +1,102 @@
+// gm_internal.h — structures shared by the HIP kernels (gm_kernels.hip) and the host side of libgnumap_hip.
+// Nothing here is part of the public ABI (include/gnumap_hip.h).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+// ---- HBM-resident index, passed to kernels by value -------------------------------------------------
+// bwt      : the occ-interleaved BWT exactly as <fa>.gnumap.bwt stores it: one 64-byte block per 128 bases
+//            = 4 x u64 cumulative counts (A,C,G,T before the block) + 8 x u32 of 16 bases, MSB first
+//            (reference: bwt_bwtupdate_core src/bwtindex.c:128-150, bwt_occ_intv inc/bwt.h:73)
+// sa_samples: rank-sampled suffix array (every 32nd rank), narrowed to u32; [0] = 0xFFFFFFFF (= (u64)-1 mod 2^32)
+// full_sa  : optional full suffix array SA[0..seq_len], u32, expanded on device from the samples
+// pac      : 2 bit/base, 4 per byte MSB first (reference: _get_pac src/bntseq.c:225)
+struct GmDevIndex {
+    const uint32_t* bwt;
+    const uint32_t* sa_samples;
+    const uint32_t* full_sa;
+    const uint8_t* pac;
+    const uint32_t* contig_off;     // n_seqs + 1 offsets, last = l_pac
+    uint32_t seq_len, primary, l_pac, n_seqs;
+    uint32_t sa_mask, sa_shift;     // sa_intv - 1, log2(sa_intv)
+    uint32_t L2[5];
+};
+
+struct GmDevParams {
+    int mer, jump, kmin, nw, fast, pos_strand, neg_strand, align_is_fraction;
+    uint32_t hcap;
+    float gap, align_score, cutoff;
+    const float* S256;              // gALIGN_SCORES, 256 x 4, in HBM: the self score indexes it with the FASTQ characters,
+                                    // the DP with rows 'a','c','g','t' (genome windows are lowercase acgt)
+    const float2* lut;              // [0..255] Phred+33, [256..511] Phred+64: (p, (1-p)/3) as fp32; p = NaN when negative
+};
+
+struct GmSeed { uint32_t k, l, pos; };
+
+// flags of GmCand
+enum { GMC_VALID = 1, GMC_ACCEPT = 2 };
+struct GmCand {
+    uint32_t rs;                    // read * 2 + strand
+    uint32_t b;                     // candidate window start on the concatenated reference
+    uint16_t step;                  // seed index at which the vote count reached kmin (NW order of the reference)
+    uint8_t flags, pad;
+    float score;                    // NW score, or the vote count with --no_nw
+};
+
+struct GmRawHit { uint32_t read; uint32_t pos; float score; uint16_t step; uint8_t strand; uint8_t pad; };
+
+// device-side counters, one u64 each (see gm_counters in the public header)
+enum {
+    GMK_KMERS = 0, GMK_OCC, GMK_SEEDS, GMK_SA_HITS, GMK_LF_STEPS, GMK_CANDS, GMK_NW_CELLS, GMK_ACCEPTED,
+    GMK_OVERFLOW_RS, GMK_BAD_QUAL, GMK_HEAVY_SLOTS, GMK_OCC_BLOCKS, GMK_N
+};
+
+struct GmDevBatch {
+    uint32_t n, stride, max_seeds, illumina_until;
+    const uint8_t* bases;
+    const uint8_t* quals;
+    const uint16_t* len;
+    int8_t* status;                 // n
+    float* self_score;              // n
+    double* min_score;              // n
+    float* top_score;               // n
+    GmSeed* seeds;                  // 2n x max_seeds
+    uint16_t* n_seeds;              // 2n
+    uint32_t* n_entries;            // 2n   number of SA hits of the seeds used
+    uint64_t* entry_off;            // 2n+1 exclusive scan of n_entries (sampled-SA mode only)
+    uint32_t* coords;               // located coordinates, entry_off order (sampled-SA mode only)
+    uint8_t* rs_overflow;           // 2n   1 = LDS vote table overflowed, handled by the global-table kernel
+    uint32_t* retry_list;           // list of overflowed rs
+    uint64_t* retry_off;            // table offsets for the retry list
+    uint32_t* gtab_keys;            // global vote tables (retry path)
+    uint32_t* gtab_vals;
+    GmCand* cands;  uint32_t cand_cap;
+    uint32_t* hit_count;            // n
+    uint64_t* hit_begin;            // n+1
+    uint32_t* hit_cursor;           // n
+    GmRawHit* raw_hits;  uint64_t raw_cap;
+    unsigned long long* counters;   // GMK_N
+    uint32_t* n_cands;              // device counter
+    uint32_t* n_retry;              // device counter
+};
+
+// Launchers (gm_kernels.hip).  All asynchronous on `stream`; they return a hipError_t cast to int.
+#ifdef __cplusplus
+extern "C++" {
+int gmk_expand_full_sa(const GmDevIndex& ix, uint32_t* full_sa, void* stream);
+int gmk_prep(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream);
+int gmk_seed(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream);
+int gmk_scan_entries(const GmDevBatch& b, void* stream);
+int gmk_locate_sampled(const GmDevIndex& ix, const GmDevBatch& b, void* stream);
+int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, void* stream);
+int gmk_vote_retry(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, uint32_t n_retry, void* stream);
+int gmk_nw(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream);
+int gmk_compact(const GmDevBatch& b, void* stream);
+int gmk_sa_interval(const GmDevIndex& ix, const uint8_t* kmers, uint32_t n, uint32_t m, uint32_t* start, uint32_t* end, void* stream);
+int gmk_locate(const GmDevIndex& ix, const uint32_t* ranks, uint32_t n, int use_full_sa, uint32_t* out, void* stream);
+int gmk_traceback(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, const GmCand* items, uint32_t n,
+                  uint8_t* ops, uint32_t ops_stride, uint16_t* ops_len, void* stream);
+int gmk_coverage_add(float* cov, uint64_t bins, uint32_t bin_size, const uint64_t* pos, const uint32_t* span, const float* w,
+                     uint32_t n, uint32_t max_span, void* stream);
+}
+#endif

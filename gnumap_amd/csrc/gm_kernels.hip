@@ -1,0 +1,901 @@
+// gm_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the GNUMAP seed-and-extend hot path.
+//
+// Kernels, in pipeline order (reference file:line each one stands for):
+//   k_expand_full_sa   once per index: rank-sampled SA -> full 32-bit SA by LF walks     (bwt_sa/bwt_invPsi src/bwt.c:53-96)
+//   k_prep             read self score, -a threshold, status                             (set_top_matches src/Driver.cpp:446-503,
+//                                                                                         get_align_score_mid src/bin_seq.cpp:860-893)
+//   k_seed             adaptive k-mer walk + backward search, one lane per read x strand (align_sequence inc/align_seq2_raw.cpp:192-243,
+//                                                                                         bwt_match_exact/bwt_2occ/bwt_occ src/bwt.c:107-239)
+//   k_locate_sampled   faithful locate: LF walk to the next sampled rank                  (bwt_sa src/bwt.c:86-96)
+//   k_vote[_retry]     locate + vote, one wavefront per read x strand, LDS vote table     (inc/align_seq2_raw.cpp:262-274, process_hits :28-40)
+//   k_nw               banded probabilistic NW score, 8 lanes per candidate               (get_align_score_begin src/bin_seq.cpp:781-850)
+//   k_scatter_hits     accepted candidates -> per-read CSR
+//   k_traceback        forward banded DP with move bits + traceback                       (get_align_score_w_traceback src/bin_seq.cpp:445-718)
+//   k_coverage_add     amount_genome[(pos+i)/bin] += w                                    (GenomeBwt::AddScore src/GenomeBwt.cpp:483-490)
+//
+// Arithmetic: ranks/coordinates are u32 (reference < 2^32-1 ranks); scores are fp32 with the reference's operation
+// order and NO fused multiply-add (built with -ffp-contract=off; mul/add also go through __fmul_rn/__fadd_rn).
+#include <hip/hip_runtime.h>
+#include "gm_internal.h"
+
+#define GM_NEG_INF (-100000.0f)
+#define GM_EMPTY 0xFFFFFFFFu
+#define GM_WALK_CAP (1u << 24)
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int gm_lane() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ uint32_t gm_nt4(uint32_t ch) {
+    // nst_nt4_table src/bntseq.c:47-64 : ACGT/acgt -> 0..3, everything else 4
+    uint32_t u = ch & 0xDFu;        // fold case
+    return u == 'A' ? 0u : u == 'C' ? 1u : u == 'G' ? 2u : u == 'T' ? 3u : 4u;
+}
+
+__device__ __forceinline__ unsigned long long gm_wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__device__ __forceinline__ void gm_count(const GmDevBatch& b, int which, unsigned long long v) {
+    unsigned long long s = gm_wave_sum(v);
+    if (gm_lane() == 0 && s) atomicAdd(&b.counters[which], s);
+}
+
+// number of bases == c among the first `take` (clamped to 0..32) bases of a word holding 32 bases MSB first
+__device__ __forceinline__ uint32_t gm_count_base(unsigned long long w, uint32_t c, int take) {
+    unsigned long long pat = ((c & 1u) ? 0x5555555555555555ull : 0ull) | ((c & 2u) ? 0xAAAAAAAAAAAAAAAAull : 0ull);
+    unsigned long long x = w ^ pat;
+    unsigned long long m = ~(x | (x >> 1)) & 0x5555555555555555ull;
+    if (take <= 0) return 0;
+    if (take < 32) m &= ~0ull << (2 * (32 - take));
+    return (uint32_t)__popcll(m);
+}
+
+// L2[c] / L2[c+1]-L2[c] by select (c is per-lane: no dynamic indexing of the by-value index struct)
+__device__ __forceinline__ uint32_t gm_L2(const GmDevIndex& ix, uint32_t c) {
+    return c == 0 ? ix.L2[0] : c == 1 ? ix.L2[1] : c == 2 ? ix.L2[2] : ix.L2[3];
+}
+__device__ __forceinline__ uint32_t gm_L2n(const GmDevIndex& ix, uint32_t c) {
+    return c == 0 ? ix.L2[1] : c == 1 ? ix.L2[2] : c == 2 ? ix.L2[3] : ix.L2[4];
+}
+
+// bwt_occ src/bwt.c:107-129 : occurrences of base c in BWT[0..k].  One 64-byte block: a dword of the
+// cumulative count + two 16-byte loads of packed bases, all from the same line.
+__device__ __forceinline__ uint32_t gm_occ(const GmDevIndex& ix, uint32_t k, uint32_t c) {
+    if (k == ix.seq_len) return gm_L2n(ix, c) - gm_L2(ix, c);
+    if (k == 0xFFFFFFFFu) return 0;                         // the reference's (bwtint_t)-1
+    k -= (k >= ix.primary) ? 1u : 0u;
+    const uint32_t* blk = ix.bwt + ((size_t)(k >> 7) << 4);
+    uint32_t n = blk[2 * c];                                // low half of the u64 count (seq_len < 2^32)
+    const uint4 w0 = *reinterpret_cast<const uint4*>(blk + 8);
+    const uint4 w1 = *reinterpret_cast<const uint4*>(blk + 12);
+    int within = (int)(k & 127u) + 1;
+    n += gm_count_base(((unsigned long long)w0.x << 32) | w0.y, c, within);
+    n += gm_count_base(((unsigned long long)w0.z << 32) | w0.w, c, within - 32);
+    n += gm_count_base(((unsigned long long)w1.x << 32) | w1.y, c, within - 64);
+    n += gm_count_base(((unsigned long long)w1.z << 32) | w1.w, c, within - 96);
+    return n;
+}
+
+// bwt_invPsi src/bwt.c:53-59
+__device__ __forceinline__ uint32_t gm_inv_psi(const GmDevIndex& ix, uint32_t k) {
+    uint32_t x = k - ((k > ix.primary) ? 1u : 0u);
+    uint32_t word = ix.bwt[((size_t)(x >> 7) << 4) + 8 + ((x & 0x7fu) >> 4)];
+    uint32_t c = (word >> ((~x & 0xfu) << 1)) & 3u;
+    uint32_t r = gm_L2(ix, c) + gm_occ(ix, k, c);
+    return k == ix.primary ? 0u : r;
+}
+
+// bwt_sa src/bwt.c:86-96 ; *steps receives the number of LF steps taken
+__device__ __forceinline__ uint32_t gm_locate_walk(const GmDevIndex& ix, uint32_t k, uint32_t* steps) {
+    uint32_t sa = 0;
+    while ((k & ix.sa_mask) && sa < GM_WALK_CAP) {
+        ++sa;
+        k = gm_inv_psi(ix, k);
+    }
+    *steps = sa;
+    return sa + ix.sa_samples[k >> ix.sa_shift];
+}
+
+// bin_seq::get_val src/bin_seq.cpp:975-987 with the PWM row given as (called base, p, q)
+__device__ __forceinline__ float gm_get_val(uint32_t code, float p, float q, const float* s) {
+    float r0 = code == 0 ? p : q, r1 = code == 1 ? p : q, r2 = code == 2 ? p : q, r3 = code == 3 ? p : q;
+    float a = __fadd_rn(__fmul_rn(r0, s[0]), __fmul_rn(r1, s[1]));
+    a = __fadd_rn(a, __fmul_rn(r2, s[2]));
+    a = __fadd_rn(a, __fmul_rn(r3, s[3]));
+    return a;
+}
+
+// bin_seq::max_flt src/bin_seq.cpp:1013-1026
+__device__ __forceinline__ float gm_max3(float a, float b, float c) {
+    if (a >= b) return a >= c ? a : c;
+    return b >= c ? b : c;
+}
+
+// bns_pos2rid src/bntseq.c:349-363 : last contig whose offset <= pos
+__device__ __forceinline__ uint32_t gm_pos2rid(const GmDevIndex& ix, uint32_t pos) {
+    uint32_t lo = 0, hi = ix.n_seqs - 1;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi + 1) >> 1;
+        if (pos >= ix.contig_off[mid]) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// GenomeBwt::GetString src/GenomeBwt.cpp:384-415 validity: the window must lie inside one contig
+__device__ __forceinline__ bool gm_window_ok(const GmDevIndex& ix, uint32_t begin, uint32_t L) {
+    if ((unsigned long long)begin + L > ix.l_pac) return false;
+    return gm_pos2rid(ix, begin) == gm_pos2rid(ix, begin + L - 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// full SA expansion (one thread per SA sample)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_expand_full_sa(GmDevIndex ix, uint32_t* full_sa, uint32_t n_sa) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_sa) return;
+    uint32_t k = s << ix.sa_shift;
+    if (k > ix.seq_len) return;
+    uint32_t v = (s == 0) ? ix.seq_len : ix.sa_samples[s];
+    full_sa[k] = v;
+    for (uint32_t it = 0; it < GM_WALK_CAP; ++it) {
+        k = gm_inv_psi(ix, k);
+        --v;
+        if ((k & ix.sa_mask) == 0) break;
+        full_sa[k] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// prep: one thread per read
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_prep(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long bad = 0;
+    if (r < b.n) {
+        uint32_t L = b.len[r];
+        const uint8_t* rb = b.bases + (size_t)r * b.stride;
+        const uint8_t* rq = b.quals + (size_t)r * b.stride;
+        const float2* lut = p.lut + ((r < b.illumina_until) ? 256 : 0);
+        int8_t st = 0;
+        float self = 0.0f;
+        double mn;
+        float score = 0.0f;
+        for (uint32_t i = 0; i < L; ++i) {
+            uint32_t ch = rb[i];
+            float2 pq = lut[rq[i]];
+            if (pq.x != pq.x) bad = 1;                       // negative probability (SeqReader.cpp:1171-1189)
+            const float* s = p.S256 + ch * 4;
+            score = __fadd_rn(score, gm_get_val(gm_nt4(ch), pq.x, pq.y, s));
+        }
+        if (L < (uint32_t)p.mer) {
+            st = -2;                                         // READ_TOO_SHORT
+            mn = 0.0;
+        } else if (p.nw) {
+            float v = 0.0f;                                  // get_align_score(read,cons,0,L-1): begin(=0) + mid + end(=0)
+            v = __fadd_rn(v, 0.0f); v = __fadd_rn(v, score); v = __fadd_rn(v, 0.0f);
+            self = v;
+            if ((double)self < (double)p.cutoff) st = -3;    // READ_TOO_POOR
+            mn = p.align_is_fraction ? (double)p.align_score * (double)self : (double)p.align_score;
+        } else {
+            mn = (double)p.kmin;                             // Driver.cpp:502
+        }
+        b.status[r] = st;
+        b.self_score[r] = self;
+        b.min_score[r] = mn;
+        b.top_score[r] = 0.0f;
+        b.hit_count[r] = 0;
+        b.hit_cursor[r] = 0;
+    }
+    gm_count(b, GMK_BAD_QUAL, bad);
+}
+
+// ------------------------------------------------------------------------------------------------
+// seed: one lane per read x strand walks the read exactly like align_sequence does
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_seed(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
+    uint32_t rs = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long nk = 0, nocc = 0, nblk = 0, nseed = 0, nent = 0;
+    if (rs < 2 * b.n) {
+        uint32_t r = rs >> 1, strand = rs & 1;
+        bool on = b.status[r] == 0 && (strand ? p.neg_strand : p.pos_strand);
+        if (on) {
+            uint32_t L = b.len[r];
+            const uint8_t* rb = b.bases + (size_t)r * b.stride;
+            GmSeed* out = b.seeds + (size_t)rs * b.max_seeds;
+            uint32_t last = L - (uint32_t)p.mer;
+            uint32_t i = 0;
+            while (i < last) {
+                // bwt_match_exact on the k-mer at [i, i+mer), right to left
+                uint32_t k = 0, l = ix.seq_len;
+                int t;
+                bool ok = true;
+                ++nk;
+                for (t = p.mer - 1; t >= 0; --t) {
+                    uint32_t pos = i + (uint32_t)t;
+                    uint32_t c = gm_nt4(strand ? rb[L - 1 - pos] : rb[pos]);
+                    if (c > 3) { ok = false; break; }
+                    if (strand) c = 3 - c;
+                    uint32_t ok_ = gm_occ(ix, k - 1, c);
+                    uint32_t ol_ = gm_occ(ix, l, c);
+                    nocc += 2;
+                    {   // 64-byte blocks this step touches (bwt_2occ src/bwt.c:132-163: one when k-1 and l share a block)
+                        uint32_t k1 = k - 1, kb = k1 - ((k1 >= ix.primary) ? 1u : 0u), lb = l - ((l >= ix.primary) ? 1u : 0u);
+                        bool ks = (k1 == 0xFFFFFFFFu) || (k1 == ix.seq_len), ls = (l == ix.seq_len);
+                        nblk += (ks ? 0u : 1u) + (ls ? 0u : 1u) - ((!ks && !ls && (kb >> 7) == (lb >> 7)) ? 1u : 0u);
+                    }
+                    k = gm_L2(ix, c) + ok_ + 1;
+                    l = gm_L2(ix, c) + ol_;
+                    if (k > l) { ok = false; break; }
+                }
+                if (!ok) {
+                    // the suffix [i+t, i+mer) of this k-mer does not occur (or holds a non-ACGT): every k-mer starting in
+                    // [i, i+t] contains it, so the reference's one-by-one slide (:200-231) fails on all of them too
+                    i += (uint32_t)t + 1;
+                    continue;
+                }
+                uint32_t cnt = l - k + 1;
+                if (p.hcap > 0 && cnt > p.hcap) { i += 1; continue; }       // too many hits: slide by one (:213-217)
+                if (nseed < b.max_seeds) { GmSeed sd; sd.k = k; sd.l = l; sd.pos = i; out[nseed] = sd; }
+                ++nseed;
+                nent += cnt;
+                i += (uint32_t)p.jump;
+            }
+        }
+        b.n_seeds[rs] = (uint16_t)(nseed < b.max_seeds ? nseed : b.max_seeds);
+        b.n_entries[rs] = nent > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nent;
+    }
+    gm_count(b, GMK_KMERS, nk);
+    gm_count(b, GMK_OCC, nocc);
+    gm_count(b, GMK_OCC_BLOCKS, nblk);
+    gm_count(b, GMK_SEEDS, nseed);
+    gm_count(b, GMK_SA_HITS, nent);
+}
+
+// ------------------------------------------------------------------------------------------------
+// exclusive scan u32 -> u64 (three small passes; 1024 items per block)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_scan_block_sums(const uint32_t* in, uint64_t n, unsigned long long* block_sums) {
+    __shared__ unsigned long long ws[4];
+    uint64_t base = (uint64_t)blockIdx.x * 1024 + (uint64_t)threadIdx.x * 4;
+    unsigned long long s = 0;
+    for (int q = 0; q < 4; ++q) if (base + q < n) s += in[base + q];
+    s = gm_wave_sum(s);
+    if (gm_lane() == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ void k_scan_sums(unsigned long long* block_sums, uint32_t nb) {
+    // one wavefront: running exclusive scan over the block sums, 64 at a time
+    int lane = gm_lane();
+    unsigned long long carry = 0;
+    for (uint32_t base = 0; base < nb; base += 64) {
+        uint32_t idx = base + lane;
+        unsigned long long v = idx < nb ? block_sums[idx] : 0, incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            unsigned long long t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (idx < nb) block_sums[idx] = carry + incl - v;
+        carry += __shfl(incl, 63);
+    }
+    if (lane == 0) block_sums[nb] = carry;
+}
+
+__global__ void __launch_bounds__(256) k_scan_final(const uint32_t* in, uint64_t n, const unsigned long long* block_sums, uint64_t* out) {
+    __shared__ unsigned long long ws[4];
+    int lane = gm_lane(), wave = threadIdx.x >> 6;
+    uint64_t base = (uint64_t)blockIdx.x * 1024 + (uint64_t)threadIdx.x * 4;
+    uint32_t v[4];
+    unsigned long long s = 0;
+    for (int q = 0; q < 4; ++q) { v[q] = base + q < n ? in[base + q] : 0; s += v[q]; }
+    unsigned long long incl = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        unsigned long long t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+    unsigned long long pre = block_sums[blockIdx.x];
+    for (int w = 0; w < wave; ++w) pre += ws[w];
+    unsigned long long run = pre + incl - s;
+    for (int q = 0; q < 4; ++q) { if (base + q < n) out[base + q] = run; run += v[q]; }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = block_sums[gridDim.x];
+}
+
+// ------------------------------------------------------------------------------------------------
+// faithful locate (sampled SA): one wavefront per read x strand, lanes = SA ranks of the current seed
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_locate_sampled(GmDevIndex ix, GmDevBatch b) {
+    uint32_t rs = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = gm_lane();
+    unsigned long long steps_total = 0;
+    if (rs < 2 * b.n) {
+        uint32_t ns = b.n_seeds[rs];
+        const GmSeed* seeds = b.seeds + (size_t)rs * b.max_seeds;
+        uint64_t off = b.entry_off[rs];
+        for (uint32_t t = 0; t < ns; ++t) {
+            GmSeed sd = seeds[t];
+            uint32_t cnt = sd.l - sd.k + 1;
+            for (uint32_t base = 0; base < cnt; base += 64) {
+                uint32_t idx = base + lane;
+                if (idx < cnt) {
+                    uint32_t st;
+                    b.coords[off + idx] = gm_locate_walk(ix, sd.k + idx, &st);
+                    steps_total += st;
+                }
+            }
+            off += cnt;
+        }
+    }
+    gm_count(b, GMK_LF_STEPS, steps_total);
+}
+
+// ------------------------------------------------------------------------------------------------
+// locate + vote.  One wavefront owns one read x strand.  Votes are counted in an LDS table; because nearly all
+// located positions are singletons, a two-level bit filter (A: seen, B: seen twice) keeps the exact table small:
+// only positions whose filter bit was hit at least twice can reach kmin >= 2 votes.
+// ------------------------------------------------------------------------------------------------
+#define GMV_FBITS 14                    // 16384 filter bits = 512 words
+#define GMV_FWORDS (1 << (GMV_FBITS - 5))
+#define GMV_TBITS 9                     // 512 exact slots
+#define GMV_TSIZE (1 << GMV_TBITS)
+#define GMV_TLIMIT (GMV_TSIZE * 3 / 4)
+
+struct GmVoteSrc {                      // where the located coordinates of seed t come from
+    const uint32_t* full_sa;
+    const uint32_t* coords;
+};
+
+template <class Table>
+__device__ __forceinline__ void gm_emit(const GmDevBatch& b, bool emit, uint32_t rs, uint32_t bpos, uint32_t step, uint8_t flags) {
+    unsigned long long mask = __ballot(emit);
+    if (mask == 0) return;
+    int lane = gm_lane();
+    int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(b.n_cands, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (emit) {
+        uint32_t idx = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (idx < b.cand_cap) {
+            GmCand c;
+            c.rs = rs; c.b = bpos; c.step = (uint16_t)step; c.flags = flags; c.pad = 0; c.score = 0.0f;
+            b.cands[idx] = c;
+        }
+    }
+}
+
+struct GmLdsTable {
+    uint32_t* keys; uint32_t* vals; uint32_t mask; int bits;
+    __device__ __forceinline__ uint32_t slot0(uint32_t key) const { return (key * 0x85EBCA6Bu) >> (32 - bits); }
+};
+
+// insert `key`; returns slot or GM_EMPTY when the table is full.  *fresh = key was not present.
+template <class T>
+__device__ __forceinline__ uint32_t gm_table_insert(T& tb, uint32_t key, bool* fresh) {
+    uint32_t slot = tb.slot0(key);
+    *fresh = false;
+    for (uint32_t probe = 0; probe <= tb.mask; ++probe) {
+        uint32_t old = atomicCAS(&tb.keys[slot], GM_EMPTY, key);
+        if (old == GM_EMPTY) { *fresh = true; return slot; }
+        if (old == key) return slot;
+        slot = (slot + 1) & tb.mask;
+    }
+    return GM_EMPTY;
+}
+
+__device__ __forceinline__ uint32_t gm_coord(const GmDevIndex& ix, const GmDevBatch& b, int use_full_sa, const GmSeed& sd,
+                                             uint32_t idx, uint64_t coord_off) {
+    return use_full_sa ? ix.full_sa[sd.k + idx] : b.coords[coord_off + idx];
+}
+
+__global__ void __launch_bounds__(256) k_vote(GmDevIndex ix, GmDevParams p, GmDevBatch b, int use_full_sa) {
+    __shared__ uint32_t s_A[4][GMV_FWORDS];
+    __shared__ uint32_t s_B[4][GMV_FWORDS];
+    __shared__ uint32_t s_keys[4][GMV_TSIZE];
+    __shared__ uint32_t s_vals[4][GMV_TSIZE];
+    int wave = threadIdx.x >> 6, lane = gm_lane();
+    uint32_t rs = blockIdx.x * 4 + wave;
+    if (rs >= 2 * b.n) return;                       // wave-uniform; no block barriers below
+    uint32_t ns = b.n_seeds[rs];
+    if (ns == 0) return;
+    uint32_t E = b.n_entries[rs];
+    const GmSeed* seeds = b.seeds + (size_t)rs * b.max_seeds;
+    uint64_t coff0 = use_full_sa ? 0 : b.entry_off[rs];
+    bool filter = p.kmin >= 2 && E > GMV_TSIZE / 2;
+    if (p.nw && p.fast) ns = 1;                      // --fast: only the first seed is looked at (:309-312)
+    uint32_t* A = s_A[wave]; uint32_t* B = s_B[wave];
+    GmLdsTable tb; tb.keys = s_keys[wave]; tb.vals = s_vals[wave]; tb.mask = GMV_TSIZE - 1; tb.bits = GMV_TBITS;
+    for (int q = lane; q < GMV_TSIZE; q += 64) { tb.keys[q] = GM_EMPTY; tb.vals[q] = 0; }
+    if (filter) {
+        for (int q = lane; q < GMV_FWORDS; q += 64) { A[q] = 0; B[q] = 0; }
+        uint64_t coff = coff0;
+        for (uint32_t t = 0; t < ns; ++t) {          // pass 1: which filter bits are hit twice
+            GmSeed sd = seeds[t];
+            uint32_t cnt = sd.l - sd.k + 1;
+            for (uint32_t base = 0; base < cnt; base += 64) {
+                uint32_t idx = base + lane;
+                if (idx < cnt) {
+                    uint32_t c = gm_coord(ix, b, use_full_sa, sd, idx, coff);
+                    uint32_t bp = (c <= sd.pos) ? 0u : c - sd.pos;
+                    uint32_t h = (bp * 0x9E3779B1u) >> (32 - GMV_FBITS);
+                    uint32_t bit = 1u << (h & 31);
+                    uint32_t old = atomicOr(&A[h >> 5], bit);
+                    if (old & bit) atomicOr(&B[h >> 5], bit);
+                }
+            }
+            coff += cnt;
+        }
+    }
+    uint32_t nkeys = 0;
+    bool overflow = false;
+    uint64_t coff = coff0;
+    for (uint32_t t = 0; t < ns && !overflow; ++t) { // pass 2: exact votes, in seed order
+        GmSeed sd = seeds[t];
+        uint32_t cnt = sd.l - sd.k + 1;
+        for (uint32_t base = 0; base < cnt && !overflow; base += 64) {
+            uint32_t idx = base + lane;
+            bool emit = false, fresh = false, full = false;
+            uint32_t bp = 0;
+            if (idx < cnt) {
+                uint32_t c = gm_coord(ix, b, use_full_sa, sd, idx, coff);
+                bp = (c <= sd.pos) ? 0u : c - sd.pos;               // :267
+                bool take = true;
+                if (filter) {
+                    uint32_t h = (bp * 0x9E3779B1u) >> (32 - GMV_FBITS);
+                    take = (B[h >> 5] >> (h & 31)) & 1u;
+                }
+                if (take) {
+                    uint32_t slot = gm_table_insert(tb, bp, &fresh);
+                    if (slot == GM_EMPTY) full = true;
+                    else {
+                        uint32_t v = atomicAdd(&tb.vals[slot], 1u) + 1u;
+                        emit = p.nw && v == (uint32_t)p.kmin;       // reaches -k votes at this seed -> NW now (:28-40)
+                    }
+                }
+            }
+            nkeys += (uint32_t)__popcll(__ballot(fresh));
+            if (__ballot(full) != 0 || nkeys > GMV_TLIMIT) overflow = true;
+            if (!overflow) gm_emit<GmLdsTable>(b, emit, rs, bp, t, 4);
+        }
+        coff += cnt;
+    }
+    if (overflow) {                                  // hand this read x strand to the global-table kernel
+        if (lane == 0) {
+            b.rs_overflow[rs] = 1;
+            uint32_t j = atomicAdd(b.n_retry, 1u);
+            uint32_t need = 2 * E; uint32_t sz = 1024; while (sz < need && sz < 0x80000000u) sz <<= 1;
+            unsigned long long off = atomicAdd(&b.counters[GMK_HEAVY_SLOTS], (unsigned long long)sz);
+            b.retry_list[j] = rs;
+            b.retry_off[j] = off;
+            atomicAdd(&b.counters[GMK_OVERFLOW_RS], 1ull);
+        }
+        return;
+    }
+    if (!p.nw) {                                     // --no_nw: one pass over the final counts (:317-325)
+        for (int q = lane; q < GMV_TSIZE; q += 64) {
+            uint32_t key = tb.keys[q], v = tb.vals[q];
+            bool emit = key != GM_EMPTY && v >= (uint32_t)p.kmin;
+            gm_emit<GmLdsTable>(b, emit, rs, key, v > 65535u ? 65535u : v, 4);
+        }
+    }
+}
+
+// retry path: one workgroup per overflowed read x strand, exact vote table in HBM (pre-set to EMPTY/0 by the host)
+struct GmGlobalTable {
+    uint32_t* keys; uint32_t* vals; uint32_t mask; int bits;
+    __device__ __forceinline__ uint32_t slot0(uint32_t key) const { return (key * 0x85EBCA6Bu) >> (32 - bits); }
+};
+
+__global__ void __launch_bounds__(256) k_vote_retry(GmDevIndex ix, GmDevParams p, GmDevBatch b, int use_full_sa, uint32_t n_retry) {
+    uint32_t j = blockIdx.x;
+    if (j >= n_retry) return;
+    uint32_t rs = b.retry_list[j];
+    uint32_t ns = b.n_seeds[rs];
+    uint32_t E = b.n_entries[rs];
+    uint32_t need = 2 * E; uint32_t sz = 1024; int bits = 10;
+    while (sz < need && sz < 0x80000000u) { sz <<= 1; ++bits; }
+    GmGlobalTable tb; tb.keys = b.gtab_keys + b.retry_off[j]; tb.vals = b.gtab_vals + b.retry_off[j]; tb.mask = sz - 1; tb.bits = bits;
+    const GmSeed* seeds = b.seeds + (size_t)rs * b.max_seeds;
+    uint64_t coff = use_full_sa ? 0 : b.entry_off[rs];
+    if (p.nw && p.fast) ns = 1;
+    for (uint32_t t = 0; t < ns; ++t) {
+        GmSeed sd = seeds[t];
+        uint32_t cnt = sd.l - sd.k + 1;
+        for (uint32_t base = 0; base < cnt; base += 256) {
+            uint32_t idx = base + threadIdx.x;
+            bool emit = false, fresh;
+            uint32_t bp = 0;
+            if (idx < cnt) {
+                uint32_t c = gm_coord(ix, b, use_full_sa, sd, idx, coff);
+                bp = (c <= sd.pos) ? 0u : c - sd.pos;
+                uint32_t slot = gm_table_insert(tb, bp, &fresh);
+                if (slot != GM_EMPTY) {
+                    uint32_t v = atomicAdd(&tb.vals[slot], 1u) + 1u;
+                    emit = p.nw && v == (uint32_t)p.kmin;
+                }
+            }
+            gm_emit<GmGlobalTable>(b, emit, rs, bp, t, 0);
+        }
+        coff += cnt;
+        __syncthreads();                             // all votes of seed t are in before seed t+1 starts
+    }
+    if (!p.nw) {
+        for (uint32_t q = threadIdx.x; q < sz; q += 256) {
+            uint32_t key = tb.keys[q], v = tb.vals[q];
+            bool emit = key != GM_EMPTY && v >= (uint32_t)p.kmin;
+            gm_emit<GmGlobalTable>(b, emit, rs, key, v > 65535u ? 65535u : v, 0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// banded NW score: 8 lanes per candidate (7 band diagonals + 1 idle), anti-diagonal sweep.
+// Lane d holds the newest cell of diagonal delta = j - i = d - 3; cells of one anti-diagonal i+j = s are independent,
+// their three inputs are this lane's previous cell (s+2) and the two neighbour lanes' cells (s+1), exchanged by
+// wave shuffles.  The read rows (called base, quality) and the 2-bit window are staged in LDS.
+// ------------------------------------------------------------------------------------------------
+#define GM_NW_HDR (512 * sizeof(float2) + 16 * sizeof(float))
+struct GmNwLds {
+    float2* lut;            // 512 entries
+    float* sg;              // 4 x 4 substitution rows a,c,g,t
+    uint16_t* rows;         // 32 groups x Lp
+    uint8_t* win;           // 32 groups x Lp
+};
+
+__device__ __forceinline__ GmNwLds gm_nw_lds(unsigned char* raw, uint32_t Lp) {
+    GmNwLds s;
+    s.lut = reinterpret_cast<float2*>(raw);
+    s.sg = reinterpret_cast<float*>(raw + 512 * sizeof(float2));
+    s.rows = reinterpret_cast<uint16_t*>(raw + GM_NW_HDR);
+    s.win = raw + GM_NW_HDR + (size_t)32 * Lp * 2;
+    return s;
+}
+
+// stage read rows (in strand orientation) and the reference window of one candidate; 8 lanes cooperate
+__device__ __forceinline__ void gm_stage(const GmDevIndex& ix, const GmDevBatch& b, uint16_t* rows, uint8_t* win,
+                                         uint32_t r, uint32_t strand, uint32_t L, uint32_t b0, int d) {
+    const uint8_t* rb = b.bases + (size_t)r * b.stride;
+    const uint8_t* rq = b.quals + (size_t)r * b.stride;
+    for (uint32_t i = (uint32_t)d; i < L; i += 8) {
+        uint32_t src = strand ? L - 1 - i : i;          // reverse_comp_cpy SequenceOperations.h:149-161
+        uint32_t code = gm_nt4(rb[src]);
+        if (strand && code < 4) code = 3 - code;
+        rows[i] = (uint16_t)((code << 8) | rq[src]);
+        uint32_t pp = b0 + i;
+        win[i] = (uint8_t)((ix.pac[pp >> 2] >> ((~pp & 3u) << 1)) & 3u);   // _get_pac src/bntseq.c:225
+    }
+}
+
+__global__ void __launch_bounds__(256) k_nw(GmDevIndex ix, GmDevParams p, GmDevBatch b, uint32_t Lp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    GmNwLds S = gm_nw_lds(s_raw, Lp);
+    for (int q = threadIdx.x; q < 512; q += 256) S.lut[q] = p.lut[q];
+    if (threadIdx.x < 16) S.sg[threadIdx.x] = p.S256[(size_t)("acgt"[threadIdx.x >> 2]) * 4 + (threadIdx.x & 3)];
+    const int lane = gm_lane(), wave = threadIdx.x >> 6;
+    const int g = (threadIdx.x >> 3), d = lane & 7, delta = d - 3;
+    uint16_t* rows = S.rows + (size_t)g * Lp;
+    uint8_t* win = S.win + (size_t)g * Lp;
+    const uint32_t n_cands = *b.n_cands < b.cand_cap ? *b.n_cands : b.cand_cap;
+    const float gap = p.gap, gap4 = __fmul_rn(p.gap, 4.0f);
+    unsigned long long cells = 0, accepted = 0;
+    (void)wave;
+    for (uint32_t base = blockIdx.x * 32; base < n_cands; base += gridDim.x * 32) {     // block-uniform trip count
+        uint32_t ci = base + g;
+        bool have = ci < n_cands;
+        GmCand c; c.rs = 0; c.b = 0; c.step = 0; c.flags = 0; c.score = 0;
+        if (have) c = b.cands[ci];
+        uint32_t r = c.rs >> 1, strand = c.rs & 1;
+        if (have && (c.flags & 4) && b.rs_overflow[c.rs]) have = false;                // superseded by the retry kernel
+        uint32_t L = have ? b.len[r] : 0;
+        bool ok = have && gm_window_ok(ix, c.b, L);
+        if (ok && p.nw) gm_stage(ix, b, rows, win, r, strand, L, c.b, d);
+        __syncthreads();
+        float result = 0.0f;
+        if (p.nw) {
+            const float2* lut = S.lut + ((r < b.illumina_until) ? 256 : 0);
+            int absd = delta < 0 ? -delta : delta;
+            float own = __fmul_rn(gap, (float)absd);      // boundary row/column: gGAP * (end - i), bin_seq.cpp:801-808
+            int Lw = (int)L;                              // wave-uniform sweep length = longest read in the wave
+#pragma unroll
+            for (int off = 8; off < 64; off <<= 1) { int o = __shfl_xor(Lw, off); Lw = o > Lw ? o : Lw; }
+            for (int s = 2 * Lw - 2; s >= 0; --s) {
+                float a = __shfl(own, lane - 1);          // diagonal delta-1, cell (i+1, j)
+                float bb = __shfl(own, lane + 1);         // diagonal delta+1, cell (i, j+1)
+                int i2 = s - delta;
+                int i = i2 >> 1, j = i + delta;
+                bool act = ok && d < 7 && i2 >= 0 && !(i2 & 1) && i < (int)L && j >= 0 && j < (int)L;
+                if (d == 0) a = (i + 1 == (int)L) ? gap4 : GM_NEG_INF;    // outside the band except on the last row
+                if (d == 6) bb = (j + 1 == (int)L) ? gap4 : GM_NEG_INF;   // ... or the last column
+                if (act) {
+                    uint32_t row = rows[i];
+                    float2 pq = lut[row & 255u];
+                    float val = gm_get_val(row >> 8, pq.x, pq.y, S.sg + 4 * win[j]);
+                    float mm = __fadd_rn(own, val);
+                    float g1 = __fadd_rn(a, gap);
+                    float g2 = __fadd_rn(bb, gap);
+                    own = gm_max3(mm, g1, g2);
+                    ++cells;
+                }
+            }
+            result = __shfl(own, (lane & ~7) + 3);        // nm[0][0] lives on diagonal 0
+        } else {
+            result = (float)c.step;                       // --no_nw: the score is the vote count (:70-76)
+        }
+        if (have && d == 3) {
+            uint8_t fl = c.flags & 4;
+            if (ok) {
+                fl |= GMC_VALID;
+                if (result > 0.0f) atomicMax(reinterpret_cast<int*>(&b.top_score[r]), __float_as_int(result));   // top_align_score (:95-98)
+                if ((double)result >= b.min_score[r]) {  // :102
+                    fl |= GMC_ACCEPT;
+                    atomicAdd(&b.hit_count[r], 1u);
+                    ++accepted;
+                }
+            }
+            b.cands[ci].score = result;
+            b.cands[ci].flags = fl;
+        }
+        __syncthreads();
+    }
+    gm_count(b, GMK_NW_CELLS, cells);
+    gm_count(b, GMK_ACCEPTED, accepted);
+}
+
+__global__ void __launch_bounds__(256) k_scatter_hits(GmDevBatch b) {
+    const uint32_t n_cands = *b.n_cands < b.cand_cap ? *b.n_cands : b.cand_cap;
+    for (uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x; ci < n_cands; ci += gridDim.x * blockDim.x) {
+        GmCand c = b.cands[ci];
+        if (!(c.flags & GMC_ACCEPT)) continue;
+        uint32_t r = c.rs >> 1;
+        uint64_t slot = b.hit_begin[r] + atomicAdd(&b.hit_cursor[r], 1u);
+        if (slot < b.raw_cap) {
+            GmRawHit h;
+            h.read = r; h.pos = c.b; h.score = c.score; h.step = c.step; h.strand = (uint8_t)(c.rs & 1); h.pad = 0;
+            b.raw_hits[slot] = h;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// traceback: forward banded DP (same 8-lane anti-diagonal sweep) recording one 2-bit move per cell in LDS,
+// then lane 0 of the group walks the moves back from (L,L).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_traceback(GmDevIndex ix, GmDevParams p, GmDevBatch b, const GmCand* items, uint32_t n,
+                                                   uint8_t* ops, uint32_t ops_stride, uint16_t* ops_len, uint32_t Lp, uint32_t mvw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    GmNwLds S = gm_nw_lds(s_raw, Lp);
+    uint32_t* mv_all = reinterpret_cast<uint32_t*>(s_raw + GM_NW_HDR + (size_t)32 * Lp * 3);   // 32 groups x 7 x mvw words
+    for (int q = threadIdx.x; q < 512; q += 256) S.lut[q] = p.lut[q];
+    if (threadIdx.x < 16) S.sg[threadIdx.x] = p.S256[(size_t)("acgt"[threadIdx.x >> 2]) * 4 + (threadIdx.x & 3)];
+    const int lane = gm_lane();
+    const int g = (threadIdx.x >> 3), d = lane & 7, delta = d - 3;
+    uint16_t* rows = S.rows + (size_t)g * Lp;
+    uint8_t* win = S.win + (size_t)g * Lp;
+    uint32_t* mvg = mv_all + (size_t)g * 7 * mvw;
+    uint32_t* mv = mvg + (size_t)(d < 7 ? d : 0) * mvw;
+    const float gap = p.gap, gap4 = __fmul_rn(p.gap, 4.0f);
+    for (uint32_t base = blockIdx.x * 32; base < n; base += gridDim.x * 32) {
+        uint32_t ci = base + g;
+        bool have = ci < n;
+        GmCand c; c.rs = 0; c.b = 0;
+        if (have) c = items[ci];
+        uint32_t r = c.rs >> 1, strand = c.rs & 1;
+        uint32_t L = have ? b.len[r] : 0;
+        bool ok = have && L > 0 && gm_window_ok(ix, c.b, L) && 2 * L <= ops_stride;
+        if (ok) gm_stage(ix, b, rows, win, r, strand, L, c.b, d);
+        if (d < 7) for (uint32_t q = 0; q < mvw; ++q) mv[q] = 0;
+        __syncthreads();
+        const float2* lut = S.lut + ((r < b.illumina_until) ? 256 : 0);
+        int absd = delta < 0 ? -delta : delta;
+        float own = __fmul_rn(gap, (float)absd);          // first row / column: gGAP * t (bin_seq.cpp:503-511)
+        int Lw = (int)L;
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) { int o = __shfl_xor(Lw, off); Lw = o > Lw ? o : Lw; }
+        for (int s = 2; s <= 2 * Lw; ++s) {
+            float u_nb = __shfl(own, lane + 1);           // diagonal delta+1, cell (i-1, j)
+            float l_nb = __shfl(own, lane - 1);           // diagonal delta-1, cell (i, j-1)
+            int i2 = s - delta;
+            int i = i2 >> 1, j = i + delta;
+            bool act = ok && d < 7 && !(i2 & 1) && i >= 1 && i <= (int)L && j >= 1 && j <= (int)L;
+            if (d == 6) u_nb = (i - 1 == 0) ? gap4 : GM_NEG_INF;
+            if (d == 0) l_nb = (j - 1 == 0) ? gap4 : GM_NEG_INF;
+            if (act) {
+                uint32_t row = rows[i - 1];
+                float2 pq = lut[row & 255u];
+                float val = gm_get_val(row >> 8, pq.x, pq.y, S.sg + 4 * win[j - 1]);
+                float dd = __fadd_rn(own, val);
+                float u = __fadd_rn(u_nb, gap);
+                float l = __fadd_rn(l_nb, gap);
+                uint32_t m; float best;                   // max_flt(char&,...) src/bin_seq.cpp:989-1011
+                if (dd >= u) { if (dd >= l) { m = 0; best = dd; } else { m = 2; best = l; } }
+                else         { if (u >= l)  { m = 1; best = u; }  else { m = 2; best = l; } }
+                own = best;
+                mv[i >> 4] |= m << ((i & 15) << 1);
+            }
+        }
+        __syncthreads();
+        if (have && d == 0) {
+            uint16_t outlen = 0;
+            if (ok) {
+                uint8_t* out = ops + (size_t)ci * ops_stride;
+                // pass 1: path length
+                int i = (int)L, j = (int)L, nops = 0; bool bad = false;
+                while (i != 0 && j != 0) {
+                    int dl = j - i;
+                    if (dl < -3 || dl > 3) { bad = true; break; }
+                    uint32_t m = (mvg[(size_t)(dl + 3) * mvw + (i >> 4)] >> ((i & 15) << 1)) & 3u;
+                    if (m == 0) { --i; --j; } else if (m == 1) { --i; } else { --j; }
+                    ++nops;
+                }
+                if (!bad) {
+                    nops += i + j;
+                    int pos = nops - 1;
+                    i = (int)L; j = (int)L;
+                    while (i != 0 && j != 0) {
+                        int dl = j - i;
+                        uint32_t m = (mvg[(size_t)(dl + 3) * mvw + (i >> 4)] >> ((i & 15) << 1)) & 3u;
+                        if (m == 0) { out[pos--] = 'M'; --i; --j; } else if (m == 1) { out[pos--] = 'I'; --i; } else { out[pos--] = 'D'; --j; }
+                    }
+                    while (i > 0) { out[pos--] = 'I'; --i; }
+                    while (j > 0) { out[pos--] = 'D'; --j; }
+                    outlen = (uint16_t)nops;
+                }
+            }
+            ops_len[ci] = outlen;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// coverage: one thread per deposited base
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_coverage_add(float* cov, uint64_t bins, uint32_t bin_size, const uint64_t* pos,
+                                                      const uint32_t* span, const float* w, uint32_t n, uint32_t max_span) {
+    uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t dep = (uint32_t)(gid / max_span), t = (uint32_t)(gid % max_span);
+    if (dep >= n || t >= span[dep]) return;
+    uint64_t bin = (pos[dep] + t) / bin_size;
+    if (bin < bins) atomicAdd(&cov[bin], w[dep]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// unit-level kernels (parity tests of the building blocks)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_sa_interval(GmDevIndex ix, const uint8_t* kmers, uint32_t n, uint32_t m, uint32_t* start, uint32_t* end) {
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const uint8_t* km = kmers + (size_t)q * m;
+    uint32_t k = 0, l = ix.seq_len;
+    bool ok = true;
+    for (int t = (int)m - 1; t >= 0; --t) {
+        uint32_t c = gm_nt4(km[t]);
+        if (c > 3) { ok = false; break; }
+        uint32_t ok_ = gm_occ(ix, k - 1, c), ol_ = gm_occ(ix, l, c);
+        k = gm_L2(ix, c) + ok_ + 1;
+        l = gm_L2(ix, c) + ol_;
+        if (k > l) { ok = false; break; }
+    }
+    start[q] = ok ? k : 0;
+    end[q] = ok ? l : 0;
+}
+
+__global__ void __launch_bounds__(256) k_locate(GmDevIndex ix, const uint32_t* ranks, uint32_t n, int use_full_sa, uint32_t* out) {
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    uint32_t st;
+    out[q] = use_full_sa ? ix.full_sa[ranks[q]] : gm_locate_walk(ix, ranks[q], &st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+int gmk_expand_full_sa(const GmDevIndex& ix, uint32_t* full_sa, void* stream) {
+    uint32_t n_sa = (uint32_t)(((uint64_t)ix.seq_len + ix.sa_mask + 1) >> ix.sa_shift);
+    hipLaunchKernelGGL(k_expand_full_sa, dim3(cdiv(n_sa, 256)), dim3(256), 0, S_(stream), ix, full_sa, n_sa);
+    return (int)hipGetLastError();
+}
+
+int gmk_prep(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream) {
+    if (b.n == 0) return 0;
+    hipLaunchKernelGGL(k_prep, dim3(cdiv(b.n, 256)), dim3(256), 0, S_(stream), ix, p, b);
+    return (int)hipGetLastError();
+}
+
+int gmk_seed(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream) {
+    if (b.n == 0) return 0;
+    hipLaunchKernelGGL(k_seed, dim3(cdiv(2ull * b.n, 256)), dim3(256), 0, S_(stream), ix, p, b);
+    return (int)hipGetLastError();
+}
+
+static int scan_u32(const uint32_t* in, uint64_t n, uint64_t* out, unsigned long long* tmp, void* stream) {
+    uint32_t nb = cdiv(n, 1024);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(256), 0, S_(stream), in, n, tmp);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, S_(stream), tmp, nb);
+    hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(256), 0, S_(stream), in, n, tmp, out);
+    return (int)hipGetLastError();
+}
+
+int gmk_scan_entries(const GmDevBatch& b, void* stream) {
+    if (b.n == 0) return 0;
+    // scan scratch: the tail of hit_begin's sibling buffer is not available yet, so the host gives us retry_off as scratch
+    return scan_u32(b.n_entries, 2ull * b.n, b.entry_off, reinterpret_cast<unsigned long long*>(b.retry_off), stream);
+}
+
+int gmk_locate_sampled(const GmDevIndex& ix, const GmDevBatch& b, void* stream) {
+    if (b.n == 0) return 0;
+    hipLaunchKernelGGL(k_locate_sampled, dim3(cdiv(2ull * b.n, 4)), dim3(256), 0, S_(stream), ix, b);
+    return (int)hipGetLastError();
+}
+
+int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, void* stream) {
+    if (b.n == 0) return 0;
+    hipLaunchKernelGGL(k_vote, dim3(cdiv(2ull * b.n, 4)), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
+    return (int)hipGetLastError();
+}
+
+int gmk_vote_retry(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, uint32_t n_retry, void* stream) {
+    if (n_retry == 0) return 0;
+    hipLaunchKernelGGL(k_vote_retry, dim3(n_retry), dim3(256), 0, S_(stream), ix, p, b, use_full_sa, n_retry);
+    return (int)hipGetLastError();
+}
+
+static inline uint32_t lp_of(uint32_t stride) { return (stride + 7u) & ~7u; }
+
+int gmk_nw(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream) {
+    if (b.n == 0) return 0;
+    uint32_t Lp = lp_of(b.stride);
+    size_t lds = GM_NW_HDR + (size_t)32 * Lp * 3;
+    hipLaunchKernelGGL(k_nw, dim3(2048), dim3(256), lds, S_(stream), ix, p, b, Lp);
+    return (int)hipGetLastError();
+}
+
+int gmk_compact(const GmDevBatch& b, void* stream) {
+    if (b.n == 0) return 0;
+    int e = scan_u32(b.hit_count, b.n, b.hit_begin, reinterpret_cast<unsigned long long*>(b.retry_off), stream);
+    if (e) return e;
+    hipLaunchKernelGGL(k_scatter_hits, dim3(2048), dim3(256), 0, S_(stream), b);
+    return (int)hipGetLastError();
+}
+
+int gmk_sa_interval(const GmDevIndex& ix, const uint8_t* kmers, uint32_t n, uint32_t m, uint32_t* start, uint32_t* end, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_sa_interval, dim3(cdiv(n, 256)), dim3(256), 0, S_(stream), ix, kmers, n, m, start, end);
+    return (int)hipGetLastError();
+}
+
+int gmk_locate(const GmDevIndex& ix, const uint32_t* ranks, uint32_t n, int use_full_sa, uint32_t* out, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_locate, dim3(cdiv(n, 256)), dim3(256), 0, S_(stream), ix, ranks, n, use_full_sa, out);
+    return (int)hipGetLastError();
+}
+
+int gmk_traceback(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, const GmCand* items, uint32_t n,
+                  uint8_t* ops, uint32_t ops_stride, uint16_t* ops_len, void* stream) {
+    if (n == 0) return 0;
+    uint32_t Lp = lp_of(b.stride);
+    uint32_t mvw = (Lp + 1 + 15) / 16 + 1;
+    size_t lds = GM_NW_HDR + (size_t)32 * Lp * 3 + (size_t)32 * 7 * mvw * 4;
+    uint32_t grid = cdiv(n, 32); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_traceback, dim3(grid), dim3(256), lds, S_(stream), ix, p, b, items, n, ops, ops_stride, ops_len, Lp, mvw);
+    return (int)hipGetLastError();
+}
+
+int gmk_coverage_add(float* cov, uint64_t bins, uint32_t bin_size, const uint64_t* pos, const uint32_t* span, const float* w,
+                     uint32_t n, uint32_t max_span, void* stream) {
+    if (n == 0 || max_span == 0) return 0;
+    uint64_t total = (uint64_t)n * max_span;
+    hipLaunchKernelGGL(k_coverage_add, dim3(cdiv(total, 256)), dim3(256), 0, S_(stream), cov, bins, bin_size, pos, span, w, n, max_span);
+    return (int)hipGetLastError();
+}

@@ -19,6 +19,8 @@ def _build_checkers():
     """Build the test-only checkers (oracle restatement; reference harness where /root/reference exists)."""
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle", "ref"], check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    # the product itself (hipcc cross-compiles gfx950 without a GPU); a failure here must be loud
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "gnumap_amd")], check=True, stdout=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope="session")

@@ -1,0 +1,266 @@
+"""Parity of the HIP path (through the C ABI of libgnumap_hip.so) with the oracle and the committed reference
+vectors.  Bit-exact: SA intervals, located coordinates, fp32 NW score bits, CIGARs, unique-map contents,
+fp64 denominators, SAM text.  Only the .sgr track is compared with a tolerance (float atomics; the reference's
+own -c > 1 runs are order-dependent in the same way)."""
+import ctypes as C
+import itertools
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import gnumap_amd as g
+from reflib import revcomp_pwm, revcomp_str
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ix_full(syn_fa):
+    return g.Index(syn_fa, flags=g.GM_INDEX_FULL_SA)
+
+
+@pytest.fixture(scope="module")
+def ix_sampled(syn_fa):
+    return g.Index(syn_fa, flags=0)
+
+
+@pytest.fixture(scope="module")
+def oix(oracle, syn_fa):
+    return oracle.index_load(syn_fa)
+
+
+@pytest.fixture(scope="module")
+def packed(syn_reads):
+    return g.pack_reads([r[1] for r in syn_reads], [r[2] for r in syn_reads])
+
+
+def rle(ops: bytes) -> bytes:
+    return b"".join(str(len(list(grp))).encode() + bytes([k]) for k, grp in itertools.groupby(ops))
+
+
+# ------------------------------------------------------------------ building blocks vs the reference's outputs
+def test_sa_interval(ix_full, golden):
+    kmers = [bytes(k) for k in golden["kmers"]]
+    by_len = {}
+    for i, k in enumerate(kmers):
+        by_len.setdefault(len(k), []).append(i)
+    for m, idxs in by_len.items():
+        s, e = ix_full.dev_sa_interval([kmers[i] for i in idxs])
+        np.testing.assert_array_equal(s, golden["kmer_iv"][idxs, 0])
+        np.testing.assert_array_equal(e, golden["kmer_iv"][idxs, 1])
+
+
+def test_locate_sampled_and_full(ix_full, golden):
+    ranks = golden["loc_rank"]
+    np.testing.assert_array_equal(ix_full.dev_locate(ranks, False), golden["loc_out"])
+    np.testing.assert_array_equal(ix_full.dev_locate(ranks, True), golden["loc_out"])
+    # the expanded SA must agree with the LF walk on EVERY rank
+    n = ix_full.info.seq_len
+    allr = np.arange(1, n + 1, dtype=np.uint64)
+    full = ix_full.dev_locate(allr, True)
+    np.testing.assert_array_equal(full, ix_full.dev_locate(allr, False))
+    assert np.array_equal(np.sort(full), np.arange(n, dtype=np.uint64))        # a permutation of the text positions
+
+
+def test_nw_score_bits(ix_full, golden, packed):
+    B, Q, Ln = packed
+    p = g.Params()
+    score, valid = ix_full.dev_nw_score(p, B, Q, Ln, golden["nw_read"], golden["nw_rc"].astype(np.uint8), golden["nw_begin"])
+    assert valid.all()
+    np.testing.assert_array_equal(score.view(np.uint32), golden["nw_score"].view(np.uint32))
+
+
+def test_window_validity_flags(ix_full, golden, packed):
+    B, Q, Ln = packed
+    p = g.Params()
+    idx = np.array([i for i, L in enumerate(Ln) if L == 100][:1], np.uint32)
+    begins = golden["win_begin"][golden["win_len"] == 100]
+    expect = np.array([len(bytes(w)) > 0 for w in golden["win_out"][golden["win_len"] == 100]])
+    _, valid = ix_full.dev_nw_score(p, B, Q, Ln, np.repeat(idx, len(begins)), np.zeros(len(begins), np.uint8), begins)
+    np.testing.assert_array_equal(valid.astype(bool), expect)
+    assert (~expect).sum() >= 2
+
+
+def test_traceback_cigars(ix_full, golden, packed):
+    B, Q, Ln = packed
+    p = g.Params()
+    ops = ix_full.dev_traceback(p, B, Q, Ln, golden["nw_read"], golden["nw_rc"].astype(np.uint8), golden["nw_begin"])
+    for i, o in enumerate(ops):
+        assert len(o) == golden["tb_len"][i]
+        assert rle(o) == bytes(golden["tb_cigar"][i]), i
+
+
+# ------------------------------------------------------------------ the whole hot path vs the oracle
+CONFIGS = {
+    "default": {},
+    "no_nw": dict(nw=0),
+    "m16": dict(mer=16),
+    "m12_j3": dict(mer=12, jump=3),
+    "h30": dict(max_kmer_hits=30),
+    "T2": dict(max_matches=2),
+    "unique": dict(unique_only=1),
+    "unique_no_nw": dict(unique_only=1, nw=0),
+    "k1": dict(min_seed_hits=1, mer=14),
+    "k3": dict(min_seed_hits=3),
+    "up": dict(neg_strand=0),
+    "down": dict(pos_strand=0),
+    "bs": dict(mode=1),
+    "atog": dict(mode=3),
+    "fast": dict(fast=1, mer=14, jump=14),
+    "raw60": dict(align_score=60.0, align_is_fraction=0),
+    "a07_q50": dict(align_score=0.7, cutoff=50.0),
+}
+
+
+def _oracle_results(oracle, oix, op, syn_reads):
+    out = []
+    for name, seq, qual in syn_reads:
+        P = oracle.pwm(seq, qual) if len(seq) else np.zeros((1, 4), np.float32)
+        out.append(oracle.map_read(oix, op, P, seq))
+    return out
+
+
+def _compare(res, ores, syn_reads):
+    mb = res["match_begin"]
+    for i, o in enumerate(ores):
+        name = syn_reads[i][0]
+        assert res["status"][i] == o["status"], (name, res["status"][i], o["status"])
+        if o["status"] in (0, 1, 2):
+            assert np.float32(res["self_score"][i]).view(np.uint32) == np.float32(o["self_score"]).view(np.uint32), name
+        assert res["top_score"][i] == o["top_score"], (name, res["top_score"][i], o["top_score"])
+        assert res["denominator"][i] == o["denominator"], (name, res["denominator"][i], o["denominator"])
+        ms = res["matches"][int(mb[i]):int(mb[i + 1])]
+        assert len(ms) == len(o["hits"]), name
+        for m, h in zip(ms, o["hits"]):                       # std::map (key) order on both sides
+            assert np.float32(m["score"]).view(np.uint32) == np.float32(h["score"]).view(np.uint32), name
+            assert m["first_strand"] == h["first_strand"], name
+            pos = [(int(q["pos"]), int(q["strand"])) for q in res["positions"][m["pos_begin"]:m["pos_end"]]]
+            assert pos == [(int(a), int(b)) for a, b in h["pos"]], name
+            assert (int(m["first_pos"]), int(m["first_strand"])) in pos
+
+
+@pytest.mark.parametrize("cfg", list(CONFIGS))
+def test_map_batch_matches_oracle(cfg, ix_full, oracle, oix, syn_reads, packed):
+    kw = CONFIGS[cfg]
+    p = g.Params(**kw)
+    op = oracle.params(**kw)
+    B, Q, Ln = packed
+    batch = g.Batch(ix_full, len(syn_reads), B.shape[1])
+    res = batch.map(p, B, Q, Ln)
+    ores = _oracle_results(oracle, oix, op, syn_reads)
+    _compare(res, ores, syn_reads)
+    assert sum(o["status"] == 0 for o in ores) > (50 if cfg != "a07_q50" else 0)
+    batch.destroy()
+
+
+def test_sampled_locate_path_equals_full_sa_path(ix_full, ix_sampled, syn_reads, packed):
+    B, Q, Ln = packed
+    p = g.Params()
+    out = []
+    for ix in (ix_full, ix_sampled):
+        batch = g.Batch(ix, len(syn_reads), B.shape[1])
+        batch.upload(p, B, Q, Ln)
+        batch.map_device(p)
+        hits, status, self_score, top = batch.raw_hits()
+        out.append((hits.tobytes(), status.tobytes(), self_score.tobytes(), top.tobytes(), batch.counters()))
+        batch.destroy()
+    assert out[0][:4] == out[1][:4]
+    assert out[1][4]["lf_steps"] > 10 * out[1][4]["sa_hits"] and out[0][4]["lf_steps"] == 0
+
+
+def test_counters_match_oracle_work(ix_sampled, oracle, oix, syn_reads, packed):
+    """the kernel-side work counters (algorithmic-bytes accounting) against the oracle's own counts"""
+    B, Q, Ln = packed
+    p = g.Params()
+    batch = g.Batch(ix_sampled, len(syn_reads), B.shape[1])
+    batch.upload(p, B, Q, Ln)
+    batch.map_device(p)
+    c = batch.counters()
+    ores = _oracle_results(oracle, oix, oracle.params(), syn_reads)
+    assert c["sa_hits"] == sum(o["ctr"]["locates"] for o in ores)
+    assert c["lf_steps"] == sum(o["ctr"]["lf_steps"] for o in ores)
+    assert c["candidates"] >= sum(o["ctr"]["nw"] for o in ores)          # the kernel also lists windows that fail the contig test
+    assert c["kmers_searched"] <= sum(o["ctr"]["kmers"] for o in ores)   # failed k-mers are skipped in one jump on the device
+    batch.destroy()
+
+
+def test_small_and_ragged_batches(ix_full, oracle, oix, syn_reads):
+    p = g.Params(); op = oracle.params()
+    for sel in ([0], [5, 6], list(range(500, len(syn_reads))), [len(syn_reads) - 1]):
+        reads = [syn_reads[i] for i in sel]
+        B, Q, Ln = g.pack_reads([r[1] for r in reads], [r[2] for r in reads])
+        batch = g.Batch(ix_full, len(reads), B.shape[1])
+        res = batch.map(p, B, Q, Ln)
+        _compare(res, _oracle_results(oracle, oix, op, reads), reads)
+        batch.destroy()
+    batch = g.Batch(ix_full, 4, 8)
+    res = batch.map(p, np.zeros((0, 8), np.uint8), np.zeros((0, 8), np.uint8), np.zeros(0, np.uint16))
+    assert len(res["matches"]) == 0
+
+
+def test_bad_quality_is_an_error(ix_full):
+    p = g.Params()
+    B, Q, Ln = g.pack_reads([b"ACGTACGTACGTACGTACGT"], [b"IIIIIIIIII IIIIIIIII"])      # ' ' = Phred -1
+    batch = g.Batch(ix_full, 1, B.shape[1])
+    with pytest.raises(g.GnumapError, match="Invalid Fastq Character"):
+        batch.map(p, B, Q, Ln)
+
+
+def test_illumina_fallback(ix_full, oracle, oix, syn_reads):
+    """--illumina (Phred+64) with the automatic switch-off at the first read that shows a quality below '@'"""
+    reads = []
+    for i, (n, s, q) in enumerate(syn_reads[:12]):
+        if i < 5:
+            q = bytes(min(126, c + 31) for c in q)            # Phred+64 encoded
+        reads.append((n, s, q))
+    B, Q, Ln = g.pack_reads([r[1] for r in reads], [r[2] for r in reads])
+    p = g.Params(illumina=1)
+    batch = g.Batch(ix_full, len(reads), B.shape[1])
+    res = batch.map(p, B, Q, Ln)
+    op64 = oracle.params(illumina=1); op33 = oracle.params()
+    ores = []
+    for i, (n, s, q) in enumerate(reads):
+        P = oracle.pwm(s, q, illumina=1 if i < 5 else 0)
+        ores.append(oracle.map_read(oix, op64 if i < 5 else op33, P, s))
+    _compare(res, ores, reads)
+
+
+# ------------------------------------------------------------------ end to end: the gnumap binary vs the oracle's run
+def _run_cli(args, out_prefix, syn_fa, syn_fq):
+    exe = os.path.join(ROOT, "gnumap_amd", "bin", "gnumap")
+    r = subprocess.run([exe, "-g", syn_fa, "-o", out_prefix] + args + [syn_fq], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    return r
+
+
+def _sgr(path):
+    d = {}
+    for line in open(path):
+        c, p, v = line.split("\t")
+        d[(c, int(p))] = float(v)
+    return d
+
+
+@pytest.mark.parametrize("name,args,kw", [
+    ("default", [], {}),
+    ("no_nw", ["--no_nw"], dict(nw=0)),
+    ("m16_h150_all", ["-m", "16", "-h", "150", "--print_all_sam"], dict(mer=16, max_kmer_hits=150, print_all_sam=1)),
+    ("bs", ["-b"], dict(mode=1)),
+    ("sampled", ["--locate=sampled"], {}),
+    ("batch64", ["--batch=64"], {}),
+])
+def test_cli_sam_identical_to_oracle(name, args, kw, tmp_path, oracle, oix, syn_fa, syn_fq):
+    mine = str(tmp_path / "mine"); ref = str(tmp_path / "orc")
+    _run_cli(args, mine, syn_fa, syn_fq)
+    oracle.run(oix, oracle.params(**kw), syn_fq, ref, threads=4)
+    a = [l for l in open(mine + ".sam") if not l.startswith("@PG")]
+    b = [l for l in open(ref + ".sam") if not l.startswith("@PG")]
+    assert len(a) > 400
+    assert a == b
+    sa, sb = _sgr(mine + ".sgr"), _sgr(ref + ".sgr")
+    assert set(sa) == set(sb) or max(abs(sa.get(k, 0) - sb.get(k, 0)) for k in set(sa) | set(sb)) < 2e-3
+    for k in sb:
+        assert abs(sa.get(k, 0.0) - sb[k]) <= 1e-4 * max(1.0, abs(sb[k])) + 2e-5, k
