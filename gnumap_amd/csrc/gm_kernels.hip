@@ -115,6 +115,14 @@ __device__ __forceinline__ float gm_max3(float a, float b, float c) {
     return b >= c ? b : c;
 }
 
+// neighbour exchange inside a row of 16 lanes without touching LDS (DPP row shifts)
+__device__ __forceinline__ float gm_from_prev_lane(float v) {      // lane i <- lane i-1   (row_shr:1)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float gm_from_next_lane(float v) {      // lane i <- lane i+1   (row_shl:1)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xF, 0xF, false));
+}
+
 // bns_pos2rid src/bntseq.c:349-363 : last contig whose offset <= pos
 __device__ __forceinline__ uint32_t gm_pos2rid(const GmDevIndex& ix, uint32_t pos) {
     uint32_t lo = 0, hi = ix.n_seqs - 1;
@@ -488,6 +496,145 @@ __global__ void __launch_bounds__(256) k_vote(GmDevIndex ix, GmDevParams p, GmDe
     }
 }
 
+// ---- order-free vote kernel (the fast path) ---------------------------------------------------------------------
+// The seed order only matters for WHEN a position reaches kmin votes (that is the seed step at which the reference
+// runs NW on it).  Per exact-table slot we therefore keep, besides the vote count, a bit mask of the seed steps that
+// voted: all votes of one position come from different seeds (one SA interval holds each text position once), so the
+// step at which the count reaches kmin is the kmin-th lowest set bit.  The only position that can collect several votes
+// from ONE seed is the clamped b = 0 (c <= i, :267); it gets its own per-step counters.  With the order gone, the SA
+// hits of all seeds are one flat list: every lane keeps GMV_U coalesced loads in flight instead of one.
+#define GMV_U 4
+template <bool MASK64>
+__global__ void __launch_bounds__(256) k_vote_fast(GmDevIndex ix, GmDevParams p, GmDevBatch b, int use_full_sa) {
+    __shared__ uint32_t s_A[4][GMV_FWORDS];          // pass 1: "seen" bits; afterwards reused as the low step masks
+    __shared__ uint32_t s_B[4][GMV_FWORDS];          // "seen twice" bits
+    __shared__ uint32_t s_keys[4][GMV_TSIZE];
+    __shared__ uint32_t s_vals[4][GMV_TSIZE];
+    __shared__ uint32_t s_hi[MASK64 ? 4 : 1][MASK64 ? GMV_TSIZE : 1];
+    __shared__ uint32_t s_pre[4][66];                // exclusive prefix of the seeds' hit counts
+    __shared__ uint32_t s_cnt0[4][64];               // votes of b = 0 per seed step
+    const int wave = threadIdx.x >> 6, lane = gm_lane();
+    const uint32_t rs = blockIdx.x * 4 + wave;
+    if (rs >= 2 * b.n) return;                       // wave-uniform; no block barriers below
+    uint32_t ns = b.n_seeds[rs];
+    if (ns == 0) return;
+    if (p.nw && p.fast) ns = 1;                      // --fast: only the first seed is looked at (:309-312)
+    const GmSeed* seeds = b.seeds + (size_t)rs * b.max_seeds;
+    uint32_t* A = s_A[wave]; uint32_t* B = s_B[wave]; uint32_t* pre = s_pre[wave]; uint32_t* cnt0 = s_cnt0[wave];
+    uint32_t* mlo = A; uint32_t* mhi = s_hi[MASK64 ? wave : 0];
+    GmLdsTable tb; tb.keys = s_keys[wave]; tb.vals = s_vals[wave]; tb.mask = GMV_TSIZE - 1; tb.bits = GMV_TBITS;
+    // seeds of this read x strand live in lanes 0..ns-1 (ns <= 64 on this path)
+    GmSeed mine; mine.k = 0; mine.l = 0; mine.pos = 0;
+    uint32_t cnt = 0;
+    if ((uint32_t)lane < ns) { mine = seeds[lane]; cnt = mine.l - mine.k + 1; }
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+    pre[lane + 1] = incl;
+    if (lane == 0) pre[0] = 0;
+    cnt0[lane] = 0;
+    const uint32_t E = __shfl(incl, 63);
+    const uint64_t coff0 = use_full_sa ? 0 : b.entry_off[rs];
+    const bool filter = p.kmin >= 2 && E > GMV_TSIZE / 2;
+    for (int q = lane; q < GMV_TSIZE; q += 64) { tb.keys[q] = GM_EMPTY; tb.vals[q] = 0; if (MASK64) mhi[q] = 0; }
+    for (int q = lane; q < GMV_FWORDS; q += 64) { A[q] = 0; B[q] = 0; }
+
+    // one sweep over the flat hit list; PASS 1 fills the filter, PASS 2 votes
+    auto sweep = [&](const int pass, bool& overflow) {
+        uint32_t nkeys = 0;
+        uint32_t t0 = 0;                             // seed of the first entry of the current group (wave-uniform)
+        for (uint32_t base = 0; base < E && !overflow; base += 64 * GMV_U) {
+            while (t0 + 1 < ns && pre[t0 + 1] <= base) ++t0;
+            uint32_t cc[GMV_U], tt[GMV_U];
+            bool vv[GMV_U];
+#pragma unroll
+            for (int u = 0; u < GMV_U; ++u) {        // which seed does each entry belong to
+                uint32_t e = base + (uint32_t)u * 64 + (uint32_t)lane;
+                vv[u] = e < E;
+                uint32_t t = t0;
+                if (vv[u]) { while (t + 1 < ns && pre[t + 1] <= e) ++t; }
+                tt[u] = t;
+                cc[u] = 0;
+            }
+#pragma unroll
+            for (int u = 0; u < GMV_U; ++u) {
+                uint32_t e = base + (uint32_t)u * 64 + (uint32_t)lane;
+                uint32_t kk = __shfl(mine.k, (int)tt[u]);      // every lane takes part in the shuffle; all loads of the group are issued here
+                if (vv[u]) cc[u] = use_full_sa ? ix.full_sa[kk + (e - pre[tt[u]])] : b.coords[coff0 + e];
+            }
+#pragma unroll
+            for (int u = 0; u < GMV_U; ++u) {
+                uint32_t sp = __shfl(mine.pos, (int)tt[u]);
+                bool fresh = false, full = false;
+                if (vv[u]) {
+                    uint32_t c = cc[u];
+                    uint32_t bp = (c <= sp) ? 0u : c - sp;                      // :267
+                    uint32_t h = (bp * 0x9E3779B1u) >> (32 - GMV_FBITS);
+                    uint32_t bit = 1u << (h & 31);
+                    if (pass == 1) {
+                        if (bp != 0) { uint32_t old = atomicOr(&A[h >> 5], bit); if (old & bit) atomicOr(&B[h >> 5], bit); }
+                    } else if (bp == 0) {
+                        atomicAdd(&cnt0[tt[u]], 1u);
+                    } else if (!filter || (B[h >> 5] & bit)) {
+                        uint32_t slot = gm_table_insert(tb, bp, &fresh);
+                        if (slot == GM_EMPTY) full = true;
+                        else {
+                            atomicAdd(&tb.vals[slot], 1u);
+                            if (tt[u] < 32) atomicOr(&mlo[slot], 1u << tt[u]);
+                            else if (MASK64) atomicOr(&mhi[slot], 1u << (tt[u] - 32));
+                        }
+                    }
+                }
+                if (pass == 2) {
+                    nkeys += (uint32_t)__popcll(__ballot(fresh));
+                    if (__ballot(full) != 0 || nkeys > GMV_TLIMIT) overflow = true;
+                }
+            }
+        }
+    };
+    bool overflow = false;
+    if (filter) sweep(1, overflow);
+    // the low step masks reuse A: clear it now that pass 1 is over
+    for (int q = lane; q < GMV_TSIZE; q += 64) mlo[q] = 0;
+    sweep(2, overflow);
+    if (overflow) {                                  // hand this read x strand to the global-table kernel
+        if (lane == 0) {
+            b.rs_overflow[rs] = 1;
+            uint32_t j = atomicAdd(b.n_retry, 1u);
+            uint32_t need = 2 * E; uint32_t sz = 1024; while (sz < need && sz < 0x80000000u) sz <<= 1;
+            unsigned long long off = atomicAdd(&b.counters[GMK_HEAVY_SLOTS], (unsigned long long)sz);
+            b.retry_list[j] = rs;
+            b.retry_off[j] = off;
+            atomicAdd(&b.counters[GMK_OVERFLOW_RS], 1ull);
+        }
+        return;
+    }
+    // emit every position with >= kmin votes; its NW step is the kmin-th lowest step that voted for it
+    for (int q = lane; q < GMV_TSIZE; q += 64) {
+        uint32_t key = tb.keys[q], v = tb.vals[q];
+        bool emit = key != GM_EMPTY && v >= (uint32_t)p.kmin;
+        uint32_t step = 0;
+        if (emit) {
+            if (p.nw) {
+                unsigned long long m = (unsigned long long)mlo[q] | (MASK64 ? ((unsigned long long)mhi[q] << 32) : 0ull);
+                for (int r = 1; r < p.kmin && m; ++r) m &= m - 1;
+                step = m ? (uint32_t)(__ffsll((long long)m) - 1) : 0u;
+            } else step = v > 65535u ? 65535u : v;
+        }
+        gm_emit<GmLdsTable>(b, emit, rs, key, step, 4);
+    }
+    {   // b = 0: cumulative per-step counts
+        uint32_t c0 = cnt0[lane], run = c0;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(run, off); if (lane >= off) run += t; }
+        uint32_t total = __shfl(run, 63);
+        unsigned long long reached = __ballot(run >= (uint32_t)p.kmin);
+        bool emit = lane == 0 && total >= (uint32_t)p.kmin;
+        uint32_t step = p.nw ? (uint32_t)(__ffsll((long long)reached) - 1) : (total > 65535u ? 65535u : total);
+        gm_emit<GmLdsTable>(b, emit, rs, 0u, step, 4);
+    }
+}
+
 // retry path: one workgroup per overflowed read x strand, exact vote table in HBM (pre-set to EMPTY/0 by the host)
 struct GmGlobalTable {
     uint32_t* keys; uint32_t* vals; uint32_t mask; int bits;
@@ -606,23 +753,34 @@ __global__ void __launch_bounds__(256) k_nw(GmDevIndex ix, GmDevParams p, GmDevB
             int Lw = (int)L;                              // wave-uniform sweep length = longest read in the wave
 #pragma unroll
             for (int off = 8; off < 64; off <<= 1) { int o = __shfl_xor(Lw, off); Lw = o > Lw ? o : Lw; }
+            // lane delta walks its diagonal from the bottom-right: cells (i, i+delta), i = i0 .. imin; it is due at s = 2i+delta,
+            // i.e. every other step, so the substitution score of its NEXT cell is fetched from LDS in the idle step
+            const int imin = delta < 0 ? -delta : 0;
+            int icur = (ok && d < 7) ? ((int)L - 1 - (delta > 0 ? delta : 0)) : -1;
+            float vcur = 0.0f;
+            if (icur >= imin) {
+                uint32_t row = rows[icur];
+                float2 pq = lut[row & 255u];
+                vcur = gm_get_val(row >> 8, pq.x, pq.y, S.sg + 4 * win[icur + delta]);
+            }
             for (int s = 2 * Lw - 2; s >= 0; --s) {
-                float a = __shfl(own, lane - 1);          // diagonal delta-1, cell (i+1, j)
-                float bb = __shfl(own, lane + 1);         // diagonal delta+1, cell (i, j+1)
-                int i2 = s - delta;
-                int i = i2 >> 1, j = i + delta;
-                bool act = ok && d < 7 && i2 >= 0 && !(i2 & 1) && i < (int)L && j >= 0 && j < (int)L;
-                if (d == 0) a = (i + 1 == (int)L) ? gap4 : GM_NEG_INF;    // outside the band except on the last row
-                if (d == 6) bb = (j + 1 == (int)L) ? gap4 : GM_NEG_INF;   // ... or the last column
+                float a = gm_from_prev_lane(own);         // diagonal delta-1, cell (i+1, j)
+                float bb = gm_from_next_lane(own);        // diagonal delta+1, cell (i, j+1)
+                const bool act = icur >= imin && s == 2 * icur + delta;
+                if (d == 0) a = (icur + 1 == (int)L) ? gap4 : GM_NEG_INF;             // outside the band except on the last row
+                if (d == 6) bb = (icur + delta + 1 == (int)L) ? gap4 : GM_NEG_INF;    // ... or the last column
                 if (act) {
-                    uint32_t row = rows[i];
-                    float2 pq = lut[row & 255u];
-                    float val = gm_get_val(row >> 8, pq.x, pq.y, S.sg + 4 * win[j]);
-                    float mm = __fadd_rn(own, val);
+                    float mm = __fadd_rn(own, vcur);
                     float g1 = __fadd_rn(a, gap);
                     float g2 = __fadd_rn(bb, gap);
                     own = gm_max3(mm, g1, g2);
                     ++cells;
+                    --icur;
+                    if (icur >= imin) {
+                        uint32_t row = rows[icur];
+                        float2 pq = lut[row & 255u];
+                        vcur = gm_get_val(row >> 8, pq.x, pq.y, S.sg + 4 * win[icur + delta]);
+                    }
                 }
             }
             result = __shfl(own, (lane & ~7) + 3);        // nm[0][0] lives on diagonal 0
@@ -699,26 +857,37 @@ __global__ void __launch_bounds__(256) k_traceback(GmDevIndex ix, GmDevParams p,
         int Lw = (int)L;
 #pragma unroll
         for (int off = 8; off < 64; off <<= 1) { int o = __shfl_xor(Lw, off); Lw = o > Lw ? o : Lw; }
+        // lane delta walks its diagonal from the top-left: cells (i, i+delta), i = imin .. imax, due at s = 2i+delta
+        const int imin = delta < 0 ? 1 - delta : 1;
+        const int imax = (int)L - (delta > 0 ? delta : 0);
+        int icur = (ok && d < 7) ? imin : 0x7fffffff;
+        float vcur = 0.0f;
+        if (icur <= imax) {
+            uint32_t row = rows[icur - 1];
+            float2 pq = lut[row & 255u];
+            vcur = gm_get_val(row >> 8, pq.x, pq.y, S.sg + 4 * win[icur + delta - 1]);
+        }
         for (int s = 2; s <= 2 * Lw; ++s) {
-            float u_nb = __shfl(own, lane + 1);           // diagonal delta+1, cell (i-1, j)
-            float l_nb = __shfl(own, lane - 1);           // diagonal delta-1, cell (i, j-1)
-            int i2 = s - delta;
-            int i = i2 >> 1, j = i + delta;
-            bool act = ok && d < 7 && !(i2 & 1) && i >= 1 && i <= (int)L && j >= 1 && j <= (int)L;
-            if (d == 6) u_nb = (i - 1 == 0) ? gap4 : GM_NEG_INF;
-            if (d == 0) l_nb = (j - 1 == 0) ? gap4 : GM_NEG_INF;
+            float u_nb = gm_from_next_lane(own);          // diagonal delta+1, cell (i-1, j)
+            float l_nb = gm_from_prev_lane(own);          // diagonal delta-1, cell (i, j-1)
+            const bool act = icur <= imax && s == 2 * icur + delta;
+            if (d == 6) u_nb = (icur - 1 == 0) ? gap4 : GM_NEG_INF;
+            if (d == 0) l_nb = (icur + delta - 1 == 0) ? gap4 : GM_NEG_INF;
             if (act) {
-                uint32_t row = rows[i - 1];
-                float2 pq = lut[row & 255u];
-                float val = gm_get_val(row >> 8, pq.x, pq.y, S.sg + 4 * win[j - 1]);
-                float dd = __fadd_rn(own, val);
+                float dd = __fadd_rn(own, vcur);
                 float u = __fadd_rn(u_nb, gap);
                 float l = __fadd_rn(l_nb, gap);
                 uint32_t m; float best;                   // max_flt(char&,...) src/bin_seq.cpp:989-1011
                 if (dd >= u) { if (dd >= l) { m = 0; best = dd; } else { m = 2; best = l; } }
                 else         { if (u >= l)  { m = 1; best = u; }  else { m = 2; best = l; } }
                 own = best;
-                mv[i >> 4] |= m << ((i & 15) << 1);
+                mv[icur >> 4] |= m << ((icur & 15) << 1);
+                ++icur;
+                if (icur <= imax) {
+                    uint32_t row = rows[icur - 1];
+                    float2 pq = lut[row & 255u];
+                    vcur = gm_get_val(row >> 8, pq.x, pq.y, S.sg + 4 * win[icur + delta - 1]);
+                }
             }
         }
         __syncthreads();
@@ -841,7 +1010,10 @@ int gmk_locate_sampled(const GmDevIndex& ix, const GmDevBatch& b, void* stream) 
 
 int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, void* stream) {
     if (b.n == 0) return 0;
-    hipLaunchKernelGGL(k_vote, dim3(cdiv(2ull * b.n, 4)), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
+    // order-free fast path while the seed steps fit a 64-bit mask; the ordered kernel is the general form
+    if (b.max_seeds <= 32) hipLaunchKernelGGL(k_vote_fast<false>, dim3(cdiv(2ull * b.n, 4)), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
+    else if (b.max_seeds <= 64) hipLaunchKernelGGL(k_vote_fast<true>, dim3(cdiv(2ull * b.n, 4)), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
+    else hipLaunchKernelGGL(k_vote, dim3(cdiv(2ull * b.n, 4)), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
     return (int)hipGetLastError();
 }
 
