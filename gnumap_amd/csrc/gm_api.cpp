@@ -61,7 +61,7 @@ struct gm_index {
     int device = -1;
     bool host_only = false;
     bool full_sa = false;
-    DevBuf d_bwt, d_sa, d_full, d_pac, d_contig, d_cov, d_ptab;
+    DevBuf d_bwt, d_sa, d_full, d_pac, d_contig, d_cov, d_ptab, d_planes;
     GmDevIndex dev{};
     uint64_t cov_bins = 0;
     uint32_t cov_bin_size = 0;
@@ -250,6 +250,14 @@ extern "C" int gm_index_open(const char* fasta_path, int device_id, int flags, g
     d.sa_mask = h.sa_intv - 1; d.sa_shift = 0;
     while ((1u << d.sa_shift) < h.sa_intv) ++d.sa_shift;
     for (int i = 0; i < 5; ++i) d.L2[i] = (uint32_t)h.L2[i];
+    {   // derive the bit-plane rank structure (one 16-byte load per rank query) from the reference-format BWT, once
+        d.occ_nblk = (uint32_t)((h.seq_len + 95) / 96) + 1;
+        if (ix->d_planes.ensure((size_t)4 * d.occ_nblk * 16)) return fail(GM_E_NOMEM);
+        if (hipMemset(ix->d_planes.p, 0, (size_t)4 * d.occ_nblk * 16) != hipSuccess) { gm_set_error("plane memset failed"); return fail(GM_E_HIP); }
+        int e = gmk_build_occ_planes(d, ix->d_planes.as<uint4>(), d.occ_nblk, nullptr);
+        if (e || hipDeviceSynchronize() != hipSuccess) { gm_set_error("occ plane construction failed"); return fail(GM_E_HIP); }
+        d.occ_planes = ix->d_planes.as<uint4>();
+    }
     if (flags & GM_INDEX_FULL_SA) {
         if (ix->d_full.ensure(((size_t)h.seq_len + 1) * 4)) return fail(GM_E_NOMEM);
         int e = gmk_expand_full_sa(d, ix->d_full.as<uint32_t>(), nullptr);
@@ -257,7 +265,7 @@ extern "C" int gm_index_open(const char* fasta_path, int device_id, int flags, g
         d.full_sa = ix->d_full.as<uint32_t>();
         ix->full_sa = true;
     }
-    ix->hbm_bytes = ix->d_bwt.cap + ix->d_sa.cap + ix->d_pac.cap + ix->d_contig.cap + ix->d_full.cap;
+    ix->hbm_bytes = ix->d_bwt.cap + ix->d_sa.cap + ix->d_pac.cap + ix->d_contig.cap + ix->d_full.cap + ix->d_planes.cap;
     *out = ix;
     return GM_OK;
 }
@@ -267,7 +275,7 @@ extern "C" void gm_index_close(gm_index* ix) {
     if (!ix->host_only && ix->device >= 0) {
         (void)hipSetDevice(ix->device);
         ix->d_bwt.release(); ix->d_sa.release(); ix->d_full.release(); ix->d_pac.release(); ix->d_contig.release();
-        ix->d_cov.release(); ix->d_ptab.release();
+        ix->d_cov.release(); ix->d_ptab.release(); ix->d_planes.release();
     }
     delete ix;
 }
@@ -379,6 +387,7 @@ static void fill_dev_batch(gm_batch* b) {
 extern "C" int gm_batch_upload(gm_batch* b, const gm_params* p, const gm_reads* r, void* stream) {
     if (!b || !p || !r || !p->finalized) return GM_E_ARG;
     if (r->n > b->max_reads || r->stride > 4096) { gm_set_error("batch larger than gm_batch_create allowed"); return GM_E_ARG; }
+    if (r->stride % 8 != 0) { gm_set_error("gm_reads.stride must be a multiple of 8"); return GM_E_ARG; }
     HIPCHK(hipSetDevice(b->ix->device));
     hipStream_t st = S_(stream);
     b->n = r->n; b->stride = r->stride; b->mapped = false;
@@ -419,6 +428,15 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
     b->mapped = false;
     if (b->n == 0) { b->n_cands = 0; b->n_raw = 0; b->mapped = true; memset(b->counters_host, 0, sizeof b->counters_host); return GM_OK; }
     const int use_full = ix->full_sa ? 1 : 0;
+    // expected SA hits per seed ~ reference length / 4^mer: dense seeds get one workgroup per read x strand in the vote
+    // kernel, sparse ones one wavefront (GM_VOTE=wave|block overrides the heuristic)
+    int dense = 0;
+    {
+        double per_seed = (double)ix->h.seq_len / pow(4.0, (double)std::min(p->mer, 31));
+        if (p->max_kmer_hits > 0) per_seed = std::min(per_seed, (double)p->max_kmer_hits);
+        dense = per_seed >= 8.0;
+        if (const char* ev = getenv("GM_VOTE")) dense = !strcmp(ev, "block") ? 1 : !strcmp(ev, "wave") ? 0 : dense;
+    }
     fill_dev_batch(b);
     HIPCHK(hipMemsetAsync(b->counters.p, 0, GMK_N * 8, st));
     { KTimer t(b, GM_K_PREP, st); KCHK(gmk_prep(ix->dev, dp, b->dev, st)); }
@@ -438,7 +456,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         HIPCHK(hipMemsetAsync(b->rs_overflow.p, 0, 2 * (size_t)b->n, st));
         HIPCHK(hipMemsetAsync(b->counters.as<unsigned long long>() + GMK_HEAVY_SLOTS, 0, 8, st));
         HIPCHK(hipMemsetAsync(b->counters.as<unsigned long long>() + GMK_OVERFLOW_RS, 0, 8, st));
-        { KTimer t(b, GM_K_VOTE, st); KCHK(gmk_vote(ix->dev, dp, b->dev, use_full, st)); }
+        { KTimer t(b, GM_K_VOTE, st); KCHK(gmk_vote(ix->dev, dp, b->dev, use_full, dense, st)); }
         uint32_t small[2];
         HIPCHK(hipMemcpyAsync(small, b->small.p, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(ctr, b->counters.p, sizeof ctr, hipMemcpyDeviceToHost, st));
@@ -754,6 +772,10 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
         if (!p->print_all_sam && best >= 0 && (double)hits->matches[best].score > hits->top_score[i] - 0.00001)   // Driver.cpp:695
             emit(i, hits->matches[best], (uint64_t)best, den);
     }
+    // capacity first: a call that is going to be repeated with larger buffers must not deposit coverage twice
+    bool fits = recs.size() <= out->recs_cap && pool.size() <= out->cigar_cap;
+    out->n_recs = recs.size(); out->cigar_len = pool.size();
+    if (!fits) { out->recs_cap = recs.size(); out->cigar_cap = pool.size(); gm_set_error("output buffers too small"); return GM_E_CAPACITY; }
     if (ix->cov_bins && !dpos.empty()) {
         size_t nd = dpos.size();
         if (b->dep_pos.ensure(nd * 8) || b->dep_span.ensure(nd * 4) || b->dep_w.ensure(nd * 4)) return GM_E_NOMEM;
@@ -764,9 +786,6 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
                               b->dep_w.as<float>(), (uint32_t)nd, max_span, st));
         HIPCHK(hipStreamSynchronize(st));
     }
-    bool fits = recs.size() <= out->recs_cap && pool.size() <= out->cigar_cap;
-    out->n_recs = recs.size(); out->cigar_len = pool.size();
-    if (!fits) { out->recs_cap = recs.size(); out->cigar_cap = pool.size(); gm_set_error("output buffers too small"); return GM_E_CAPACITY; }
     if (!recs.empty()) memcpy(out->recs, recs.data(), recs.size() * sizeof(gm_sam_rec));
     if (!pool.empty()) memcpy(out->cigar_pool, pool.data(), pool.size());
     return GM_OK;

@@ -11,8 +11,13 @@
 // sa_samples: rank-sampled suffix array (every 32nd rank), narrowed to u32; [0] = 0xFFFFFFFF (= (u64)-1 mod 2^32)
 // full_sa  : optional full suffix array SA[0..seq_len], u32, expanded on device from the samples
 // pac      : 2 bit/base, 4 per byte MSB first (reference: _get_pac src/bntseq.c:225)
+// occ_planes: the MI355X-native rank structure derived from bwt once per index: for each base c a bit plane over the
+//            $-removed BWT, cut into 16-byte granules {u32 count of c before the granule, 96 membership bits}, so that
+//            one rank query (bwt_occ) is ONE 16-byte load + three popcounts.  planes[c * occ_nblk + x / 96].
 struct GmDevIndex {
     const uint32_t* bwt;
+    const uint4* occ_planes;
+    uint32_t occ_nblk;
     const uint32_t* sa_samples;
     const uint32_t* full_sa;
     const uint8_t* pac;
@@ -84,11 +89,12 @@ struct GmDevBatch {
 #ifdef __cplusplus
 extern "C++" {
 int gmk_expand_full_sa(const GmDevIndex& ix, uint32_t* full_sa, void* stream);
+int gmk_build_occ_planes(const GmDevIndex& ix, uint4* planes, uint32_t nblk, void* stream);
 int gmk_prep(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream);
 int gmk_seed(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream);
 int gmk_scan_entries(const GmDevBatch& b, void* stream);
 int gmk_locate_sampled(const GmDevIndex& ix, const GmDevBatch& b, void* stream);
-int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, void* stream);
+int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, int dense, void* stream);
 int gmk_vote_retry(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, uint32_t n_retry, void* stream);
 int gmk_nw(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream);
 int gmk_compact(const GmDevBatch& b, void* stream);

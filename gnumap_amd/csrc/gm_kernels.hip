@@ -80,6 +80,20 @@ __device__ __forceinline__ uint32_t gm_occ(const GmDevIndex& ix, uint32_t k, uin
     return n;
 }
 
+// the same rank query on the bit-plane layout: one 16-byte load.  x-space = positions of the $-removed BWT.
+__device__ __forceinline__ uint32_t gm_occ_plane(const GmDevIndex& ix, uint32_t k, uint32_t c) {
+    if (k == ix.seq_len) return gm_L2n(ix, c) - gm_L2(ix, c);
+    if (k == 0xFFFFFFFFu) return 0;
+    uint32_t x = k - ((k >= ix.primary) ? 1u : 0u);
+    uint32_t blk = x / 96u;
+    int r = (int)(x - blk * 96u) + 1;                       // bits [0, r) of the granule count
+    const uint4 v = ix.occ_planes[(size_t)c * ix.occ_nblk + blk];
+    uint32_t m0 = r >= 32 ? 0xFFFFFFFFu : ((1u << r) - 1u);
+    uint32_t m1 = r >= 64 ? 0xFFFFFFFFu : (r > 32 ? ((1u << (r - 32)) - 1u) : 0u);
+    uint32_t m2 = r >= 96 ? 0xFFFFFFFFu : (r > 64 ? ((1u << (r - 64)) - 1u) : 0u);
+    return v.x + (uint32_t)__popc(v.y & m0) + (uint32_t)__popc(v.z & m1) + (uint32_t)__popc(v.w & m2);
+}
+
 // bwt_invPsi src/bwt.c:53-59
 __device__ __forceinline__ uint32_t gm_inv_psi(const GmDevIndex& ix, uint32_t k) {
     uint32_t x = k - ((k > ix.primary) ? 1u : 0u);
@@ -124,19 +138,19 @@ __device__ __forceinline__ float gm_from_next_lane(float v) {      // lane i <- 
 }
 
 // bns_pos2rid src/bntseq.c:349-363 : last contig whose offset <= pos
-__device__ __forceinline__ uint32_t gm_pos2rid(const GmDevIndex& ix, uint32_t pos) {
-    uint32_t lo = 0, hi = ix.n_seqs - 1;
+__device__ __forceinline__ uint32_t gm_pos2rid(const uint32_t* coff, uint32_t n_seqs, uint32_t pos) {
+    uint32_t lo = 0, hi = n_seqs - 1;
     while (lo < hi) {
         uint32_t mid = (lo + hi + 1) >> 1;
-        if (pos >= ix.contig_off[mid]) lo = mid; else hi = mid - 1;
+        if (pos >= coff[mid]) lo = mid; else hi = mid - 1;
     }
     return lo;
 }
 
 // GenomeBwt::GetString src/GenomeBwt.cpp:384-415 validity: the window must lie inside one contig
-__device__ __forceinline__ bool gm_window_ok(const GmDevIndex& ix, uint32_t begin, uint32_t L) {
+__device__ __forceinline__ bool gm_window_ok(const GmDevIndex& ix, const uint32_t* coff, uint32_t begin, uint32_t L) {
     if ((unsigned long long)begin + L > ix.l_pac) return false;
-    return gm_pos2rid(ix, begin) == gm_pos2rid(ix, begin + L - 1);
+    return gm_pos2rid(coff, ix.n_seqs, begin) == gm_pos2rid(coff, ix.n_seqs, begin + L - 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -157,6 +171,31 @@ __global__ void __launch_bounds__(256) k_expand_full_sa(GmDevIndex ix, uint32_t*
     }
 }
 
+// one thread per 96-position granule: derives the four bit planes from the reference-format BWT
+__global__ void __launch_bounds__(256) k_build_occ_planes(GmDevIndex ix, uint4* planes, uint32_t nblk) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nblk) return;
+    uint32_t x0 = j * 96u;
+    uint32_t w[4][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
+    for (uint32_t t = 0; t < 96; ++t) {
+        uint32_t x = x0 + t;
+        if (x >= ix.seq_len) break;
+        uint32_t word = ix.bwt[((size_t)(x >> 7) << 4) + 8 + ((x & 0x7fu) >> 4)];     // bwt_B0 inc/bwt.h:72-78
+        uint32_t c = (word >> ((~x & 0xfu) << 1)) & 3u;
+        w[c][t >> 5] |= 1u << (t & 31);
+    }
+    for (uint32_t c = 0; c < 4; ++c) {
+        uint32_t cnt = 0;
+        if (j > 0) {
+            uint32_t xl = x0 - 1;                            // last position before the granule, back in rank space
+            uint32_t k = xl < ix.primary ? xl : xl + 1;
+            cnt = gm_occ(ix, k, c);
+        }
+        uint4 v; v.x = cnt; v.y = w[c][0]; v.z = w[c][1]; v.w = w[c][2];
+        planes[(size_t)c * nblk + j] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // prep: one thread per read
 // ------------------------------------------------------------------------------------------------
@@ -172,12 +211,20 @@ __global__ void __launch_bounds__(256) k_prep(GmDevIndex ix, GmDevParams p, GmDe
         float self = 0.0f;
         double mn;
         float score = 0.0f;
-        for (uint32_t i = 0; i < L; ++i) {
-            uint32_t ch = rb[i];
-            float2 pq = lut[rq[i]];
-            if (pq.x != pq.x) bad = 1;                       // negative probability (SeqReader.cpp:1171-1189)
-            const float* s = p.S256 + ch * 4;
-            score = __fadd_rn(score, gm_get_val(gm_nt4(ch), pq.x, pq.y, s));
+        for (uint32_t i0 = 0; i0 < L; i0 += 8) {             // rows are 8-byte aligned (stride is a multiple of 8)
+            const uint2 bw = *reinterpret_cast<const uint2*>(rb + i0);
+            const uint2 qw = *reinterpret_cast<const uint2*>(rq + i0);
+#pragma unroll
+            for (uint32_t t = 0; t < 8; ++t) {
+                if (i0 + t < L) {
+                    uint32_t ch = ((t < 4 ? bw.x : bw.y) >> ((t & 3) * 8)) & 255u;
+                    uint32_t qc = ((t < 4 ? qw.x : qw.y) >> ((t & 3) * 8)) & 255u;
+                    float2 pq = lut[qc];
+                    if (pq.x != pq.x) bad = 1;               // negative probability (SeqReader.cpp:1171-1189)
+                    const float* s = p.S256 + ch * 4;
+                    score = __fadd_rn(score, gm_get_val(gm_nt4(ch), pq.x, pq.y, s));
+                }
+            }
         }
         if (L < (uint32_t)p.mer) {
             st = -2;                                         // READ_TOO_SHORT
@@ -205,6 +252,23 @@ __global__ void __launch_bounds__(256) k_prep(GmDevIndex ix, GmDevParams p, GmDe
 // seed: one lane per read x strand walks the read exactly like align_sequence does
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_seed(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
+    // the 128 reads of this workgroup (2 lanes per read: + and - strand) are staged into LDS with coalesced 16-byte loads
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_reads[];
+    const uint32_t r0 = blockIdx.x * 128u;
+    {
+        const uint32_t nr = b.n - r0 < 128u ? b.n - r0 : 128u;
+        const size_t bytes = (size_t)nr * b.stride;                       // stride is a multiple of 8; r0 * stride of 16 when stride % 16 == 0
+        const unsigned char* src = b.bases + (size_t)r0 * b.stride;
+        if ((((size_t)src) & 15) == 0) {
+            for (size_t o = (size_t)threadIdx.x * 16; o < bytes; o += 256 * 16) {
+                if (o + 16 <= bytes) *reinterpret_cast<uint4*>(s_reads + o) = *reinterpret_cast<const uint4*>(src + o);
+                else for (size_t q = o; q < bytes; ++q) s_reads[q] = src[q];
+            }
+        } else {
+            for (size_t o = (size_t)threadIdx.x * 8; o < bytes; o += 256 * 8) *reinterpret_cast<uint2*>(s_reads + o) = *reinterpret_cast<const uint2*>(src + o);
+        }
+    }
+    __syncthreads();
     uint32_t rs = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long nk = 0, nocc = 0, nblk = 0, nseed = 0, nent = 0;
     if (rs < 2 * b.n) {
@@ -212,7 +276,7 @@ __global__ void __launch_bounds__(256) k_seed(GmDevIndex ix, GmDevParams p, GmDe
         bool on = b.status[r] == 0 && (strand ? p.neg_strand : p.pos_strand);
         if (on) {
             uint32_t L = b.len[r];
-            const uint8_t* rb = b.bases + (size_t)r * b.stride;
+            const unsigned char* rb = s_reads + (size_t)(r - r0) * b.stride;
             GmSeed* out = b.seeds + (size_t)rs * b.max_seeds;
             uint32_t last = L - (uint32_t)p.mer;
             uint32_t i = 0;
@@ -227,10 +291,11 @@ __global__ void __launch_bounds__(256) k_seed(GmDevIndex ix, GmDevParams p, GmDe
                     uint32_t c = gm_nt4(strand ? rb[L - 1 - pos] : rb[pos]);
                     if (c > 3) { ok = false; break; }
                     if (strand) c = 3 - c;
-                    uint32_t ok_ = gm_occ(ix, k - 1, c);
-                    uint32_t ol_ = gm_occ(ix, l, c);
+                    uint32_t ok_ = gm_occ_plane(ix, k - 1, c);
+                    uint32_t ol_ = gm_occ_plane(ix, l, c);
                     nocc += 2;
-                    {   // 64-byte blocks this step touches (bwt_2occ src/bwt.c:132-163: one when k-1 and l share a block)
+                    {   // 64-byte blocks of the REFERENCE layout this step touches (bwt_2occ src/bwt.c:132-163: one when k-1 and l
+                        // share a block) - kept as the unit of the algorithmic-bytes accounting
                         uint32_t k1 = k - 1, kb = k1 - ((k1 >= ix.primary) ? 1u : 0u), lb = l - ((l >= ix.primary) ? 1u : 0u);
                         bool ks = (k1 == 0xFFFFFFFFu) || (k1 == ix.seq_len), ls = (l == ix.seq_len);
                         nblk += (ks ? 0u : 1u) + (ls ? 0u : 1u) - ((!ks && !ls && (kb >> 7) == (lb >> 7)) ? 1u : 0u);
@@ -635,6 +700,158 @@ __global__ void __launch_bounds__(256) k_vote_fast(GmDevIndex ix, GmDevParams p,
     }
 }
 
+// ---- order-free vote kernel, one WORKGROUP per read x strand (dense seeds: tens of SA hits per seed and more) ----
+// Same algorithm as k_vote_fast, but the flat hit list of the read x strand is spread over 256 lanes: every lane issues
+// all of its (up to GMB_U) loads at once - one HBM latency per read x strand instead of one per 256 hits - and keeps the
+// located positions in registers, so the second (exact) pass does not touch memory again.
+#define GMB_U 8
+template <bool MASK64>
+__global__ void __launch_bounds__(256) k_vote_block(GmDevIndex ix, GmDevParams p, GmDevBatch b, int use_full_sa) {
+    __shared__ uint32_t s_A[GMV_FWORDS];             // pass 1 "seen" bits, later the low step masks
+    __shared__ uint32_t s_B[GMV_FWORDS];             // "seen twice"
+    __shared__ uint32_t s_keys[GMV_TSIZE];
+    __shared__ uint32_t s_vals[GMV_TSIZE];
+    __shared__ uint32_t s_hi[MASK64 ? GMV_TSIZE : 1];
+    __shared__ uint32_t s_pre[66], s_k[64], s_pos[64], s_cnt0[64];
+    __shared__ uint32_t s_nkeys, s_full;
+    const uint32_t rs = blockIdx.x;                  // grid = 2n
+    const int tid = threadIdx.x, lane = gm_lane();
+    uint32_t ns = b.n_seeds[rs];
+    if (ns == 0) return;                             // block-uniform
+    if (p.nw && p.fast) ns = 1;
+    const GmSeed* seeds = b.seeds + (size_t)rs * b.max_seeds;
+    if (tid < 64) {                                  // wave 0: seeds -> LDS, exclusive prefix of their hit counts
+        GmSeed mine; mine.k = 0; mine.l = 0; mine.pos = 0;
+        uint32_t cnt = 0;
+        if ((uint32_t)tid < ns) { mine = seeds[tid]; cnt = mine.l - mine.k + 1; }
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+        s_pre[tid + 1] = incl; s_k[tid] = mine.k; s_pos[tid] = mine.pos; s_cnt0[tid] = 0;
+        if (tid == 0) { s_pre[0] = 0; s_nkeys = 0; s_full = 0; }
+    }
+    for (int q = tid; q < GMV_TSIZE; q += 256) { s_keys[q] = GM_EMPTY; s_vals[q] = 0; if (MASK64) s_hi[q] = 0; }
+    for (int q = tid; q < GMV_FWORDS; q += 256) { s_A[q] = 0; s_B[q] = 0; }
+    __syncthreads();
+    const uint32_t E = s_pre[ns];
+    const uint64_t coff0 = use_full_sa ? 0 : b.entry_off[rs];
+    const bool filter = p.kmin >= 2 && E > GMV_TSIZE / 2;
+    const bool one_round = E <= 256u * GMB_U;
+    GmLdsTable tb; tb.keys = s_keys; tb.vals = s_vals; tb.mask = GMV_TSIZE - 1; tb.bits = GMV_TBITS;
+    uint32_t bpv[GMB_U], ttv[GMB_U];
+
+    auto load_round = [&](uint32_t base) {           // located position (as window start) of up to GMB_U entries per lane
+        uint32_t ee[GMB_U];
+#pragma unroll
+        for (int u = 0; u < GMB_U; ++u) {
+            uint32_t e = base + (uint32_t)u * 256u + (uint32_t)tid;
+            ee[u] = e;
+            uint32_t t = 0;
+            if (e < E) { uint32_t lo = 0, hi = ns; while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (s_pre[mid] <= e) lo = mid; else hi = mid; } t = lo; }
+            ttv[u] = e < E ? t : 0xFFFFFFFFu;
+        }
+        uint32_t cc[GMB_U];
+#pragma unroll
+        for (int u = 0; u < GMB_U; ++u) {            // all loads in flight together
+            cc[u] = 0;
+            if (ttv[u] != 0xFFFFFFFFu) cc[u] = use_full_sa ? ix.full_sa[s_k[ttv[u]] + (ee[u] - s_pre[ttv[u]])] : b.coords[coff0 + ee[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < GMB_U; ++u) {
+            uint32_t sp = ttv[u] != 0xFFFFFFFFu ? s_pos[ttv[u]] : 0u;
+            bpv[u] = (cc[u] <= sp) ? 0u : cc[u] - sp;                       // :267
+        }
+    };
+    auto pass1 = [&]() {
+#pragma unroll
+        for (int u = 0; u < GMB_U; ++u)
+            if (ttv[u] != 0xFFFFFFFFu && bpv[u] != 0) {
+                uint32_t h = (bpv[u] * 0x9E3779B1u) >> (32 - GMV_FBITS), bit = 1u << (h & 31);
+                uint32_t old = atomicOr(&s_A[h >> 5], bit);
+                if (old & bit) atomicOr(&s_B[h >> 5], bit);
+            }
+    };
+    auto pass2 = [&]() {
+        uint32_t nfresh = 0; bool full = false;
+#pragma unroll
+        for (int u = 0; u < GMB_U; ++u)
+            if (ttv[u] != 0xFFFFFFFFu) {
+                uint32_t bp = bpv[u], t = ttv[u];
+                uint32_t h = (bp * 0x9E3779B1u) >> (32 - GMV_FBITS), bit = 1u << (h & 31);
+                if (bp == 0) atomicAdd(&s_cnt0[t], 1u);
+                else if (!filter || (s_B[h >> 5] & bit)) {
+                    bool fresh;
+                    uint32_t slot = gm_table_insert(tb, bp, &fresh);
+                    if (slot == GM_EMPTY) full = true;
+                    else {
+                        nfresh += fresh ? 1u : 0u;
+                        atomicAdd(&s_vals[slot], 1u);
+                        if (t < 32) atomicOr(&s_A[slot], 1u << t);          // low step mask (A is free after pass 1)
+                        else if (MASK64) atomicOr(&s_hi[slot], 1u << (t - 32));
+                    }
+                }
+            }
+        if (nfresh) atomicAdd(&s_nkeys, nfresh);
+        if (full) s_full = 1;
+    };
+
+    if (one_round) {
+        load_round(0);
+        if (filter) pass1();
+        __syncthreads();
+        for (int q = tid; q < GMV_TSIZE; q += 256) s_A[q] = 0;              // A becomes the low step masks
+        __syncthreads();
+        pass2();
+    } else {
+        if (filter) for (uint32_t base = 0; base < E; base += 256u * GMB_U) { load_round(base); pass1(); }
+        __syncthreads();
+        for (int q = tid; q < GMV_TSIZE; q += 256) s_A[q] = 0;
+        __syncthreads();
+        for (uint32_t base = 0; base < E; base += 256u * GMB_U) {
+            load_round(base);
+            pass2();
+            __syncthreads();
+            if (s_full || s_nkeys > GMV_TLIMIT) break;                       // block-uniform
+        }
+    }
+    __syncthreads();
+    if (s_full || s_nkeys > GMV_TLIMIT) {           // hand this read x strand to the global-table kernel
+        if (tid == 0) {
+            b.rs_overflow[rs] = 1;
+            uint32_t j = atomicAdd(b.n_retry, 1u);
+            uint32_t need = 2 * E; uint32_t sz = 1024; while (sz < need && sz < 0x80000000u) sz <<= 1;
+            unsigned long long off = atomicAdd(&b.counters[GMK_HEAVY_SLOTS], (unsigned long long)sz);
+            b.retry_list[j] = rs;
+            b.retry_off[j] = off;
+            atomicAdd(&b.counters[GMK_OVERFLOW_RS], 1ull);
+        }
+        return;
+    }
+    for (int q = tid; q < GMV_TSIZE; q += 256) {     // emit: NW step = kmin-th lowest step that voted
+        uint32_t key = s_keys[q], v = s_vals[q];
+        bool emit = key != GM_EMPTY && v >= (uint32_t)p.kmin;
+        uint32_t step = 0;
+        if (emit) {
+            if (p.nw) {
+                unsigned long long m = (unsigned long long)s_A[q] | (MASK64 ? ((unsigned long long)s_hi[q] << 32) : 0ull);
+                for (int r = 1; r < p.kmin && m; ++r) m &= m - 1;
+                step = m ? (uint32_t)(__ffsll((long long)m) - 1) : 0u;
+            } else step = v > 65535u ? 65535u : v;
+        }
+        gm_emit<GmLdsTable>(b, emit, rs, key, step, 4);
+    }
+    if (tid < 64) {                                  // b = 0: cumulative per-step counts
+        uint32_t run = s_cnt0[tid];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(run, off); if (lane >= off) run += t; }
+        uint32_t total = __shfl(run, 63);
+        unsigned long long reached = __ballot(run >= (uint32_t)p.kmin);
+        bool emit = tid == 0 && total >= (uint32_t)p.kmin;
+        uint32_t step = p.nw ? (uint32_t)(__ffsll((long long)reached) - 1) : (total > 65535u ? 65535u : total);
+        gm_emit<GmLdsTable>(b, emit, rs, 0u, step, 4);
+    }
+}
+
 // retry path: one workgroup per overflowed read x strand, exact vote table in HBM (pre-set to EMPTY/0 by the host)
 struct GmGlobalTable {
     uint32_t* keys; uint32_t* vals; uint32_t mask; int bits;
@@ -689,10 +906,12 @@ __global__ void __launch_bounds__(256) k_vote_retry(GmDevIndex ix, GmDevParams p
 // their three inputs are this lane's previous cell (s+2) and the two neighbour lanes' cells (s+1), exchanged by
 // wave shuffles.  The read rows (called base, quality) and the 2-bit window are staged in LDS.
 // ------------------------------------------------------------------------------------------------
-#define GM_NW_HDR (512 * sizeof(float2) + 16 * sizeof(float))
+#define GM_NW_NCOFF 1024        // contig offsets cached in LDS when there are at most this many
+#define GM_NW_HDR (512 * sizeof(float2) + 16 * sizeof(float) + GM_NW_NCOFF * sizeof(uint32_t))
 struct GmNwLds {
     float2* lut;            // 512 entries
     float* sg;              // 4 x 4 substitution rows a,c,g,t
+    uint32_t* coff;         // contig offsets
     uint16_t* rows;         // 32 groups x Lp
     uint8_t* win;           // 32 groups x Lp
 };
@@ -701,23 +920,45 @@ __device__ __forceinline__ GmNwLds gm_nw_lds(unsigned char* raw, uint32_t Lp) {
     GmNwLds s;
     s.lut = reinterpret_cast<float2*>(raw);
     s.sg = reinterpret_cast<float*>(raw + 512 * sizeof(float2));
+    s.coff = reinterpret_cast<uint32_t*>(raw + 512 * sizeof(float2) + 16 * sizeof(float));
     s.rows = reinterpret_cast<uint16_t*>(raw + GM_NW_HDR);
     s.win = raw + GM_NW_HDR + (size_t)32 * Lp * 2;
     return s;
 }
 
-// stage read rows (in strand orientation) and the reference window of one candidate; 8 lanes cooperate
+// stage read rows (in strand orientation) and the reference window of one candidate; 8 lanes cooperate.
+// All global loads of a lane are independent 8-byte (read) / 1-byte (packed reference) loads issued back to back.
 __device__ __forceinline__ void gm_stage(const GmDevIndex& ix, const GmDevBatch& b, uint16_t* rows, uint8_t* win,
                                          uint32_t r, uint32_t strand, uint32_t L, uint32_t b0, int d) {
     const uint8_t* rb = b.bases + (size_t)r * b.stride;
     const uint8_t* rq = b.quals + (size_t)r * b.stride;
-    for (uint32_t i = (uint32_t)d; i < L; i += 8) {
-        uint32_t src = strand ? L - 1 - i : i;          // reverse_comp_cpy SequenceOperations.h:149-161
-        uint32_t code = gm_nt4(rb[src]);
-        if (strand && code < 4) code = 3 - code;
-        rows[i] = (uint16_t)((code << 8) | rq[src]);
-        uint32_t pp = b0 + i;
-        win[i] = (uint8_t)((ix.pac[pp >> 2] >> ((~pp & 3u) << 1)) & 3u);   // _get_pac src/bntseq.c:225
+    for (uint32_t o = (uint32_t)d * 8; o < L; o += 64) {                  // rows are 8-byte aligned
+        const uint2 bw = *reinterpret_cast<const uint2*>(rb + o);
+        const uint2 qw = *reinterpret_cast<const uint2*>(rq + o);
+#pragma unroll
+        for (uint32_t t = 0; t < 8; ++t) {
+            uint32_t src = o + t;
+            if (src < L) {
+                uint32_t ch = ((t < 4 ? bw.x : bw.y) >> ((t & 3) * 8)) & 255u;
+                uint32_t qc = ((t < 4 ? qw.x : qw.y) >> ((t & 3) * 8)) & 255u;
+                uint32_t code = gm_nt4(ch);
+                if (strand && code < 4) code = 3 - code;
+                rows[strand ? L - 1 - src : src] = (uint16_t)((code << 8) | qc);   // reverse_comp_cpy SequenceOperations.h:149-161
+            }
+        }
+    }
+    const uint32_t y0 = b0 >> 2, y1 = (b0 + L - 1) >> 2;                   // bytes of the 2-bit reference holding the window
+    for (uint32_t y = y0 + (uint32_t)d * 4; y <= y1; y += 32) {
+        uint32_t by[4];
+#pragma unroll
+        for (uint32_t t = 0; t < 4; ++t) by[t] = (y + t <= y1) ? ix.pac[y + t] : 0u;
+#pragma unroll
+        for (uint32_t t = 0; t < 4; ++t)
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                uint32_t pp = ((y + t) << 2) + q;                           // _get_pac src/bntseq.c:225
+                if (pp >= b0 && pp < b0 + L) win[pp - b0] = (uint8_t)((by[t] >> ((~pp & 3u) << 1)) & 3u);
+            }
     }
 }
 
@@ -726,6 +967,10 @@ __global__ void __launch_bounds__(256) k_nw(GmDevIndex ix, GmDevParams p, GmDevB
     GmNwLds S = gm_nw_lds(s_raw, Lp);
     for (int q = threadIdx.x; q < 512; q += 256) S.lut[q] = p.lut[q];
     if (threadIdx.x < 16) S.sg[threadIdx.x] = p.S256[(size_t)("acgt"[threadIdx.x >> 2]) * 4 + (threadIdx.x & 3)];
+    const bool lds_coff = ix.n_seqs + 1 <= GM_NW_NCOFF;
+    if (lds_coff) for (uint32_t q = threadIdx.x; q <= ix.n_seqs; q += 256) S.coff[q] = ix.contig_off[q];
+    const uint32_t* coff = lds_coff ? S.coff : ix.contig_off;
+    __syncthreads();
     const int lane = gm_lane(), wave = threadIdx.x >> 6;
     const int g = (threadIdx.x >> 3), d = lane & 7, delta = d - 3;
     uint16_t* rows = S.rows + (size_t)g * Lp;
@@ -742,7 +987,7 @@ __global__ void __launch_bounds__(256) k_nw(GmDevIndex ix, GmDevParams p, GmDevB
         uint32_t r = c.rs >> 1, strand = c.rs & 1;
         if (have && (c.flags & 4) && b.rs_overflow[c.rs]) have = false;                // superseded by the retry kernel
         uint32_t L = have ? b.len[r] : 0;
-        bool ok = have && gm_window_ok(ix, c.b, L);
+        bool ok = have && gm_window_ok(ix, coff, c.b, L);
         if (ok && p.nw) gm_stage(ix, b, rows, win, r, strand, L, c.b, d);
         __syncthreads();
         float result = 0.0f;
@@ -833,6 +1078,10 @@ __global__ void __launch_bounds__(256) k_traceback(GmDevIndex ix, GmDevParams p,
     uint32_t* mv_all = reinterpret_cast<uint32_t*>(s_raw + GM_NW_HDR + (size_t)32 * Lp * 3);   // 32 groups x 7 x mvw words
     for (int q = threadIdx.x; q < 512; q += 256) S.lut[q] = p.lut[q];
     if (threadIdx.x < 16) S.sg[threadIdx.x] = p.S256[(size_t)("acgt"[threadIdx.x >> 2]) * 4 + (threadIdx.x & 3)];
+    const bool lds_coff = ix.n_seqs + 1 <= GM_NW_NCOFF;
+    if (lds_coff) for (uint32_t q = threadIdx.x; q <= ix.n_seqs; q += 256) S.coff[q] = ix.contig_off[q];
+    const uint32_t* coff = lds_coff ? S.coff : ix.contig_off;
+    __syncthreads();
     const int lane = gm_lane();
     const int g = (threadIdx.x >> 3), d = lane & 7, delta = d - 3;
     uint16_t* rows = S.rows + (size_t)g * Lp;
@@ -847,7 +1096,7 @@ __global__ void __launch_bounds__(256) k_traceback(GmDevIndex ix, GmDevParams p,
         if (have) c = items[ci];
         uint32_t r = c.rs >> 1, strand = c.rs & 1;
         uint32_t L = have ? b.len[r] : 0;
-        bool ok = have && L > 0 && gm_window_ok(ix, c.b, L) && 2 * L <= ops_stride;
+        bool ok = have && L > 0 && gm_window_ok(ix, coff, c.b, L) && 2 * L <= ops_stride;
         if (ok) gm_stage(ix, b, rows, win, r, strand, L, c.b, d);
         if (d < 7) for (uint32_t q = 0; q < mvw; ++q) mv[q] = 0;
         __syncthreads();
@@ -948,7 +1197,7 @@ __global__ void __launch_bounds__(256) k_sa_interval(GmDevIndex ix, const uint8_
     for (int t = (int)m - 1; t >= 0; --t) {
         uint32_t c = gm_nt4(km[t]);
         if (c > 3) { ok = false; break; }
-        uint32_t ok_ = gm_occ(ix, k - 1, c), ol_ = gm_occ(ix, l, c);
+        uint32_t ok_ = gm_occ_plane(ix, k - 1, c), ol_ = gm_occ_plane(ix, l, c);
         k = gm_L2(ix, c) + ok_ + 1;
         l = gm_L2(ix, c) + ol_;
         if (k > l) { ok = false; break; }
@@ -976,6 +1225,11 @@ int gmk_expand_full_sa(const GmDevIndex& ix, uint32_t* full_sa, void* stream) {
     return (int)hipGetLastError();
 }
 
+int gmk_build_occ_planes(const GmDevIndex& ix, uint4* planes, uint32_t nblk, void* stream) {
+    hipLaunchKernelGGL(k_build_occ_planes, dim3(cdiv(nblk, 256)), dim3(256), 0, S_(stream), ix, planes, nblk);
+    return (int)hipGetLastError();
+}
+
 int gmk_prep(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream) {
     if (b.n == 0) return 0;
     hipLaunchKernelGGL(k_prep, dim3(cdiv(b.n, 256)), dim3(256), 0, S_(stream), ix, p, b);
@@ -984,7 +1238,7 @@ int gmk_prep(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, vo
 
 int gmk_seed(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream) {
     if (b.n == 0) return 0;
-    hipLaunchKernelGGL(k_seed, dim3(cdiv(2ull * b.n, 256)), dim3(256), 0, S_(stream), ix, p, b);
+    hipLaunchKernelGGL(k_seed, dim3(cdiv(2ull * b.n, 256)), dim3(256), (size_t)128 * b.stride, S_(stream), ix, p, b);
     return (int)hipGetLastError();
 }
 
@@ -1008,8 +1262,14 @@ int gmk_locate_sampled(const GmDevIndex& ix, const GmDevBatch& b, void* stream) 
     return (int)hipGetLastError();
 }
 
-int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, void* stream) {
+int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, int dense, void* stream) {
     if (b.n == 0) return 0;
+    // dense seeds (many SA hits per read x strand): one workgroup per read x strand
+    if (dense && b.max_seeds <= 64) {
+        if (b.max_seeds <= 32) hipLaunchKernelGGL(k_vote_block<false>, dim3(2 * b.n), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
+        else hipLaunchKernelGGL(k_vote_block<true>, dim3(2 * b.n), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
+        return (int)hipGetLastError();
+    }
     // order-free fast path while the seed steps fit a 64-bit mask; the ordered kernel is the general form
     if (b.max_seeds <= 32) hipLaunchKernelGGL(k_vote_fast<false>, dim3(cdiv(2ull * b.n, 4)), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
     else if (b.max_seeds <= 64) hipLaunchKernelGGL(k_vote_fast<true>, dim3(cdiv(2ull * b.n, 4)), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);

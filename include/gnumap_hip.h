@@ -97,7 +97,7 @@ typedef struct {
 /* a block of reads exactly as they stand in the FASTQ file; caller-owned host memory */
 typedef struct {
     uint32_t n;                 /* number of reads */
-    uint32_t stride;            /* bytes between consecutive reads in bases[] / quals[] (>= longest read) */
+    uint32_t stride;            /* bytes between consecutive reads in bases[] / quals[] (>= longest read, multiple of 8) */
     const uint8_t* bases;       /* n x stride, FASTQ sequence characters verbatim (any case, N allowed) */
     const uint8_t* quals;       /* n x stride, raw FASTQ quality characters */
     const uint16_t* len;        /* n read lengths */
