@@ -76,7 +76,7 @@ struct gm_batch {
     uint32_t max_reads = 0, max_len = 0;
     uint32_t n = 0, stride = 0, max_seeds = 0, illumina_until = 0;
     DevBuf bases, quals, len, status, self_score, min_score, top_score, seeds, n_seeds, n_entries, entry_off, coords,
-        rs_overflow, retry_list, retry_off, gtab_keys, gtab_vals, cands, hit_count, hit_begin, hit_cursor, raw_hits, counters, small,
+        rs_overflow, retry_list, retry_off, gtab_keys, gtab_vals, cands, hit_count, hit_begin, hit_cursor, raw_hits, counters, small, shards,
         tb_items, tb_ops, tb_len, dep_pos, dep_span, dep_w;
     uint32_t cand_cap = 0;
     uint64_t raw_cap = 0;
@@ -344,7 +344,7 @@ extern "C" void gm_batch_destroy(gm_batch* b) {
     (void)hipSetDevice(b->ix->device);
     DevBuf* all[] = { &b->bases, &b->quals, &b->len, &b->status, &b->self_score, &b->min_score, &b->top_score, &b->seeds, &b->n_seeds,
                       &b->n_entries, &b->entry_off, &b->coords, &b->rs_overflow, &b->retry_list, &b->retry_off, &b->gtab_keys, &b->gtab_vals,
-                      &b->cands, &b->hit_count, &b->hit_begin, &b->hit_cursor, &b->raw_hits, &b->counters, &b->small, &b->tb_items, &b->tb_ops,
+                      &b->cands, &b->hit_count, &b->hit_begin, &b->hit_cursor, &b->raw_hits, &b->counters, &b->small, &b->shards, &b->tb_items, &b->tb_ops,
                       &b->tb_len, &b->dep_pos, &b->dep_span, &b->dep_w };
     for (DevBuf* d : all) d->release();
     for (auto& ev : b->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
@@ -362,8 +362,8 @@ static int ensure_batch_buffers(gm_batch* b, const gm_params* p) {
     rc |= b->entry_off.ensure((n2 + 1) * 8); rc |= b->rs_overflow.ensure(n2); rc |= b->retry_list.ensure(n2 * 4);
     rc |= b->retry_off.ensure((n2 + 1024) * 8);
     rc |= b->hit_count.ensure(n * 4); rc |= b->hit_begin.ensure((n + 1) * 8); rc |= b->hit_cursor.ensure(n * 4);
-    rc |= b->counters.ensure(GMK_N * 8); rc |= b->small.ensure(64);
-    if (b->cand_cap < 32 * n + 1024) { b->cand_cap = (uint32_t)std::min<size_t>(32 * n + 1024, 0x7FFFFFFF); }
+    rc |= b->counters.ensure(GMK_N * 8); rc |= b->small.ensure(64); rc |= b->shards.ensure((size_t)GM_NSHARD * GM_SHARD_STRIDE * 4);
+    if (b->cand_cap < 16 * n + 64 * GM_NSHARD) { b->cand_cap = (uint32_t)std::min<size_t>(16 * n + 64 * GM_NSHARD, 0x7FFFFFFF); }
     rc |= b->cands.ensure((size_t)b->cand_cap * sizeof(GmCand));
     return rc ? GM_E_NOMEM : GM_OK;
 }
@@ -377,11 +377,12 @@ static void fill_dev_batch(gm_batch* b) {
     d.n_entries = b->n_entries.as<uint32_t>(); d.entry_off = b->entry_off.as<uint64_t>(); d.coords = b->coords.as<uint32_t>();
     d.rs_overflow = b->rs_overflow.as<uint8_t>(); d.retry_list = b->retry_list.as<uint32_t>(); d.retry_off = b->retry_off.as<uint64_t>();
     d.gtab_keys = b->gtab_keys.as<uint32_t>(); d.gtab_vals = b->gtab_vals.as<uint32_t>();
-    d.cands = b->cands.as<GmCand>(); d.cand_cap = b->cand_cap;
+    d.cands = b->cands.as<GmCand>(); d.cand_cap = b->cand_cap; d.cand_region = b->cand_cap / GM_NSHARD;
+    d.shard_cnt = b->shards.as<uint32_t>();
     d.hit_count = b->hit_count.as<uint32_t>(); d.hit_begin = b->hit_begin.as<uint64_t>(); d.hit_cursor = b->hit_cursor.as<uint32_t>();
     d.raw_hits = b->raw_hits.as<GmRawHit>(); d.raw_cap = b->raw_cap;
     d.counters = b->counters.as<unsigned long long>();
-    d.n_cands = b->small.as<uint32_t>(); d.n_retry = b->small.as<uint32_t>() + 1;
+    d.n_retry = b->small.as<uint32_t>() + 1;
 }
 
 extern "C" int gm_batch_upload(gm_batch* b, const gm_params* p, const gm_reads* r, void* stream) {
@@ -451,8 +452,17 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         KCHK(gmk_scan_entries(b->dev, st));
         { KTimer t(b, GM_K_LOCATE, st); KCHK(gmk_locate_sampled(ix->dev, b->dev, st)); }
     }
+    std::vector<uint32_t> shard_host((size_t)GM_NSHARD * GM_SHARD_STRIDE);
+    auto read_shards = [&](uint64_t& total, uint32_t& mx) -> int {
+        HIPCHK(hipMemcpyAsync(shard_host.data(), b->shards.p, shard_host.size() * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        total = 0; mx = 0;
+        for (int s = 0; s < GM_NSHARD; ++s) { uint32_t c = shard_host[(size_t)s * GM_SHARD_STRIDE]; total += c; mx = std::max(mx, c); }
+        return GM_OK;
+    };
     for (int attempt = 0;; ++attempt) {
         HIPCHK(hipMemsetAsync(b->small.p, 0, 64, st));
+        HIPCHK(hipMemsetAsync(b->shards.p, 0, (size_t)GM_NSHARD * GM_SHARD_STRIDE * 4, st));
         HIPCHK(hipMemsetAsync(b->rs_overflow.p, 0, 2 * (size_t)b->n, st));
         HIPCHK(hipMemsetAsync(b->counters.as<unsigned long long>() + GMK_HEAVY_SLOTS, 0, 8, st));
         HIPCHK(hipMemsetAsync(b->counters.as<unsigned long long>() + GMK_OVERFLOW_RS, 0, 8, st));
@@ -460,30 +470,31 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         uint32_t small[2];
         HIPCHK(hipMemcpyAsync(small, b->small.p, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(ctr, b->counters.p, sizeof ctr, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        uint64_t total = 0; uint32_t mx = 0;
+        rc = read_shards(total, mx);
+        if (rc) return rc;
         if (ctr[GMK_BAD_QUAL]) { gm_set_error("Invalid Fastq Character? (negative base probability)"); return GM_E_BAD_QUAL; }
-        uint32_t n_cands = small[0], n_retry = small[1];
-        if (n_retry && n_cands <= b->cand_cap) {
+        uint32_t n_retry = small[1];
+        if (n_retry && mx <= b->dev.cand_region) {
             size_t slots = (size_t)ctr[GMK_HEAVY_SLOTS];
             if (b->gtab_keys.ensure(slots * 4) || b->gtab_vals.ensure(slots * 4)) return GM_E_NOMEM;
             fill_dev_batch(b);
             HIPCHK(hipMemsetAsync(b->gtab_keys.p, 0xFF, slots * 4, st));
             HIPCHK(hipMemsetAsync(b->gtab_vals.p, 0, slots * 4, st));
             { KTimer t(b, GM_K_VOTE_RETRY, st); KCHK(gmk_vote_retry(ix->dev, dp, b->dev, use_full, n_retry, st)); }
-            HIPCHK(hipMemcpyAsync(small, b->small.p, 8, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            n_cands = small[0];
+            rc = read_shards(total, mx);
+            if (rc) return rc;
         }
-        if (n_cands > b->cand_cap) {                    // candidate list too small: grow and vote again
+        if (mx > b->dev.cand_region) {                  // a candidate shard overflowed: grow the list and vote again
             if (attempt > 8) { gm_set_error("candidate list keeps overflowing"); return GM_E_NOMEM; }
-            size_t want = std::min<size_t>((size_t)n_cands + n_cands / 4 + 1024, 0x7FFFFFFFu);
-            if ((size_t)n_cands > 0x7FFFFFFFu) { gm_set_error("too many candidates in one batch; use smaller batches"); return GM_E_CAPACITY; }
+            size_t want = ((size_t)mx + mx / 4 + 64) * GM_NSHARD;
+            if (want > 0x7FFFFFFFu) { gm_set_error("too many candidates in one batch; use smaller batches"); return GM_E_CAPACITY; }
             b->cand_cap = (uint32_t)want;
             if (b->cands.ensure((size_t)b->cand_cap * sizeof(GmCand))) return GM_E_NOMEM;
             fill_dev_batch(b);
             continue;
         }
-        b->n_cands = n_cands;
+        b->n_cands = (uint32_t)total;
         break;
     }
     if (b->raw_cap < b->n_cands + 16ull) b->raw_cap = b->n_cands + 16ull;
@@ -867,11 +878,13 @@ extern "C" int gm_dev_nw_score(gm_index* ix, const gm_params* p, const gm_reads*
         c[i].rs = read_idx[i] * 2 + (strand[i] ? 1 : 0); c[i].b = (uint32_t)pos[i]; c[i].step = 0; c[i].flags = 0; c[i].pad = 0; c[i].score = 0;
     }
     do {
-        b->cand_cap = std::max<uint32_t>(b->cand_cap, n);
+        b->cand_cap = std::max<uint32_t>(b->cand_cap, n + 16);
         if (b->cands.ensure((size_t)b->cand_cap * sizeof(GmCand))) { rc = GM_E_NOMEM; break; }
         fill_dev_batch(b);
+        b->dev.cand_region = b->cand_cap;               // everything sits in shard 0
         if (n && hipMemcpy(b->cands.p, c.data(), (size_t)n * sizeof(GmCand), hipMemcpyHostToDevice) != hipSuccess) { rc = GM_E_HIP; break; }
-        if (hipMemcpy(b->small.p, &n, 4, hipMemcpyHostToDevice) != hipSuccess) { rc = GM_E_HIP; break; }
+        if (hipMemset(b->shards.p, 0, (size_t)GM_NSHARD * GM_SHARD_STRIDE * 4) != hipSuccess) { rc = GM_E_HIP; break; }
+        if (hipMemcpy(b->shards.p, &n, 4, hipMemcpyHostToDevice) != hipSuccess) { rc = GM_E_HIP; break; }
         if (gmk_nw(ix->dev, dp, b->dev, nullptr)) { rc = GM_E_HIP; break; }
         if (n && hipMemcpy(c.data(), b->cands.p, (size_t)n * sizeof(GmCand), hipMemcpyDeviceToHost) != hipSuccess) { rc = GM_E_HIP; break; }
     } while (0);

@@ -38,6 +38,9 @@ struct GmDevParams {
 
 struct GmSeed { uint32_t k, l, pos; };
 
+#define GM_NSHARD 1024
+#define GM_SHARD_STRIDE 32
+
 // flags of GmCand
 enum { GMC_VALID = 1, GMC_ACCEPT = 2 };
 struct GmCand {
@@ -75,13 +78,15 @@ struct GmDevBatch {
     uint64_t* retry_off;            // table offsets for the retry list
     uint32_t* gtab_keys;            // global vote tables (retry path)
     uint32_t* gtab_vals;
-    GmCand* cands;  uint32_t cand_cap;
+    // candidates are appended through GM_NSHARD bump counters (one 128-byte line each) instead of one global counter:
+    // shard s owns cands[s * cand_region, (s+1) * cand_region)
+    GmCand* cands;  uint32_t cand_cap, cand_region;
+    uint32_t* shard_cnt;            // GM_NSHARD counters, GM_SHARD_STRIDE words apart
     uint32_t* hit_count;            // n
     uint64_t* hit_begin;            // n+1
     uint32_t* hit_cursor;           // n
     GmRawHit* raw_hits;  uint64_t raw_cap;
     unsigned long long* counters;   // GMK_N
-    uint32_t* n_cands;              // device counter
     uint32_t* n_retry;              // device counter
 };
 

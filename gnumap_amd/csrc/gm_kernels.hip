@@ -432,17 +432,50 @@ __device__ __forceinline__ void gm_emit(const GmDevBatch& b, bool emit, uint32_t
     if (mask == 0) return;
     int lane = gm_lane();
     int leader = __ffsll((long long)mask) - 1;
+    const uint32_t shard = blockIdx.x & (GM_NSHARD - 1);   // a single bump counter saturates at ~90 M atomics/s: shard it
     uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(b.n_cands, (uint32_t)__popcll(mask));
+    if (lane == leader) base = atomicAdd(&b.shard_cnt[shard * GM_SHARD_STRIDE], (uint32_t)__popcll(mask));
     base = __shfl(base, leader);
     if (emit) {
         uint32_t idx = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        if (idx < b.cand_cap) {
+        if (idx < b.cand_region) {
             GmCand c;
             c.rs = rs; c.b = bpos; c.step = (uint16_t)step; c.flags = flags; c.pad = 0; c.score = 0.0f;
-            b.cands[idx] = c;
+            b.cands[(size_t)shard * b.cand_region + idx] = c;
         }
     }
+}
+
+// consumers of the sharded candidate list: exclusive prefix of the shard fill counts (block-wide, into LDS) and the
+// map from a flat work index to the candidate slot
+__device__ __forceinline__ uint32_t gm_cand_prefix(const GmDevBatch& b, uint32_t* pre /* GM_NSHARD + 1 */) {
+    __shared__ uint32_t s_wsum[4];
+    const int tid = threadIdx.x, lane = gm_lane(), wave = tid >> 6;
+    uint32_t v[GM_NSHARD / 256], sum = 0;
+#pragma unroll
+    for (int q = 0; q < GM_NSHARD / 256; ++q) {
+        uint32_t c = b.shard_cnt[(size_t)(tid * (GM_NSHARD / 256) + q) * GM_SHARD_STRIDE];
+        v[q] = c < b.cand_region ? c : b.cand_region;
+        sum += v[q];
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += s_wsum[w];
+#pragma unroll
+    for (int q = 0; q < GM_NSHARD / 256; ++q) { pre[tid * (GM_NSHARD / 256) + q] = run; run += v[q]; }
+    if (tid == 255) pre[GM_NSHARD] = run;
+    __syncthreads();
+    return pre[GM_NSHARD];
+}
+
+__device__ __forceinline__ size_t gm_cand_slot(const GmDevBatch& b, const uint32_t* pre, uint32_t w) {
+    uint32_t lo = 0, hi = GM_NSHARD;
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= w) lo = mid; else hi = mid; }
+    return (size_t)lo * b.cand_region + (w - pre[lo]);
 }
 
 struct GmLdsTable {
@@ -907,11 +940,12 @@ __global__ void __launch_bounds__(256) k_vote_retry(GmDevIndex ix, GmDevParams p
 // wave shuffles.  The read rows (called base, quality) and the 2-bit window are staged in LDS.
 // ------------------------------------------------------------------------------------------------
 #define GM_NW_NCOFF 1024        // contig offsets cached in LDS when there are at most this many
-#define GM_NW_HDR (512 * sizeof(float2) + 16 * sizeof(float) + GM_NW_NCOFF * sizeof(uint32_t))
+#define GM_NW_HDR (512 * sizeof(float2) + 16 * sizeof(float) + GM_NW_NCOFF * sizeof(uint32_t) + (GM_NSHARD + 4) * sizeof(uint32_t))
 struct GmNwLds {
     float2* lut;            // 512 entries
     float* sg;              // 4 x 4 substitution rows a,c,g,t
     uint32_t* coff;         // contig offsets
+    uint32_t* pre;          // prefix of the candidate shard counts
     uint16_t* rows;         // 32 groups x Lp
     uint8_t* win;           // 32 groups x Lp
 };
@@ -921,6 +955,7 @@ __device__ __forceinline__ GmNwLds gm_nw_lds(unsigned char* raw, uint32_t Lp) {
     s.lut = reinterpret_cast<float2*>(raw);
     s.sg = reinterpret_cast<float*>(raw + 512 * sizeof(float2));
     s.coff = reinterpret_cast<uint32_t*>(raw + 512 * sizeof(float2) + 16 * sizeof(float));
+    s.pre = s.coff + GM_NW_NCOFF;
     s.rows = reinterpret_cast<uint16_t*>(raw + GM_NW_HDR);
     s.win = raw + GM_NW_HDR + (size_t)32 * Lp * 2;
     return s;
@@ -975,13 +1010,14 @@ __global__ void __launch_bounds__(256) k_nw(GmDevIndex ix, GmDevParams p, GmDevB
     const int g = (threadIdx.x >> 3), d = lane & 7, delta = d - 3;
     uint16_t* rows = S.rows + (size_t)g * Lp;
     uint8_t* win = S.win + (size_t)g * Lp;
-    const uint32_t n_cands = *b.n_cands < b.cand_cap ? *b.n_cands : b.cand_cap;
+    const uint32_t n_cands = gm_cand_prefix(b, S.pre);
     const float gap = p.gap, gap4 = __fmul_rn(p.gap, 4.0f);
     unsigned long long cells = 0, accepted = 0;
     (void)wave;
     for (uint32_t base = blockIdx.x * 32; base < n_cands; base += gridDim.x * 32) {     // block-uniform trip count
-        uint32_t ci = base + g;
-        bool have = ci < n_cands;
+        uint32_t wi = base + g;
+        bool have = wi < n_cands;
+        size_t ci = have ? gm_cand_slot(b, S.pre, wi) : 0;
         GmCand c; c.rs = 0; c.b = 0; c.step = 0; c.flags = 0; c.score = 0;
         if (have) c = b.cands[ci];
         uint32_t r = c.rs >> 1, strand = c.rs & 1;
@@ -1053,9 +1089,10 @@ __global__ void __launch_bounds__(256) k_nw(GmDevIndex ix, GmDevParams p, GmDevB
 }
 
 __global__ void __launch_bounds__(256) k_scatter_hits(GmDevBatch b) {
-    const uint32_t n_cands = *b.n_cands < b.cand_cap ? *b.n_cands : b.cand_cap;
-    for (uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x; ci < n_cands; ci += gridDim.x * blockDim.x) {
-        GmCand c = b.cands[ci];
+    __shared__ uint32_t s_pre[GM_NSHARD + 4];
+    const uint32_t n_cands = gm_cand_prefix(b, s_pre);
+    for (uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x; wi < n_cands; wi += gridDim.x * blockDim.x) {
+        GmCand c = b.cands[gm_cand_slot(b, s_pre, wi)];
         if (!(c.flags & GMC_ACCEPT)) continue;
         uint32_t r = c.rs >> 1;
         uint64_t slot = b.hit_begin[r] + atomicAdd(&b.hit_cursor[r], 1u);
