@@ -330,7 +330,7 @@ extern "C" int gm_index_window(const gm_index* ix, uint64_t begin, uint32_t L, c
 // batches
 // ------------------------------------------------------------------------------------------------
 extern "C" int gm_batch_create(gm_index* ix, uint32_t max_reads, uint32_t max_len, gm_batch** out) {
-    if (!ix || !out || max_reads == 0 || max_len == 0 || max_len > 4096) return GM_E_ARG;
+    if (!ix || !out || max_reads == 0 || max_len == 0 || max_len > 4096) return GM_E_ARG;     /* reads themselves: <= 2048 bases (LDS budget of the DP kernels) */
     if (ix->host_only) { gm_set_error("index opened host-only"); return GM_E_NO_DEVICE; }
     HIPCHK(hipSetDevice(ix->device));
     gm_batch* b = new gm_batch();
@@ -387,7 +387,7 @@ static void fill_dev_batch(gm_batch* b) {
 
 extern "C" int gm_batch_upload(gm_batch* b, const gm_params* p, const gm_reads* r, void* stream) {
     if (!b || !p || !r || !p->finalized) return GM_E_ARG;
-    if (r->n > b->max_reads || r->stride > 4096) { gm_set_error("batch larger than gm_batch_create allowed"); return GM_E_ARG; }
+    if (r->n > b->max_reads || r->stride > 2048) { gm_set_error("batch larger than gm_batch_create allowed, or reads longer than 2048 bases"); return GM_E_ARG; }
     if (r->stride % 8 != 0) { gm_set_error("gm_reads.stride must be a multiple of 8"); return GM_E_ARG; }
     HIPCHK(hipSetDevice(b->ix->device));
     hipStream_t st = S_(stream);

@@ -16,6 +16,8 @@
 // Arithmetic: ranks/coordinates are u32 (reference < 2^32-1 ranks); scores are fp32 with the reference's operation
 // order and NO fused multiply-add (built with -ffp-contract=off; mul/add also go through __fmul_rn/__fadd_rn).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
 #include "gm_internal.h"
 
 #define GM_NEG_INF (-100000.0f)
@@ -449,25 +451,23 @@ __device__ __forceinline__ void gm_emit(const GmDevBatch& b, bool emit, uint32_t
 // consumers of the sharded candidate list: exclusive prefix of the shard fill counts (block-wide, into LDS) and the
 // map from a flat work index to the candidate slot
 __device__ __forceinline__ uint32_t gm_cand_prefix(const GmDevBatch& b, uint32_t* pre /* GM_NSHARD + 1 */) {
-    __shared__ uint32_t s_wsum[4];
-    const int tid = threadIdx.x, lane = gm_lane(), wave = tid >> 6;
-    uint32_t v[GM_NSHARD / 256], sum = 0;
+    const int tid = threadIdx.x;
+    if (tid < 64) {                                  // wave 0: 16 shards per lane, wave scan
+        uint32_t v[GM_NSHARD / 64], sum = 0;
 #pragma unroll
-    for (int q = 0; q < GM_NSHARD / 256; ++q) {
-        uint32_t c = b.shard_cnt[(size_t)(tid * (GM_NSHARD / 256) + q) * GM_SHARD_STRIDE];
-        v[q] = c < b.cand_region ? c : b.cand_region;
-        sum += v[q];
+        for (int q = 0; q < GM_NSHARD / 64; ++q) {
+            uint32_t c = b.shard_cnt[(size_t)(tid * (GM_NSHARD / 64) + q) * GM_SHARD_STRIDE];
+            v[q] = c < b.cand_region ? c : b.cand_region;
+            sum += v[q];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off); if (tid >= off) incl += t; }
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int q = 0; q < GM_NSHARD / 64; ++q) { pre[tid * (GM_NSHARD / 64) + q] = run; run += v[q]; }
+        if (tid == 63) pre[GM_NSHARD] = run;
     }
-    uint32_t incl = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
-    if (lane == 63) s_wsum[wave] = incl;
-    __syncthreads();
-    uint32_t run = incl - sum;
-    for (int w = 0; w < wave; ++w) run += s_wsum[w];
-#pragma unroll
-    for (int q = 0; q < GM_NSHARD / 256; ++q) { pre[tid * (GM_NSHARD / 256) + q] = run; run += v[q]; }
-    if (tid == 255) pre[GM_NSHARD] = run;
     __syncthreads();
     return pre[GM_NSHARD];
 }
@@ -737,9 +737,9 @@ __global__ void __launch_bounds__(256) k_vote_fast(GmDevIndex ix, GmDevParams p,
 // Same algorithm as k_vote_fast, but the flat hit list of the read x strand is spread over 256 lanes: every lane issues
 // all of its (up to GMB_U) loads at once - one HBM latency per read x strand instead of one per 256 hits - and keeps the
 // located positions in registers, so the second (exact) pass does not touch memory again.
-#define GMB_U 8
-template <bool MASK64>
-__global__ void __launch_bounds__(256) k_vote_block(GmDevIndex ix, GmDevParams p, GmDevBatch b, int use_full_sa) {
+#define GMB_ENTRIES 2048       // hits a workgroup keeps in registers (NT lanes x GMB_ENTRIES/NT each)
+template <bool MASK64, int NT>
+__global__ void __launch_bounds__(NT) k_vote_block(GmDevIndex ix, GmDevParams p, GmDevBatch b, int use_full_sa) {
     __shared__ uint32_t s_A[GMV_FWORDS];             // pass 1 "seen" bits, later the low step masks
     __shared__ uint32_t s_B[GMV_FWORDS];             // "seen twice"
     __shared__ uint32_t s_keys[GMV_TSIZE];
@@ -747,6 +747,7 @@ __global__ void __launch_bounds__(256) k_vote_block(GmDevIndex ix, GmDevParams p
     __shared__ uint32_t s_hi[MASK64 ? GMV_TSIZE : 1];
     __shared__ uint32_t s_pre[66], s_k[64], s_pos[64], s_cnt0[64];
     __shared__ uint32_t s_nkeys, s_full;
+    constexpr int GMB_U = GMB_ENTRIES / NT;
     const uint32_t rs = blockIdx.x;                  // grid = 2n
     const int tid = threadIdx.x, lane = gm_lane();
     uint32_t ns = b.n_seeds[rs];
@@ -763,13 +764,13 @@ __global__ void __launch_bounds__(256) k_vote_block(GmDevIndex ix, GmDevParams p
         s_pre[tid + 1] = incl; s_k[tid] = mine.k; s_pos[tid] = mine.pos; s_cnt0[tid] = 0;
         if (tid == 0) { s_pre[0] = 0; s_nkeys = 0; s_full = 0; }
     }
-    for (int q = tid; q < GMV_TSIZE; q += 256) { s_keys[q] = GM_EMPTY; s_vals[q] = 0; if (MASK64) s_hi[q] = 0; }
-    for (int q = tid; q < GMV_FWORDS; q += 256) { s_A[q] = 0; s_B[q] = 0; }
+    for (int q = tid; q < GMV_TSIZE; q += NT) { s_keys[q] = GM_EMPTY; s_vals[q] = 0; if (MASK64) s_hi[q] = 0; }
+    for (int q = tid; q < GMV_FWORDS; q += NT) { s_A[q] = 0; s_B[q] = 0; }
     __syncthreads();
     const uint32_t E = s_pre[ns];
     const uint64_t coff0 = use_full_sa ? 0 : b.entry_off[rs];
     const bool filter = p.kmin >= 2 && E > GMV_TSIZE / 2;
-    const bool one_round = E <= 256u * GMB_U;
+    const bool one_round = E <= (uint32_t)NT * GMB_U;
     GmLdsTable tb; tb.keys = s_keys; tb.vals = s_vals; tb.mask = GMV_TSIZE - 1; tb.bits = GMV_TBITS;
     uint32_t bpv[GMB_U], ttv[GMB_U];
 
@@ -777,7 +778,7 @@ __global__ void __launch_bounds__(256) k_vote_block(GmDevIndex ix, GmDevParams p
         uint32_t ee[GMB_U];
 #pragma unroll
         for (int u = 0; u < GMB_U; ++u) {
-            uint32_t e = base + (uint32_t)u * 256u + (uint32_t)tid;
+            uint32_t e = base + (uint32_t)u * (uint32_t)NT + (uint32_t)tid;
             ee[u] = e;
             uint32_t t = 0;
             if (e < E) { uint32_t lo = 0, hi = ns; while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (s_pre[mid] <= e) lo = mid; else hi = mid; } t = lo; }
@@ -832,15 +833,15 @@ __global__ void __launch_bounds__(256) k_vote_block(GmDevIndex ix, GmDevParams p
         load_round(0);
         if (filter) pass1();
         __syncthreads();
-        for (int q = tid; q < GMV_TSIZE; q += 256) s_A[q] = 0;              // A becomes the low step masks
+        for (int q = tid; q < GMV_TSIZE; q += NT) s_A[q] = 0;              // A becomes the low step masks
         __syncthreads();
         pass2();
     } else {
-        if (filter) for (uint32_t base = 0; base < E; base += 256u * GMB_U) { load_round(base); pass1(); }
+        if (filter) for (uint32_t base = 0; base < E; base += (uint32_t)NT * GMB_U) { load_round(base); pass1(); }
         __syncthreads();
-        for (int q = tid; q < GMV_TSIZE; q += 256) s_A[q] = 0;
+        for (int q = tid; q < GMV_TSIZE; q += NT) s_A[q] = 0;
         __syncthreads();
-        for (uint32_t base = 0; base < E; base += 256u * GMB_U) {
+        for (uint32_t base = 0; base < E; base += (uint32_t)NT * GMB_U) {
             load_round(base);
             pass2();
             __syncthreads();
@@ -860,7 +861,7 @@ __global__ void __launch_bounds__(256) k_vote_block(GmDevIndex ix, GmDevParams p
         }
         return;
     }
-    for (int q = tid; q < GMV_TSIZE; q += 256) {     // emit: NW step = kmin-th lowest step that voted
+    for (int q = tid; q < GMV_TSIZE; q += NT) {     // emit: NW step = kmin-th lowest step that voted
         uint32_t key = s_keys[q], v = s_vals[q];
         bool emit = key != GM_EMPTY && v >= (uint32_t)p.kmin;
         uint32_t step = 0;
@@ -946,18 +947,18 @@ struct GmNwLds {
     float* sg;              // 4 x 4 substitution rows a,c,g,t
     uint32_t* coff;         // contig offsets
     uint32_t* pre;          // prefix of the candidate shard counts
-    uint16_t* rows;         // 32 groups x Lp
-    uint8_t* win;           // 32 groups x Lp
+    uint16_t* rows;         // G groups x Lp   (G = blockDim / 8 candidates per workgroup)
+    uint8_t* win;           // G groups x Lp
 };
 
-__device__ __forceinline__ GmNwLds gm_nw_lds(unsigned char* raw, uint32_t Lp) {
+__device__ __forceinline__ GmNwLds gm_nw_lds(unsigned char* raw, uint32_t Lp, uint32_t G) {
     GmNwLds s;
     s.lut = reinterpret_cast<float2*>(raw);
     s.sg = reinterpret_cast<float*>(raw + 512 * sizeof(float2));
     s.coff = reinterpret_cast<uint32_t*>(raw + 512 * sizeof(float2) + 16 * sizeof(float));
     s.pre = s.coff + GM_NW_NCOFF;
     s.rows = reinterpret_cast<uint16_t*>(raw + GM_NW_HDR);
-    s.win = raw + GM_NW_HDR + (size_t)32 * Lp * 2;
+    s.win = raw + GM_NW_HDR + (size_t)G * Lp * 2;
     return s;
 }
 
@@ -999,11 +1000,12 @@ __device__ __forceinline__ void gm_stage(const GmDevIndex& ix, const GmDevBatch&
 
 __global__ void __launch_bounds__(256) k_nw(GmDevIndex ix, GmDevParams p, GmDevBatch b, uint32_t Lp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    GmNwLds S = gm_nw_lds(s_raw, Lp);
-    for (int q = threadIdx.x; q < 512; q += 256) S.lut[q] = p.lut[q];
+    const uint32_t G = blockDim.x >> 3;
+    GmNwLds S = gm_nw_lds(s_raw, Lp, G);
+    for (int q = threadIdx.x; q < 512; q += blockDim.x) S.lut[q] = p.lut[q];
     if (threadIdx.x < 16) S.sg[threadIdx.x] = p.S256[(size_t)("acgt"[threadIdx.x >> 2]) * 4 + (threadIdx.x & 3)];
     const bool lds_coff = ix.n_seqs + 1 <= GM_NW_NCOFF;
-    if (lds_coff) for (uint32_t q = threadIdx.x; q <= ix.n_seqs; q += 256) S.coff[q] = ix.contig_off[q];
+    if (lds_coff) for (uint32_t q = threadIdx.x; q <= ix.n_seqs; q += blockDim.x) S.coff[q] = ix.contig_off[q];
     const uint32_t* coff = lds_coff ? S.coff : ix.contig_off;
     __syncthreads();
     const int lane = gm_lane(), wave = threadIdx.x >> 6;
@@ -1014,7 +1016,7 @@ __global__ void __launch_bounds__(256) k_nw(GmDevIndex ix, GmDevParams p, GmDevB
     const float gap = p.gap, gap4 = __fmul_rn(p.gap, 4.0f);
     unsigned long long cells = 0, accepted = 0;
     (void)wave;
-    for (uint32_t base = blockIdx.x * 32; base < n_cands; base += gridDim.x * 32) {     // block-uniform trip count
+    for (uint32_t base = blockIdx.x * G; base < n_cands; base += gridDim.x * G) {       // block-uniform trip count
         uint32_t wi = base + g;
         bool have = wi < n_cands;
         size_t ci = have ? gm_cand_slot(b, S.pre, wi) : 0;
@@ -1088,6 +1090,123 @@ __global__ void __launch_bounds__(256) k_nw(GmDevIndex ix, GmDevParams p, GmDevB
     gm_count(b, GMK_ACCEPTED, accepted);
 }
 
+// ------------------------------------------------------------------------------------------------
+// banded NW score, one LANE per candidate (the throughput form).  The 7-cell band row lives in registers and is
+// swept row by row from the bottom-right exactly like get_align_score_begin (src/bin_seq.cpp:819-843): cell order
+// j = i+3 .. i-3, three adds and the reference's 3-way max per cell, fp32 without contraction.  Per row the four
+// possible substitution scores are formed once (get_val for g = a,c,g,t) and each cell selects by its window base.
+// Reads stream through two 8-byte words, the 2-bit reference through two 32-bit words; nothing is staged in LDS
+// except the quality LUT.  (k_nw below is the 8-lanes-per-candidate anti-diagonal form; GM_NW=wave selects it.)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_nw_lane(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
+    __shared__ float2 s_lut[512];
+    __shared__ uint32_t s_coff[GM_NW_NCOFF];
+    __shared__ uint32_t s_pre[GM_NSHARD + 4];
+    for (int q = threadIdx.x; q < 512; q += 256) s_lut[q] = p.lut[q];
+    const bool lds_coff = ix.n_seqs + 1 <= GM_NW_NCOFF;
+    if (lds_coff) for (uint32_t q = threadIdx.x; q <= ix.n_seqs; q += 256) s_coff[q] = ix.contig_off[q];
+    const uint32_t* coff = lds_coff ? s_coff : ix.contig_off;
+    const uint32_t n_cands = gm_cand_prefix(b, s_pre);          // includes the barrier that publishes s_lut / s_coff
+    float sg[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sg[g][k] = p.S256[(size_t)("acgt"[g]) * 4 + k];
+    const float gap = p.gap, gap4 = __fmul_rn(p.gap, 4.0f);
+    const uint32_t* pac32 = reinterpret_cast<const uint32_t*>(ix.pac);
+    unsigned long long cells = 0, accepted = 0;
+    for (uint32_t wi = blockIdx.x * 256 + threadIdx.x; wi < n_cands; wi += gridDim.x * 256) {
+        const size_t ci = gm_cand_slot(b, s_pre, wi);
+        GmCand c = b.cands[ci];
+        const uint32_t r = c.rs >> 1, strand = c.rs & 1;
+        if ((c.flags & 4) && b.rs_overflow[c.rs]) continue;                 // superseded by the retry kernel
+        const uint32_t L = b.len[r];
+        const bool ok = gm_window_ok(ix, coff, c.b, L);
+        float result = 0.0f;
+        if (ok && p.nw) {
+            const float2* lut = s_lut + ((r < b.illumina_until) ? 256 : 0);
+            const uint8_t* rb = b.bases + (size_t)r * b.stride;
+            const uint8_t* rq = b.quals + (size_t)r * b.stride;
+            const int Li = (int)L;
+            // band row of i+1: P[d] = nm[i+1][i+1+delta], delta = d-3.  Row L: gGAP * (L - j) for j <= L (bin_seq.cpp:805-808)
+            float P[7], C[7];
+#pragma unroll
+            for (int d = 0; d < 7; ++d) P[d] = d <= 3 ? __fmul_rn(gap, (float)(3 - d)) : GM_NEG_INF;
+            // window bases of the current row: W[d] = w[i+delta]; start with row L-1
+            uint32_t W[7];
+            uint32_t wword_lo = 0, wword_hi = 0; int wbase = -1;          // 16-base words [wbase*16, +16) and the next one
+            auto wcode = [&](int j) -> uint32_t {                          // 2-bit code of the reference at window offset j
+                uint32_t g = c.b + (uint32_t)j;
+                int wi16 = (int)(g >> 4);
+                if (wi16 != wbase && wi16 != wbase + 1) { wbase = wi16; wword_lo = pac32[wi16]; wword_hi = pac32[wi16 + 1]; }
+                uint32_t word = wi16 == wbase ? wword_lo : wword_hi;
+                return (word >> ((((g >> 2) & 3u) << 3) + ((~g & 3u) << 1))) & 3u;     // _get_pac src/bntseq.c:225 on a little-endian word
+            };
+#pragma unroll
+            for (int d = 0; d < 7; ++d) { int j = Li - 1 + d - 3; W[d] = (j >= 0 && j < Li) ? wcode(j) : 0u; }
+            uint2 bw = make_uint2(0, 0), qw = make_uint2(0, 0); int chunk = -1;
+            for (int i = Li - 1; i >= 0; --i) {
+                // PWM row i in strand orientation (reverse_comp_cpy SequenceOperations.h:149-161)
+                const int src = strand ? Li - 1 - i : i;
+                if ((src >> 3) != chunk) {
+                    chunk = src >> 3;
+                    bw = *reinterpret_cast<const uint2*>(rb + (chunk << 3));
+                    qw = *reinterpret_cast<const uint2*>(rq + (chunk << 3));
+                }
+                const uint32_t sh = (uint32_t)(src & 3) << 3;
+                const uint32_t ch = (((src & 4) ? bw.y : bw.x) >> sh) & 255u;
+                const uint32_t qc = (((src & 4) ? qw.y : qw.x) >> sh) & 255u;
+                uint32_t code = gm_nt4(ch);
+                if (strand && code < 4) code = 3 - code;
+                const float2 pq = lut[qc];
+                float v4[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) v4[g] = gm_get_val(code, pq.x, pq.y, sg[g]);
+                const float lastcol = __fmul_rn(gap, (float)(unsigned)(Li - i));        // nm[i][L] = gGAP * (L - i)
+#pragma unroll
+                for (int d = 6; d >= 0; --d) {
+                    const int j = i + d - 3;
+                    float val = W[d] == 0 ? v4[0] : W[d] == 1 ? v4[1] : W[d] == 2 ? v4[2] : v4[3];
+                    float up = d > 0 ? P[d - 1] : ((i + 1 == Li) ? gap4 : GM_NEG_INF);      // nm[i+1][j]
+                    float left = d < 6 ? C[d + 1] : ((j + 1 == Li) ? gap4 : GM_NEG_INF);     // nm[i][j+1]
+                    float mm = __fadd_rn(P[d], val);
+                    float g1 = __fadd_rn(up, gap);
+                    float g2 = __fadd_rn(left, gap);
+                    float best = gm_max3(mm, g1, g2);
+                    C[d] = (j >= 0 && j < Li) ? best : (j == Li ? lastcol : GM_NEG_INF);
+                }
+                {
+                    int lo = i - 3 < 0 ? 0 : i - 3, hi = i + 3 >= Li ? Li - 1 : i + 3;
+                    cells += (unsigned long long)(hi - lo + 1);
+                }
+#pragma unroll
+                for (int d = 0; d < 7; ++d) P[d] = C[d];
+                // slide the window bases to row i-1
+#pragma unroll
+                for (int d = 6; d >= 1; --d) W[d] = W[d - 1];
+                W[0] = (i - 4 >= 0) ? wcode(i - 4) : 0u;
+            }
+            result = P[3];                                                      // nm[0][0]
+        } else if (!p.nw) {
+            result = (float)c.step;                                             // --no_nw: the score is the vote count (:70-76)
+        }
+        uint8_t fl = c.flags & 4;
+        if (ok) {
+            fl |= GMC_VALID;
+            if (result > 0.0f) atomicMax(reinterpret_cast<int*>(&b.top_score[r]), __float_as_int(result));   // top_align_score (:95-98)
+            if ((double)result >= b.min_score[r]) {                            // :102
+                fl |= GMC_ACCEPT;
+                atomicAdd(&b.hit_count[r], 1u);
+                ++accepted;
+            }
+        }
+        b.cands[ci].score = result;
+        b.cands[ci].flags = fl;
+    }
+    gm_count(b, GMK_NW_CELLS, cells);
+    gm_count(b, GMK_ACCEPTED, accepted);
+}
+
 __global__ void __launch_bounds__(256) k_scatter_hits(GmDevBatch b) {
     __shared__ uint32_t s_pre[GM_NSHARD + 4];
     const uint32_t n_cands = gm_cand_prefix(b, s_pre);
@@ -1111,12 +1230,13 @@ __global__ void __launch_bounds__(256) k_scatter_hits(GmDevBatch b) {
 __global__ void __launch_bounds__(256) k_traceback(GmDevIndex ix, GmDevParams p, GmDevBatch b, const GmCand* items, uint32_t n,
                                                    uint8_t* ops, uint32_t ops_stride, uint16_t* ops_len, uint32_t Lp, uint32_t mvw) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    GmNwLds S = gm_nw_lds(s_raw, Lp);
-    uint32_t* mv_all = reinterpret_cast<uint32_t*>(s_raw + GM_NW_HDR + (size_t)32 * Lp * 3);   // 32 groups x 7 x mvw words
-    for (int q = threadIdx.x; q < 512; q += 256) S.lut[q] = p.lut[q];
+    const uint32_t G = blockDim.x >> 3;
+    GmNwLds S = gm_nw_lds(s_raw, Lp, G);
+    uint32_t* mv_all = reinterpret_cast<uint32_t*>(s_raw + GM_NW_HDR + (size_t)G * Lp * 3);   // G groups x 7 x mvw words
+    for (int q = threadIdx.x; q < 512; q += blockDim.x) S.lut[q] = p.lut[q];
     if (threadIdx.x < 16) S.sg[threadIdx.x] = p.S256[(size_t)("acgt"[threadIdx.x >> 2]) * 4 + (threadIdx.x & 3)];
     const bool lds_coff = ix.n_seqs + 1 <= GM_NW_NCOFF;
-    if (lds_coff) for (uint32_t q = threadIdx.x; q <= ix.n_seqs; q += 256) S.coff[q] = ix.contig_off[q];
+    if (lds_coff) for (uint32_t q = threadIdx.x; q <= ix.n_seqs; q += blockDim.x) S.coff[q] = ix.contig_off[q];
     const uint32_t* coff = lds_coff ? S.coff : ix.contig_off;
     __syncthreads();
     const int lane = gm_lane();
@@ -1126,7 +1246,7 @@ __global__ void __launch_bounds__(256) k_traceback(GmDevIndex ix, GmDevParams p,
     uint32_t* mvg = mv_all + (size_t)g * 7 * mvw;
     uint32_t* mv = mvg + (size_t)(d < 7 ? d : 0) * mvw;
     const float gap = p.gap, gap4 = __fmul_rn(p.gap, 4.0f);
-    for (uint32_t base = blockIdx.x * 32; base < n; base += gridDim.x * 32) {
+    for (uint32_t base = blockIdx.x * G; base < n; base += gridDim.x * G) {
         uint32_t ci = base + g;
         bool have = ci < n;
         GmCand c; c.rs = 0; c.b = 0;
@@ -1303,8 +1423,13 @@ int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, in
     if (b.n == 0) return 0;
     // dense seeds (many SA hits per read x strand): one workgroup per read x strand
     if (dense && b.max_seeds <= 64) {
-        if (b.max_seeds <= 32) hipLaunchKernelGGL(k_vote_block<false>, dim3(2 * b.n), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
-        else hipLaunchKernelGGL(k_vote_block<true>, dim3(2 * b.n), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
+        static const int nt = [] { const char* e = getenv("GM_VOTE_NT"); int v = e ? atoi(e) : 128; return v == 64 || v == 256 ? v : 128; }();
+        const bool m64 = b.max_seeds > 32;
+#define GM_LAUNCH_VB(M, N) hipLaunchKernelGGL((k_vote_block<M, N>), dim3(2 * b.n), dim3(N), 0, S_(stream), ix, p, b, use_full_sa)
+        if (nt == 64) { if (m64) GM_LAUNCH_VB(true, 64); else GM_LAUNCH_VB(false, 64); }
+        else if (nt == 256) { if (m64) GM_LAUNCH_VB(true, 256); else GM_LAUNCH_VB(false, 256); }
+        else { if (m64) GM_LAUNCH_VB(true, 128); else GM_LAUNCH_VB(false, 128); }
+#undef GM_LAUNCH_VB
         return (int)hipGetLastError();
     }
     // order-free fast path while the seed steps fit a 64-bit mask; the ordered kernel is the general form
@@ -1324,9 +1449,16 @@ static inline uint32_t lp_of(uint32_t stride) { return (stride + 7u) & ~7u; }
 
 int gmk_nw(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream) {
     if (b.n == 0) return 0;
+    static const bool wave_form = [] { const char* e = getenv("GM_NW"); return e && !strcmp(e, "wave"); }();
+    if (!wave_form) {
+        hipLaunchKernelGGL(k_nw_lane, dim3(2048), dim3(256), 0, S_(stream), ix, p, b);
+        return (int)hipGetLastError();
+    }
     uint32_t Lp = lp_of(b.stride);
-    size_t lds = GM_NW_HDR + (size_t)32 * Lp * 3;
-    hipLaunchKernelGGL(k_nw, dim3(2048), dim3(256), lds, S_(stream), ix, p, b, Lp);
+    uint32_t threads = 256;                                  // 32 candidates per workgroup; long reads: 8, to stay inside LDS
+    if (GM_NW_HDR + (size_t)32 * Lp * 3 > 60 * 1024) threads = 64;
+    size_t lds = GM_NW_HDR + (size_t)(threads / 8) * Lp * 3;
+    hipLaunchKernelGGL(k_nw, dim3(threads == 256 ? 2048 : 8192), dim3(threads), lds, S_(stream), ix, p, b, Lp);
     return (int)hipGetLastError();
 }
 
@@ -1355,9 +1487,12 @@ int gmk_traceback(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& 
     if (n == 0) return 0;
     uint32_t Lp = lp_of(b.stride);
     uint32_t mvw = (Lp + 1 + 15) / 16 + 1;
-    size_t lds = GM_NW_HDR + (size_t)32 * Lp * 3 + (size_t)32 * 7 * mvw * 4;
-    uint32_t grid = cdiv(n, 32); if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_traceback, dim3(grid), dim3(256), lds, S_(stream), ix, p, b, items, n, ops, ops_stride, ops_len, Lp, mvw);
+    uint32_t threads = 256;
+    if (GM_NW_HDR + (size_t)32 * Lp * 3 + (size_t)32 * 7 * mvw * 4 > 60 * 1024) threads = 64;
+    const uint32_t G = threads / 8;
+    size_t lds = GM_NW_HDR + (size_t)G * Lp * 3 + (size_t)G * 7 * mvw * 4;
+    uint32_t grid = cdiv(n, G); if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(k_traceback, dim3(grid), dim3(threads), lds, S_(stream), ix, p, b, items, n, ops, ops_stride, ops_len, Lp, mvw);
     return (int)hipGetLastError();
 }
 

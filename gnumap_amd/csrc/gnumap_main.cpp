@@ -167,7 +167,7 @@ struct FastqReader {
                 done = true;
                 break;
             }
-            if (seq.size() > 4000) { fprintf(stderr, "read %s longer than 4000 bases\n", name.c_str()); done = true; break; }
+            if (seq.size() > 2048) { fprintf(stderr, "read %s longer than 2048 bases\n", name.c_str()); done = true; break; }
             b.names.push_back(name.substr(1));
             maxlen = std::max<uint32_t>(maxlen, (uint32_t)seq.size());
             b.seqs.push_back(seq); b.quals.push_back(qual);
