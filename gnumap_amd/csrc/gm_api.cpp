@@ -183,6 +183,7 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
     }
     dp.mer = p->mer; dp.jump = p->jump; dp.kmin = p->min_seed_hits; dp.nw = p->nw; dp.fast = p->fast;
     dp.pos_strand = p->pos_strand; dp.neg_strand = p->neg_strand; dp.align_is_fraction = p->align_is_fraction;
+    { const char* e = getenv("GM_DBG"); dp.dbg = e ? atoi(e) : 0; }
     dp.hcap = p->max_kmer_hits; dp.gap = p->gap; dp.align_score = p->align_score; dp.cutoff = p->cutoff;
     dp.S256 = ix->d_ptab.as<float>();
     dp.lut = reinterpret_cast<const float2*>(ix->d_ptab.as<float>() + 1024);

@@ -30,6 +30,7 @@ struct GmDevIndex {
 struct GmDevParams {
     int mer, jump, kmin, nw, fast, pos_strand, neg_strand, align_is_fraction;
     uint32_t hcap;
+    int dbg;                        // GM_DBG bits for kernel timing experiments (0 in production)
     float gap, align_score, cutoff;
     const float* S256;              // gALIGN_SCORES, 256 x 4, in HBM: the self score indexes it with the FASTQ characters,
                                     // the DP with rows 'a','c','g','t' (genome windows are lowercase acgt)

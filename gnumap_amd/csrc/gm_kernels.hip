@@ -734,22 +734,37 @@ __global__ void __launch_bounds__(256) k_vote_fast(GmDevIndex ix, GmDevParams p,
 }
 
 // ---- order-free vote kernel, one WORKGROUP per read x strand (dense seeds: tens of SA hits per seed and more) ----
-// Same algorithm as k_vote_fast, but the flat hit list of the read x strand is spread over 256 lanes: every lane issues
-// all of its (up to GMB_U) loads at once - one HBM latency per read x strand instead of one per 256 hits - and keeps the
-// located positions in registers, so the second (exact) pass does not touch memory again.
-#define GMB_ENTRIES 2048       // hits a workgroup keeps in registers (NT lanes x GMB_ENTRIES/NT each)
+// Same algorithm as k_vote_fast, but the flat hit list of the read x strand is spread over NT lanes: every lane issues
+// all of its loads at once - one HBM latency per read x strand - and keeps the located positions in registers.
+// LDS atomics run at roughly one wave-instruction per 25 cycles per CU, so they are rationed:
+//   pass 1   one NON-returning ds_add per hit into a counting filter (8192 slots x 8 bit)
+//   pass 2a  hits whose filter slot counted >= 2 (about one in five) are compacted into an LDS list with ballots and plain
+//            stores - no atomics
+//   pass 2b  only the compacted list goes through the exact table (CAS + two non-returning atomics), with full waves
+// The filter region is dead after pass 2a and becomes the exact table.  Reads x strands with more than GMB_ENTRIES hits
+// take the round-based path with the bit filter (as k_vote_fast).
+#define GMB_ENTRIES 2048        // hits a workgroup keeps in registers (NT lanes x GMB_ENTRIES/NT each)
+#define GMB_FBITS 13            // counting filter slots
+#define GMB_FWORDS (1 << (GMB_FBITS - 2))
+#define GMB_TBITS 10            // exact table of the one-round path
+#define GMB_TSIZE (1 << GMB_TBITS)
+#define GMB_TLIMIT (GMB_TSIZE * 3 / 4)
+#define GMB_LCAP 768            // compacted list entries per workgroup
+#define GMB_FSAT 200u           // a filter byte this high could have wrapped: hand the read x strand to the retry kernel
 template <bool MASK64, int NT>
 __global__ void __launch_bounds__(NT) k_vote_block(GmDevIndex ix, GmDevParams p, GmDevBatch b, int use_full_sa) {
-    __shared__ uint32_t s_A[GMV_FWORDS];             // pass 1 "seen" bits, later the low step masks
-    __shared__ uint32_t s_B[GMV_FWORDS];             // "seen twice"
-    __shared__ uint32_t s_keys[GMV_TSIZE];
-    __shared__ uint32_t s_vals[GMV_TSIZE];
-    __shared__ uint32_t s_hi[MASK64 ? GMV_TSIZE : 1];
-    __shared__ uint32_t s_pre[66], s_k[64], s_pos[64], s_cnt0[64];
-    __shared__ uint32_t s_nkeys, s_full;
     constexpr int GMB_U = GMB_ENTRIES / NT;
+    constexpr int NW = NT / 64;
+    constexpr int LSEG = GMB_LCAP / NW;
+    __shared__ uint32_t s_r0[2048];                  // 8 KB: counting filter, then keys[1024] + vals[1024]  (round path: A,B,keys,vals x 512)
+    __shared__ uint32_t s_mlo[GMB_TSIZE];            // low step masks
+    __shared__ uint32_t s_mhi[MASK64 ? GMB_TSIZE : 1];
+    __shared__ uint32_t s_lbp[GMB_LCAP];
+    __shared__ uint8_t s_lt[GMB_LCAP];
+    __shared__ uint32_t s_pre[66], s_k[64], s_pos[64], s_cnt0[64], s_chunk[64];
+    __shared__ uint32_t s_nkeys, s_full, s_lcnt[NW];
     const uint32_t rs = blockIdx.x;                  // grid = 2n
-    const int tid = threadIdx.x, lane = gm_lane();
+    const int tid = threadIdx.x, lane = gm_lane(), wave = tid >> 6;
     uint32_t ns = b.n_seeds[rs];
     if (ns == 0) return;                             // block-uniform
     if (p.nw && p.fast) ns = 1;
@@ -763,15 +778,17 @@ __global__ void __launch_bounds__(NT) k_vote_block(GmDevIndex ix, GmDevParams p,
         for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
         s_pre[tid + 1] = incl; s_k[tid] = mine.k; s_pos[tid] = mine.pos; s_cnt0[tid] = 0;
         if (tid == 0) { s_pre[0] = 0; s_nkeys = 0; s_full = 0; }
+        // seed of the first entry of every 32-entry chunk (the per-entry search then needs one or two steps); s_pre was
+        // written by this same wave just above, LDS operations of one wave complete in order
+        const uint32_t E0 = __shfl(incl, 63);
+        uint32_t e = (uint32_t)tid * 32u, t = 0;
+        if (e < E0) { uint32_t lo = 0, hi = ns; while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (s_pre[mid] <= e) lo = mid; else hi = mid; } t = lo; }
+        s_chunk[tid] = t;
     }
-    for (int q = tid; q < GMV_TSIZE; q += NT) { s_keys[q] = GM_EMPTY; s_vals[q] = 0; if (MASK64) s_hi[q] = 0; }
-    for (int q = tid; q < GMV_FWORDS; q += NT) { s_A[q] = 0; s_B[q] = 0; }
+    for (int q = tid; q < 2048; q += NT) s_r0[q] = 0;
     __syncthreads();
     const uint32_t E = s_pre[ns];
     const uint64_t coff0 = use_full_sa ? 0 : b.entry_off[rs];
-    const bool filter = p.kmin >= 2 && E > GMV_TSIZE / 2;
-    const bool one_round = E <= (uint32_t)NT * GMB_U;
-    GmLdsTable tb; tb.keys = s_keys; tb.vals = s_vals; tb.mask = GMV_TSIZE - 1; tb.bits = GMV_TBITS;
     uint32_t bpv[GMB_U], ttv[GMB_U];
 
     auto load_round = [&](uint32_t base) {           // located position (as window start) of up to GMB_U entries per lane
@@ -780,9 +797,12 @@ __global__ void __launch_bounds__(NT) k_vote_block(GmDevIndex ix, GmDevParams p,
         for (int u = 0; u < GMB_U; ++u) {
             uint32_t e = base + (uint32_t)u * (uint32_t)NT + (uint32_t)tid;
             ee[u] = e;
-            uint32_t t = 0;
-            if (e < E) { uint32_t lo = 0, hi = ns; while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (s_pre[mid] <= e) lo = mid; else hi = mid; } t = lo; }
-            ttv[u] = e < E ? t : 0xFFFFFFFFu;
+            uint32_t t = 0xFFFFFFFFu;
+            if (e < E) {
+                if (base == 0) { t = s_chunk[e >> 5]; while (t + 1 < ns && s_pre[t + 1] <= e) ++t; }
+                else { uint32_t lo = 0, hi = ns; while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (s_pre[mid] <= e) lo = mid; else hi = mid; } t = lo; }
+            }
+            ttv[u] = t;
         }
         uint32_t cc[GMB_U];
 #pragma unroll
@@ -796,60 +816,133 @@ __global__ void __launch_bounds__(NT) k_vote_block(GmDevIndex ix, GmDevParams p,
             bpv[u] = (cc[u] <= sp) ? 0u : cc[u] - sp;                       // :267
         }
     };
-    auto pass1 = [&]() {
+    if (p.dbg & 1) {                                 // timing experiment: loads only
+        uint32_t acc = 0;
+        for (uint32_t base = 0; base < E; base += (uint32_t)NT * GMB_U) { load_round(base);
 #pragma unroll
-        for (int u = 0; u < GMB_U; ++u)
-            if (ttv[u] != 0xFFFFFFFFu && bpv[u] != 0) {
-                uint32_t h = (bpv[u] * 0x9E3779B1u) >> (32 - GMV_FBITS), bit = 1u << (h & 31);
-                uint32_t old = atomicOr(&s_A[h >> 5], bit);
-                if (old & bit) atomicOr(&s_B[h >> 5], bit);
-            }
-    };
-    auto pass2 = [&]() {
-        uint32_t nfresh = 0; bool full = false;
+            for (int u = 0; u < GMB_U; ++u) acc ^= bpv[u]; }
+        if (acc == 0x12345678u) b.rs_overflow[rs] = 3;
+        return;
+    }
+
+    GmLdsTable tb;
+    uint32_t* mlo = s_mlo;
+    bool failed = false;
+    if (E <= (uint32_t)NT * GMB_U) {
+        // ------------------------------------------------------------ one round: everything stays in registers
+        const bool filter = p.kmin >= 2 && E > 256;
+        load_round(0);
+        if (filter && !(p.dbg & 2)) {
 #pragma unroll
-        for (int u = 0; u < GMB_U; ++u)
+            for (int u = 0; u < GMB_U; ++u)
+                if (ttv[u] != 0xFFFFFFFFu && bpv[u] != 0) {
+                    uint32_t h = (bpv[u] * 0x9E3779B1u) >> (32 - GMB_FBITS);
+                    atomicAdd(&s_r0[h >> 2], 1u << ((h & 3) << 3));         // result unused: non-returning ds_add
+                }
+        }
+        __syncthreads();
+        uint32_t wcount = 0;                         // wave-uniform fill of this wave's list segment
+#pragma unroll
+        for (int u = 0; u < GMB_U; ++u) {
+            bool pass = false;
             if (ttv[u] != 0xFFFFFFFFu) {
-                uint32_t bp = bpv[u], t = ttv[u];
-                uint32_t h = (bp * 0x9E3779B1u) >> (32 - GMV_FBITS), bit = 1u << (h & 31);
-                if (bp == 0) atomicAdd(&s_cnt0[t], 1u);
-                else if (!filter || (s_B[h >> 5] & bit)) {
-                    bool fresh;
+                if (bpv[u] == 0) atomicAdd(&s_cnt0[ttv[u]], 1u);
+                else if (!filter) pass = true;
+                else {
+                    uint32_t h = (bpv[u] * 0x9E3779B1u) >> (32 - GMB_FBITS);
+                    pass = ((s_r0[h >> 2] >> ((h & 3) << 3)) & 255u) >= 2u;
+                }
+            }
+            unsigned long long m = __ballot(pass);
+            if (pass) {
+                uint32_t at = wcount + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (at < (uint32_t)LSEG) { s_lbp[wave * LSEG + at] = bpv[u]; s_lt[wave * LSEG + at] = (uint8_t)ttv[u]; }
+            }
+            wcount += (uint32_t)__popcll(m);
+        }
+        if (lane == 0) { s_lcnt[wave] = wcount < (uint32_t)LSEG ? wcount : (uint32_t)LSEG; if (wcount > (uint32_t)LSEG) s_full = 1; }
+        __syncthreads();
+        // the filter is dead: check it for saturation while turning its memory into the exact table
+        for (int q = tid; q < 2048; q += NT) {
+            uint32_t w = s_r0[q];
+            if (filter && ((w & 255u) >= GMB_FSAT || ((w >> 8) & 255u) >= GMB_FSAT || ((w >> 16) & 255u) >= GMB_FSAT || (w >> 24) >= GMB_FSAT)) s_full = 1;
+            s_r0[q] = q < GMB_TSIZE ? GM_EMPTY : 0u;
+        }
+        for (int q = tid; q < GMB_TSIZE; q += NT) { s_mlo[q] = 0; if (MASK64) s_mhi[q] = 0; }
+        __syncthreads();
+        tb.keys = s_r0; tb.vals = s_r0 + GMB_TSIZE; tb.mask = GMB_TSIZE - 1; tb.bits = GMB_TBITS;
+        if (!(p.dbg & 4)) {
+            const uint32_t n_l = s_lcnt[wave];
+            uint32_t nfresh = 0; bool full = false;
+            for (uint32_t i0 = 0; i0 < n_l; i0 += 64) {
+                uint32_t i = i0 + (uint32_t)lane;
+                bool fresh = false;
+                if (i < n_l) {
+                    uint32_t bp = s_lbp[wave * LSEG + i], t = s_lt[wave * LSEG + i];
                     uint32_t slot = gm_table_insert(tb, bp, &fresh);
                     if (slot == GM_EMPTY) full = true;
                     else {
-                        nfresh += fresh ? 1u : 0u;
-                        atomicAdd(&s_vals[slot], 1u);
-                        if (t < 32) atomicOr(&s_A[slot], 1u << t);          // low step mask (A is free after pass 1)
-                        else if (MASK64) atomicOr(&s_hi[slot], 1u << (t - 32));
+                        atomicAdd(&tb.vals[slot], 1u);
+                        if (t < 32) atomicOr(&s_mlo[slot], 1u << t);
+                        else if (MASK64) atomicOr(&s_mhi[slot], 1u << (t - 32));
                     }
                 }
+                nfresh += (uint32_t)__popcll(__ballot(fresh));
             }
-        if (nfresh) atomicAdd(&s_nkeys, nfresh);
-        if (full) s_full = 1;
-    };
-
-    if (one_round) {
-        load_round(0);
-        if (filter) pass1();
+            if (lane == 0 && nfresh) atomicAdd(&s_nkeys, nfresh);
+            if (full) s_full = 1;
+        }
         __syncthreads();
-        for (int q = tid; q < GMV_TSIZE; q += NT) s_A[q] = 0;              // A becomes the low step masks
-        __syncthreads();
-        pass2();
+        failed = s_full || s_nkeys > GMB_TLIMIT;
     } else {
-        if (filter) for (uint32_t base = 0; base < E; base += (uint32_t)NT * GMB_U) { load_round(base); pass1(); }
+        // ------------------------------------------------------------ rounds of GMB_ENTRIES hits, bit filter (as k_vote_fast)
+        uint32_t* A = s_r0; uint32_t* B = s_r0 + 512;
+        tb.keys = s_r0 + 1024; tb.vals = s_r0 + 1536; tb.mask = GMV_TSIZE - 1; tb.bits = GMV_TBITS;
+        const bool filter = p.kmin >= 2;
+        for (int q = tid; q < GMV_TSIZE; q += NT) { tb.keys[q] = GM_EMPTY; s_mlo[q] = 0; if (MASK64) s_mhi[q] = 0; }
         __syncthreads();
-        for (int q = tid; q < GMV_TSIZE; q += NT) s_A[q] = 0;
+        if (filter)
+            for (uint32_t base = 0; base < E; base += (uint32_t)NT * GMB_U) {
+                load_round(base);
+#pragma unroll
+                for (int u = 0; u < GMB_U; ++u)
+                    if (ttv[u] != 0xFFFFFFFFu && bpv[u] != 0) {
+                        uint32_t h = (bpv[u] * 0x9E3779B1u) >> (32 - GMV_FBITS), bit = 1u << (h & 31);
+                        uint32_t old = atomicOr(&A[h >> 5], bit);
+                        if (old & bit) atomicOr(&B[h >> 5], bit);
+                    }
+            }
         __syncthreads();
         for (uint32_t base = 0; base < E; base += (uint32_t)NT * GMB_U) {
             load_round(base);
-            pass2();
+            uint32_t nfresh = 0; bool full = false;
+#pragma unroll
+            for (int u = 0; u < GMB_U; ++u)
+                if (ttv[u] != 0xFFFFFFFFu) {
+                    uint32_t bp = bpv[u], t = ttv[u];
+                    uint32_t h = (bp * 0x9E3779B1u) >> (32 - GMV_FBITS), bit = 1u << (h & 31);
+                    if (bp == 0) atomicAdd(&s_cnt0[t], 1u);
+                    else if (!filter || (B[h >> 5] & bit)) {
+                        bool fresh;
+                        uint32_t slot = gm_table_insert(tb, bp, &fresh);
+                        if (slot == GM_EMPTY) full = true;
+                        else {
+                            nfresh += fresh ? 1u : 0u;
+                            atomicAdd(&tb.vals[slot], 1u);
+                            if (t < 32) atomicOr(&s_mlo[slot], 1u << t);
+                            else if (MASK64) atomicOr(&s_mhi[slot], 1u << (t - 32));
+                        }
+                    }
+                }
+            if (nfresh) atomicAdd(&s_nkeys, nfresh);
+            if (full) s_full = 1;
             __syncthreads();
             if (s_full || s_nkeys > GMV_TLIMIT) break;                       // block-uniform
         }
+        __syncthreads();
+        failed = s_full || s_nkeys > GMV_TLIMIT;
     }
-    __syncthreads();
-    if (s_full || s_nkeys > GMV_TLIMIT) {           // hand this read x strand to the global-table kernel
+    if (failed) {                                    // hand this read x strand to the global-table kernel
         if (tid == 0) {
             b.rs_overflow[rs] = 1;
             uint32_t j = atomicAdd(b.n_retry, 1u);
@@ -861,13 +954,13 @@ __global__ void __launch_bounds__(NT) k_vote_block(GmDevIndex ix, GmDevParams p,
         }
         return;
     }
-    for (int q = tid; q < GMV_TSIZE; q += NT) {     // emit: NW step = kmin-th lowest step that voted
-        uint32_t key = s_keys[q], v = s_vals[q];
+    for (uint32_t q = (uint32_t)tid; q <= tb.mask; q += NT) {      // emit: NW step = kmin-th lowest step that voted
+        uint32_t key = tb.keys[q], v = tb.vals[q];
         bool emit = key != GM_EMPTY && v >= (uint32_t)p.kmin;
         uint32_t step = 0;
         if (emit) {
             if (p.nw) {
-                unsigned long long m = (unsigned long long)s_A[q] | (MASK64 ? ((unsigned long long)s_hi[q] << 32) : 0ull);
+                unsigned long long m = (unsigned long long)mlo[q] | (MASK64 ? ((unsigned long long)s_mhi[q] << 32) : 0ull);
                 for (int r = 1; r < p.kmin && m; ++r) m &= m - 1;
                 step = m ? (uint32_t)(__ffsll((long long)m) - 1) : 0u;
             } else step = v > 65535u ? 65535u : v;
