@@ -67,6 +67,7 @@ struct gm_index {
     uint32_t cov_bin_size = 0;
     // parameter tables resident in HBM: S256 (256x4 floats) + lut (512 float2)
     std::vector<float> ptab_host;
+    std::map<int, DevBuf> kmer_tabs;        // memoised backward search of the last T characters of a seed, per T
     std::mutex mu;
     uint64_t hbm_bytes = 0;
 };
@@ -184,6 +185,24 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
     dp.mer = p->mer; dp.jump = p->jump; dp.kmin = p->min_seed_hits; dp.nw = p->nw; dp.fast = p->fast;
     dp.pos_strand = p->pos_strand; dp.neg_strand = p->neg_strand; dp.align_is_fraction = p->align_is_fraction;
     { const char* e = getenv("GM_DBG"); dp.dbg = e ? atoi(e) : 0; }
+    // k-mer interval table: the last T = min(mer, 12) characters of every seed are one 8-byte lookup (GM_KMER_TABLE=0
+    // keeps the pure occ walk; GM_KMER_TABLE=<T> picks another suffix length)
+    dp.kmer_tab = nullptr; dp.kmer_T = 0;
+    {
+        int T = std::min(p->mer, 12);
+        if (const char* e = getenv("GM_KMER_TABLE")) T = std::min(std::min(atoi(e), p->mer), 13);
+        if (T >= 4) {
+            std::lock_guard<std::mutex> lk(ix->mu);
+            DevBuf& tb = ix->kmer_tabs[T];
+            if (!tb.p) {
+                if (tb.ensure(((size_t)1 << (2 * T)) * 8)) return GM_E_NOMEM;
+                KCHK(gmk_build_kmer_table(ix->dev, tb.as<uint2>(), T, st));
+                HIPCHK(hipStreamSynchronize(st));
+                ix->hbm_bytes += tb.cap;
+            }
+            dp.kmer_tab = tb.as<uint2>(); dp.kmer_T = T;
+        }
+    }
     dp.hcap = p->max_kmer_hits; dp.gap = p->gap; dp.align_score = p->align_score; dp.cutoff = p->cutoff;
     dp.S256 = ix->d_ptab.as<float>();
     dp.lut = reinterpret_cast<const float2*>(ix->d_ptab.as<float>() + 1024);
@@ -277,6 +296,7 @@ extern "C" void gm_index_close(gm_index* ix) {
         (void)hipSetDevice(ix->device);
         ix->d_bwt.release(); ix->d_sa.release(); ix->d_full.release(); ix->d_pac.release(); ix->d_contig.release();
         ix->d_cov.release(); ix->d_ptab.release(); ix->d_planes.release();
+        for (auto& kv : ix->kmer_tabs) kv.second.release();
     }
     delete ix;
 }

@@ -34,6 +34,8 @@ struct GmDevParams {
     float gap, align_score, cutoff;
     const float* S256;              // gALIGN_SCORES, 256 x 4, in HBM: the self score indexes it with the FASTQ characters,
                                     // the DP with rows 'a','c','g','t' (genome windows are lowercase acgt)
+    const uint2* kmer_tab;          // SA interval of every kmer_T-mer (suffix of the seed k-mer), or null: {k,l}; empty = {0xFFFFFFFF, depth}
+    int kmer_T;
     const float2* lut;              // [0..255] Phred+33, [256..511] Phred+64: (p, (1-p)/3) as fp32; p = NaN when negative
 };
 
@@ -57,7 +59,7 @@ struct GmRawHit { uint32_t read; uint32_t pos; float score; uint16_t step; uint8
 // device-side counters, one u64 each (see gm_counters in the public header)
 enum {
     GMK_KMERS = 0, GMK_OCC, GMK_SEEDS, GMK_SA_HITS, GMK_LF_STEPS, GMK_CANDS, GMK_NW_CELLS, GMK_ACCEPTED,
-    GMK_OVERFLOW_RS, GMK_BAD_QUAL, GMK_HEAVY_SLOTS, GMK_OCC_BLOCKS, GMK_N
+    GMK_OVERFLOW_RS, GMK_BAD_QUAL, GMK_HEAVY_SLOTS, GMK_OCC_BLOCKS, GMK_TAB_LOOKUPS, GMK_N
 };
 
 struct GmDevBatch {
@@ -96,6 +98,7 @@ struct GmDevBatch {
 extern "C++" {
 int gmk_expand_full_sa(const GmDevIndex& ix, uint32_t* full_sa, void* stream);
 int gmk_build_occ_planes(const GmDevIndex& ix, uint4* planes, uint32_t nblk, void* stream);
+int gmk_build_kmer_table(const GmDevIndex& ix, uint2* tab, int T, void* stream);
 int gmk_prep(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream);
 int gmk_seed(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream);
 int gmk_scan_entries(const GmDevBatch& b, void* stream);

@@ -198,6 +198,27 @@ __global__ void __launch_bounds__(256) k_build_occ_planes(GmDevIndex ix, uint4* 
     }
 }
 
+// SA interval of every T-mer (memoised bwt_match_exact on the last T characters of a seed k-mer): one thread per T-mer.
+// code = sum over characters, leftmost character in the highest bits.  Empty: {0xFFFFFFFF, d} with d = number of
+// characters (from the right end) after which the backward search died.
+__global__ void __launch_bounds__(256) k_build_kmer_table(GmDevIndex ix, uint2* tab, int T) {
+    uint32_t code = blockIdx.x * blockDim.x + threadIdx.x;
+    if (code >= (1u << (2 * T))) return;
+    uint32_t k = 0, l = ix.seq_len;
+    uint2 out;
+    out.x = 0; out.y = 0;
+    bool ok = true;
+    for (int t = 0; t < T; ++t) {                    // t-th character from the right end
+        uint32_t c = (code >> (2 * t)) & 3u;
+        uint32_t ok_ = gm_occ_plane(ix, k - 1, c), ol_ = gm_occ_plane(ix, l, c);
+        k = gm_L2(ix, c) + ok_ + 1;
+        l = gm_L2(ix, c) + ol_;
+        if (k > l) { ok = false; out.x = 0xFFFFFFFFu; out.y = (uint32_t)t + 1; break; }
+    }
+    if (ok) { out.x = k; out.y = l; }
+    tab[code] = out;
+}
+
 // ------------------------------------------------------------------------------------------------
 // prep: one thread per read
 // ------------------------------------------------------------------------------------------------
@@ -272,7 +293,7 @@ __global__ void __launch_bounds__(256) k_seed(GmDevIndex ix, GmDevParams p, GmDe
     }
     __syncthreads();
     uint32_t rs = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long nk = 0, nocc = 0, nblk = 0, nseed = 0, nent = 0;
+    unsigned long long nk = 0, nocc = 0, nblk = 0, nseed = 0, nent = 0, ntab = 0;
     if (rs < 2 * b.n) {
         uint32_t r = rs >> 1, strand = rs & 1;
         bool on = b.status[r] == 0 && (strand ? p.neg_strand : p.pos_strand);
@@ -285,10 +306,27 @@ __global__ void __launch_bounds__(256) k_seed(GmDevIndex ix, GmDevParams p, GmDe
             while (i < last) {
                 // bwt_match_exact on the k-mer at [i, i+mer), right to left
                 uint32_t k = 0, l = ix.seq_len;
-                int t;
+                int t = p.mer - 1;
                 bool ok = true;
                 ++nk;
-                for (t = p.mer - 1; t >= 0; --t) {
+                if (p.kmer_tab) {
+                    // the last kmer_T characters in one lookup of the memoised backward search
+                    uint32_t code = 0;
+                    for (int q = 0; q < p.kmer_T; ++q, --t) {
+                        uint32_t pos = i + (uint32_t)t;
+                        uint32_t c = gm_nt4(strand ? rb[L - 1 - pos] : rb[pos]);
+                        if (c > 3) { ok = false; break; }           // t = position of the rightmost non-ACGT
+                        if (strand) c = 3 - c;
+                        code |= c << (2 * q);
+                    }
+                    if (ok) {
+                        const uint2 iv = p.kmer_tab[code];
+                        ++ntab;
+                        if (iv.x == 0xFFFFFFFFu) { ok = false; t = p.mer - (int)iv.y; }   // the last iv.y characters do not occur
+                        else { k = iv.x; l = iv.y; }
+                    }
+                }
+                for (; ok && t >= 0; --t) {
                     uint32_t pos = i + (uint32_t)t;
                     uint32_t c = gm_nt4(strand ? rb[L - 1 - pos] : rb[pos]);
                     if (c > 3) { ok = false; break; }
@@ -326,6 +364,7 @@ __global__ void __launch_bounds__(256) k_seed(GmDevIndex ix, GmDevParams p, GmDe
     gm_count(b, GMK_KMERS, nk);
     gm_count(b, GMK_OCC, nocc);
     gm_count(b, GMK_OCC_BLOCKS, nblk);
+    gm_count(b, GMK_TAB_LOOKUPS, ntab);
     gm_count(b, GMK_SEEDS, nseed);
     gm_count(b, GMK_SA_HITS, nent);
 }
@@ -1477,6 +1516,12 @@ int gmk_expand_full_sa(const GmDevIndex& ix, uint32_t* full_sa, void* stream) {
 
 int gmk_build_occ_planes(const GmDevIndex& ix, uint4* planes, uint32_t nblk, void* stream) {
     hipLaunchKernelGGL(k_build_occ_planes, dim3(cdiv(nblk, 256)), dim3(256), 0, S_(stream), ix, planes, nblk);
+    return (int)hipGetLastError();
+}
+
+int gmk_build_kmer_table(const GmDevIndex& ix, uint2* tab, int T, void* stream) {
+    uint32_t n = 1u << (2 * T);
+    hipLaunchKernelGGL(k_build_kmer_table, dim3(cdiv(n, 256)), dim3(256), 0, S_(stream), ix, tab, T);
     return (int)hipGetLastError();
 }
 
