@@ -100,7 +100,7 @@ def algorithmic_bytes(c, L, n_reads):
     win = L // 4 + 1
     return {
         "k_prep": n_reads * (2 * L + 17),
-        "k_seed": c["occ_blocks"] * 64 + n_reads * 2 * L + c["seeds_used"] * 12 + 2 * n_reads * 6,
+        "k_seed": c["occ_blocks"] * 64 + c.get("table_lookups", 0) * 8 + n_reads * 2 * L + c["seeds_used"] * 12 + 2 * n_reads * 6,
         "k_locate_sampled": c["lf_steps"] * 64 + c["sa_hits"] * 8,
         "k_vote": c["sa_hits"] * 4 + c["seeds_used"] * 12 + c["candidates"] * 16,
         "k_nw": c["candidates"] * (16 + 2 * L + win + 4),
@@ -157,19 +157,15 @@ def main():
     import torch
     import torch.distributed as dist
     import gnumap_amd as g
+    from gnumap_amd import dist as gd
 
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local = gd.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libgnumap_hip has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    gd.init("nccl", dev)                                      # RCCL over xGMI when WORLD_SIZE > 1
+    barrier = gd.barrier
 
     kw = dict(mer=a.mer, jump=a.jump, max_kmer_hits=a.max_kmer_hits, nw=0 if a.no_nw else 1)
     key = f"g{a.genome_mbp:g}m_c{a.contigs}_s42"
@@ -189,7 +185,7 @@ def main():
     pac = np.fromfile(fa + ".gnumap.pac", np.uint8)[: ix.info.l_pac // 4 + 1]
     codes = np.stack([(pac >> 6) & 3, (pac >> 4) & 3, (pac >> 2) & 3, pac & 3], 1).reshape(-1)[: ix.info.l_pac]
     codes_t = torch.from_numpy(codes).to(dev)
-    B, Q, Ln = make_reads(codes_t, a.reads, a.read_len, 1000 + rank, dev)
+    B, Q, Ln = make_reads(codes_t, a.reads, a.read_len, gd.read_seed(1000, rank), dev)
     del codes_t
     torch.cuda.empty_cache()
     p = g.Params(**kw)
@@ -197,6 +193,12 @@ def main():
     batch.upload(p, B, Q, Ln)                   # reads resident in HBM from here on
     ix.coverage_reset(p.bin_size)
     torch.cuda.synchronize()
+    # PCIe-inclusive rate (never `value`): host -> HBM upload of the batch + one pass, measured once outside the timed region
+    t_up = time.perf_counter()
+    batch.upload(p, B, Q, Ln)
+    batch.map_device(p)
+    torch.cuda.synchronize()
+    pcie_inclusive = a.reads / (time.perf_counter() - t_up)
     log(f"[bench] rank {rank}: setup {time.time() - t_setup:.1f} s, index {ix.info.hbm_bytes / 1e9:.2f} GB in HBM, {a.reads} reads resident")
 
     for _ in range(a.warmup):
@@ -210,10 +212,7 @@ def main():
         batch.map_device(p)
     torch.cuda.synchronize(); barrier()
     t1 = time.perf_counter()
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
+    elapsed = gd.max_over_ranks(t1 - t0, dev)
     ktimes = batch.kernel_times()
     counters = batch.counters()
 
@@ -221,12 +220,10 @@ def main():
     # per-step loop, like the reference's MPI Allreduce at end of run: src/Driver.cpp:1660-1672)
     allreduce_ms = None
     if world > 1:
-        class _Cov:
-            __cuda_array_interface__ = {"shape": (ix.coverage_bins(),), "typestr": "<f4", "data": (ix.coverage_device_ptr(), False), "version": 2}
-        cov = torch.as_tensor(_Cov(), device=dev)
+        cov = gd.DeviceTrack(ix.coverage_device_ptr(), ix.coverage_bins()).tensor(dev)
         torch.cuda.synchronize(); barrier()
         ta = time.perf_counter()
-        dist.all_reduce(cov)
+        gd.allreduce_coverage(cov)
         torch.cuda.synchronize()
         allreduce_ms = (time.perf_counter() - ta) * 1e3
 
@@ -270,6 +267,7 @@ def main():
             "kernels": {k: {"ms": round(v["ms"], 4), "alg_GBps": round(v["GBps"], 2)} for k, v in per_kernel.items()},
             "counters_per_step": counters,
             "coverage_allreduce_ms": allreduce_ms,
+            "pcie_inclusive_reads_per_s": round(pcie_inclusive, 1),
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -63,7 +63,7 @@ class gm_sam_out(C.Structure):
 
 class gm_counters(C.Structure):
     _fields_ = [(n, u64) for n in ("reads", "kmers_searched", "occ_calls", "occ_blocks", "seeds_used", "sa_hits", "lf_steps", "candidates",
-                                   "nw_cells", "accepted", "vote_retries")]
+                                   "nw_cells", "accepted", "vote_retries", "table_lookups")]
 
 GM_K_COUNT = 7
 

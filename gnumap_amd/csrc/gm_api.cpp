@@ -536,7 +536,7 @@ extern "C" int gm_batch_counters(gm_batch* b, gm_counters* o) {
     o->reads = b->n; o->kmers_searched = c[GMK_KMERS]; o->occ_calls = c[GMK_OCC]; o->occ_blocks = c[GMK_OCC_BLOCKS];
     o->seeds_used = c[GMK_SEEDS]; o->sa_hits = c[GMK_SA_HITS];
     o->lf_steps = c[GMK_LF_STEPS]; o->candidates = b->n_cands; o->nw_cells = c[GMK_NW_CELLS]; o->accepted = c[GMK_ACCEPTED];
-    o->vote_retries = c[GMK_OVERFLOW_RS];
+    o->vote_retries = c[GMK_OVERFLOW_RS]; o->table_lookups = c[GMK_TAB_LOOKUPS];
     return GM_OK;
 }
 

@@ -148,7 +148,8 @@ typedef struct {
 
 /* kernel-side work counters of the last gm_map_batch on a batch (algorithmic-bytes accounting) */
 typedef struct {
-    uint64_t reads, kmers_searched, occ_calls, occ_blocks, seeds_used, sa_hits, lf_steps, candidates, nw_cells, accepted, vote_retries;
+    uint64_t reads, kmers_searched, occ_calls, occ_blocks, seeds_used, sa_hits, lf_steps, candidates, nw_cells, accepted, vote_retries,
+        table_lookups;
 } gm_counters;
 
 /* kernels of gm_map_batch_device, for the HIP-event timing of gm_batch_kernel_times */
