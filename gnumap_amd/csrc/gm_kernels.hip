@@ -1018,6 +1018,218 @@ __global__ void __launch_bounds__(NT) k_vote_block(GmDevIndex ix, GmDevParams p,
     }
 }
 
+// ---- vote kernel v4 (dense seeds): seed-uniform load steps, tag filter with plain LDS stores ----------------------
+// The workgroup walks "steps": step s covers NT consecutive SA ranks of ONE seed, so the seed (its step index, SA base and
+// read offset) is wave-uniform and no per-hit table lookups are needed.  All steps' loads are issued back to back.
+// Duplicate detection without LDS atomics: votes for the same position always come from DIFFERENT seeds, so
+//   P1  every hit writes its seed tag (one byte) into slot h(b)                       (plain store, last writer wins)
+//   P2  a hit that reads back a different tag sets the slot's dup flag               (plain load + plain store of 1)
+//   P3  hits whose slot is flagged are compacted into a list (ballot + plain stores)  -> about 1 in 5
+// If two different tags met in a slot at least one of them sees the other's tag, so the flag cannot be missed.  Only the
+// compacted list goes through the exact table (CAS + two non-returning atomics, full waves).
+#define GMC_SLOTS 8192
+template <bool MASK64, int NT>
+__global__ void __launch_bounds__(NT, 4) k_vote_steps(GmDevIndex ix, GmDevParams p, GmDevBatch b, int use_full_sa) {
+    constexpr int SMAX = NT == 64 ? 40 : 24;
+    constexpr int NW = NT / 64;
+    constexpr int LSEG = GMB_LCAP / NW;
+    __shared__ __attribute__((aligned(16))) uint32_t s_tag[GMC_SLOTS / 4];    // 8 KB: tags, then keys[1024] + vals[1024]
+    __shared__ __attribute__((aligned(16))) uint32_t s_dup[GMC_SLOTS / 8];    // 4 KB: dup flags (1 byte per 2 slots), then low step masks
+    __shared__ __attribute__((aligned(16))) uint32_t s_mhi[MASK64 ? GMB_TSIZE : 4];
+    __shared__ uint32_t s_lbp[GMB_LCAP];
+    __shared__ uint8_t s_lt[GMB_LCAP];
+    __shared__ uint32_t s_stk[SMAX], s_stw[SMAX], s_cnt0[64];     // per step: first SA rank | (valid lanes, read offset, seed index) packed
+    __shared__ uint32_t s_S, s_E, s_nkeys, s_full, s_lcnt[NW];
+    const uint32_t rs = blockIdx.x;
+    const int tid = threadIdx.x, lane = gm_lane(), wave = tid >> 6;
+    uint32_t ns = b.n_seeds[rs];
+    if (ns == 0) return;                             // block-uniform
+    if (p.nw && p.fast) ns = 1;
+    const GmSeed* seeds = b.seeds + (size_t)rs * b.max_seeds;
+    const uint64_t coff0 = use_full_sa ? 0 : b.entry_off[rs];
+    if (tid < 64) {                                  // wave 0: seeds -> step table
+        GmSeed mine; mine.k = 0; mine.l = 0; mine.pos = 0;
+        uint32_t cnt = 0;
+        if ((uint32_t)tid < ns) { mine = seeds[tid]; cnt = mine.l - mine.k + 1; }
+        uint32_t nch = (cnt + NT - 1) / NT;
+        uint32_t incl = nch, einc = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t t1 = __shfl_up(incl, off), t2 = __shfl_up(einc, off);
+            if (lane >= off) { incl += t1; einc += t2; }
+        }
+        const uint32_t S = __shfl(incl, 63), E = __shfl(einc, 63);
+        if (S <= SMAX) {
+            uint32_t s0 = incl - nch, e0 = einc - cnt;
+            for (uint32_t q = 0; q < nch; ++q) {
+                uint32_t left = cnt - q * NT;
+                // full SA: absolute rank of the step's first hit; sampled mode: its index in coords[]
+                s_stk[s0 + q] = use_full_sa ? mine.k + q * NT : e0 + q * NT;
+                s_stw[s0 + q] = (left < (uint32_t)NT ? left : (uint32_t)NT) | (mine.pos << 8) | ((uint32_t)tid << 24);   // n <= 128, pos < 2^16, t < 64
+            }
+        }
+        s_cnt0[tid] = 0;
+        if (tid == 0) { s_S = S; s_E = E; s_nkeys = 0; s_full = 0; }
+    }
+    {   // clear tags + dup flags with 16-byte stores
+        uint4 z = make_uint4(0, 0, 0, 0);
+        for (int q = tid; q < GMC_SLOTS / 16; q += NT) reinterpret_cast<uint4*>(s_tag)[q] = z;
+        for (int q = tid; q < GMC_SLOTS / 32; q += NT) reinterpret_cast<uint4*>(s_dup)[q] = z;
+    }
+    __syncthreads();
+    const uint32_t S = s_S, E = s_E;
+    if (S > SMAX) {                                  // too many steps for the register file: the global-table kernel takes it
+        if (tid == 0) {
+            b.rs_overflow[rs] = 1;
+            uint32_t j = atomicAdd(b.n_retry, 1u);
+            uint32_t need = 2 * E; uint32_t sz = 1024; while (sz < need && sz < 0x80000000u) sz <<= 1;
+            unsigned long long off = atomicAdd(&b.counters[GMK_HEAVY_SLOTS], (unsigned long long)sz);
+            b.retry_list[j] = rs; b.retry_off[j] = off;
+            atomicAdd(&b.counters[GMK_OVERFLOW_RS], 1ull);
+        }
+        return;
+    }
+    const bool filter = p.kmin >= 2 && E > 256;
+    uint8_t* tag8 = reinterpret_cast<uint8_t*>(s_tag);
+    uint8_t* dup8 = reinterpret_cast<uint8_t*>(s_dup);
+    // ---- loads: one per step, all in flight together
+    uint32_t bpv[SMAX];
+    unsigned long long vmask = 0;                    // bit s: this lane holds a hit in step s
+    uint32_t stw[SMAX];                              // wave-uniform step words, kept in scalar registers
+#pragma unroll
+    for (int q = 0; q < SMAX; ++q) {
+        bpv[q] = 0; stw[q] = 0;
+        if ((uint32_t)q < S) {
+            stw[q] = __builtin_amdgcn_readfirstlane(s_stw[q]);
+            const uint32_t k0 = __builtin_amdgcn_readfirstlane(s_stk[q]);
+            if ((uint32_t)tid < (stw[q] & 255u)) {
+                vmask |= 1ull << q;
+                bpv[q] = use_full_sa ? ix.full_sa[k0 + (uint32_t)tid] : b.coords[coff0 + k0 + (uint32_t)tid];
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < SMAX; ++q)
+        if ((uint32_t)q < S) { uint32_t sp = (stw[q] >> 8) & 0xFFFFu; bpv[q] = (bpv[q] <= sp) ? 0u : bpv[q] - sp; }     // :267
+    if (p.dbg & 1) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int q = 0; q < SMAX; ++q) acc ^= bpv[q];
+        if (acc == 0x12345678u) b.rs_overflow[rs] = 3;
+        return;
+    }
+    // ---- P1 / P2: tag filter
+    if (filter && !(p.dbg & 2)) {
+#pragma unroll
+        for (int q = 0; q < SMAX; ++q)
+            if ((uint32_t)q < S && ((vmask >> q) & 1) && bpv[q] != 0) {
+                uint32_t h = (bpv[q] * 0x9E3779B1u) >> (32 - GMB_FBITS);
+                tag8[h] = (uint8_t)((stw[q] >> 24) + 1);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < SMAX; ++q)
+            if ((uint32_t)q < S && ((vmask >> q) & 1) && bpv[q] != 0) {
+                uint32_t h = (bpv[q] * 0x9E3779B1u) >> (32 - GMB_FBITS);
+                if (tag8[h] != (uint8_t)((stw[q] >> 24) + 1)) dup8[h >> 1] = 1;
+            }
+    }
+    __syncthreads();
+    // ---- P3: compaction of the flagged hits
+    uint32_t wcount = 0;
+#pragma unroll
+    for (int q = 0; q < SMAX; ++q) {
+        if ((uint32_t)q < S) {                       // block-uniform
+            bool pass = false;
+            const uint32_t t = stw[q] >> 24;
+            if ((vmask >> q) & 1) {
+                if (bpv[q] == 0) atomicAdd(&s_cnt0[t], 1u);
+                else if (!filter) pass = true;
+                else { uint32_t h = (bpv[q] * 0x9E3779B1u) >> (32 - GMB_FBITS); pass = dup8[h >> 1] != 0; }
+            }
+            unsigned long long m = __ballot(pass);
+            if (pass) {
+                uint32_t at = wcount + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (at < (uint32_t)LSEG) { s_lbp[wave * LSEG + at] = bpv[q]; s_lt[wave * LSEG + at] = (uint8_t)t; }
+            }
+            wcount += (uint32_t)__popcll(m);
+        }
+    }
+    if (lane == 0) { s_lcnt[wave] = wcount < (uint32_t)LSEG ? wcount : (uint32_t)LSEG; if (wcount > (uint32_t)LSEG) s_full = 1; }
+    __syncthreads();
+    // ---- the filter memory becomes the exact table: keys (EMPTY) | vals (0) | low masks (0)
+    {
+        uint4 e4 = make_uint4(GM_EMPTY, GM_EMPTY, GM_EMPTY, GM_EMPTY), z = make_uint4(0, 0, 0, 0);
+        for (int q = tid; q < GMC_SLOTS / 16; q += NT) reinterpret_cast<uint4*>(s_tag)[q] = q < GMB_TSIZE / 4 ? e4 : z;
+        for (int q = tid; q < GMB_TSIZE / 4; q += NT) reinterpret_cast<uint4*>(s_dup)[q] = z;
+        if (MASK64) for (int q = tid; q < GMB_TSIZE / 4; q += NT) reinterpret_cast<uint4*>(s_mhi)[q] = z;
+    }
+    __syncthreads();
+    GmLdsTable tb; tb.keys = s_tag; tb.vals = s_tag + GMB_TSIZE; tb.mask = GMB_TSIZE - 1; tb.bits = GMB_TBITS;
+    uint32_t* mlo = s_dup;
+    if (!(p.dbg & 4)) {
+        const uint32_t n_l = s_lcnt[wave];
+        uint32_t nfresh = 0; bool full = false;
+        for (uint32_t i0 = 0; i0 < n_l; i0 += 64) {
+            uint32_t i = i0 + (uint32_t)lane;
+            bool fresh = false;
+            if (i < n_l) {
+                uint32_t bp = s_lbp[wave * LSEG + i], t = s_lt[wave * LSEG + i];
+                uint32_t slot = gm_table_insert(tb, bp, &fresh);
+                if (slot == GM_EMPTY) full = true;
+                else {
+                    atomicAdd(&tb.vals[slot], 1u);
+                    if (t < 32) atomicOr(&mlo[slot], 1u << t);
+                    else if (MASK64) atomicOr(&s_mhi[slot], 1u << (t - 32));
+                }
+            }
+            nfresh += (uint32_t)__popcll(__ballot(fresh));
+        }
+        if (lane == 0 && nfresh) atomicAdd(&s_nkeys, nfresh);
+        if (full) s_full = 1;
+    }
+    __syncthreads();
+    if (s_full || s_nkeys > GMB_TLIMIT) {            // hand this read x strand to the global-table kernel
+        if (tid == 0) {
+            b.rs_overflow[rs] = 1;
+            uint32_t j = atomicAdd(b.n_retry, 1u);
+            uint32_t need = 2 * E; uint32_t sz = 1024; while (sz < need && sz < 0x80000000u) sz <<= 1;
+            unsigned long long off = atomicAdd(&b.counters[GMK_HEAVY_SLOTS], (unsigned long long)sz);
+            b.retry_list[j] = rs; b.retry_off[j] = off;
+            atomicAdd(&b.counters[GMK_OVERFLOW_RS], 1ull);
+        }
+        return;
+    }
+    for (uint32_t q0 = (uint32_t)tid * 4; q0 < GMB_TSIZE; q0 += NT * 4) {       // emit: 4 slots per lane per trip
+        const uint4 k4 = *reinterpret_cast<const uint4*>(tb.keys + q0);
+        const uint4 v4 = *reinterpret_cast<const uint4*>(tb.vals + q0);
+        const uint32_t kk[4] = { k4.x, k4.y, k4.z, k4.w }, vv[4] = { v4.x, v4.y, v4.z, v4.w };
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            bool emit = kk[w] != GM_EMPTY && vv[w] >= (uint32_t)p.kmin;
+            uint32_t step = 0;
+            if (emit) {
+                if (p.nw) {
+                    unsigned long long m = (unsigned long long)mlo[q0 + w] | (MASK64 ? ((unsigned long long)s_mhi[q0 + w] << 32) : 0ull);
+                    for (int r = 1; r < p.kmin && m; ++r) m &= m - 1;
+                    step = m ? (uint32_t)(__ffsll((long long)m) - 1) : 0u;
+                } else step = vv[w] > 65535u ? 65535u : vv[w];
+            }
+            gm_emit<GmLdsTable>(b, emit, rs, kk[w], step, 4);
+        }
+    }
+    if (tid < 64) {                                  // b = 0: cumulative per-step counts
+        uint32_t run = s_cnt0[tid];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(run, off); if (lane >= off) run += t; }
+        uint32_t total = __shfl(run, 63);
+        unsigned long long reached = __ballot(run >= (uint32_t)p.kmin);
+        bool emit = tid == 0 && total >= (uint32_t)p.kmin;
+        uint32_t step = p.nw ? (uint32_t)(__ffsll((long long)reached) - 1) : (total > 65535u ? 65535u : total);
+        gm_emit<GmLdsTable>(b, emit, rs, 0u, step, 4);
+    }
+}
+
 // retry path: one workgroup per overflowed read x strand, exact vote table in HBM (pre-set to EMPTY/0 by the host)
 struct GmGlobalTable {
     uint32_t* keys; uint32_t* vals; uint32_t mask; int bits;
@@ -1563,6 +1775,14 @@ int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, in
     if (dense && b.max_seeds <= 64) {
         static const int nt = [] { const char* e = getenv("GM_VOTE_NT"); int v = e ? atoi(e) : 128; return v == 64 || v == 256 ? v : 128; }();
         const bool m64 = b.max_seeds > 32;
+        static const bool steps_form = [] { const char* e = getenv("GM_VOTE_KERNEL"); return !(e && !strcmp(e, "block")); }();
+        if (steps_form) {
+#define GM_LAUNCH_VS(M, N) hipLaunchKernelGGL((k_vote_steps<M, N>), dim3(2 * b.n), dim3(N), 0, S_(stream), ix, p, b, use_full_sa)
+            if (nt == 64) { if (m64) GM_LAUNCH_VS(true, 64); else GM_LAUNCH_VS(false, 64); }
+            else { if (m64) GM_LAUNCH_VS(true, 128); else GM_LAUNCH_VS(false, 128); }
+#undef GM_LAUNCH_VS
+            return (int)hipGetLastError();
+        }
 #define GM_LAUNCH_VB(M, N) hipLaunchKernelGGL((k_vote_block<M, N>), dim3(2 * b.n), dim3(N), 0, S_(stream), ix, p, b, use_full_sa)
         if (nt == 64) { if (m64) GM_LAUNCH_VB(true, 64); else GM_LAUNCH_VB(false, 64); }
         else if (nt == 256) { if (m64) GM_LAUNCH_VB(true, 256); else GM_LAUNCH_VB(false, 256); }

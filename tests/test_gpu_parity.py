@@ -311,3 +311,18 @@ def test_cli_sam_identical_to_oracle(name, args, kw, tmp_path, oracle, oix, syn_
     assert set(sa) == set(sb) or max(abs(sa.get(k, 0) - sb.get(k, 0)) for k in set(sa) | set(sb)) < 2e-3
     for k in sb:
         assert abs(sa.get(k, 0.0) - sb[k]) <= 1e-4 * max(1.0, abs(sb[k])) + 2e-5, k
+
+
+def test_coverage_device_view_for_rccl(ix_full):
+    """bench.py all-reduces the HBM-resident coverage track in place through a zero-copy torch view"""
+    import torch
+    from gnumap_amd import dist as gd
+    ix_full.coverage_reset(8)
+    t = gd.DeviceTrack(ix_full.coverage_device_ptr(), ix_full.coverage_bins()).tensor(torch.device("cuda", 0))
+    assert t.dtype == torch.float32 and t.numel() == ix_full.coverage_bins() and float(t.abs().sum()) == 0.0
+    t[5] = 2.5; t[-1] = 1.0
+    gd.allreduce_coverage(t)            # world size 1: identity
+    torch.cuda.synchronize()
+    host = ix_full.coverage_download()
+    assert host[5] == 2.5 and host[-1] == 1.0 and host.sum() == 3.5
+    ix_full.coverage_reset(8)
