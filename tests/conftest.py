@@ -4,6 +4,11 @@ import sys
 
 import pytest
 
+try:                                    # torch bundles its own HIP runtime: when a test uses both torch.cuda and libgnumap_hip
+    import torch  # noqa: F401          # in one process, torch has to be loaded first (bench.py does the same)
+except Exception:                       # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
