@@ -831,57 +831,29 @@ __global__ void __launch_bounds__(NT) k_vote_block(GmDevIndex ix, GmDevParams p,
     uint32_t bpv[GMB_U], ttv[GMB_U];
 
     auto load_round = [&](uint32_t base) {           // located position (as window start) of up to GMB_U entries per lane
-        uint32_t aa[GMB_U], sp[GMB_U];               // SA index (or coords index) and read offset of each entry
+        uint32_t ee[GMB_U];
 #pragma unroll
         for (int u = 0; u < GMB_U; ++u) {
-            const uint32_t e = base + (uint32_t)u * (uint32_t)NT + (uint32_t)tid;
+            uint32_t e = base + (uint32_t)u * (uint32_t)NT + (uint32_t)tid;
+            ee[u] = e;
             uint32_t t = 0xFFFFFFFFu;
-            aa[u] = 0; sp[u] = 0;
-            // the 64 consecutive entries of this wave start in seed t0 (wave-uniform, kept in scalar registers); when they
-            // span at most four seeds the per-entry seed is three compares against uniform bounds - no per-lane table walks
-            const uint32_t e0 = __builtin_amdgcn_readfirstlane(e);
-            bool quick = false;
-            if (base == 0 && e0 < E) {
-                const uint32_t t0 = __builtin_amdgcn_readfirstlane(s_chunk[e0 >> 5]);
-                uint32_t tt0 = t0;
-                while (tt0 + 1 < ns && __builtin_amdgcn_readfirstlane(s_pre[tt0 + 1]) <= e0) ++tt0;       // uniform
-                const uint32_t p1 = tt0 + 1 <= ns ? __builtin_amdgcn_readfirstlane(s_pre[tt0 + 1 <= ns ? tt0 + 1 : ns]) : E;
-                const uint32_t p2 = __builtin_amdgcn_readfirstlane(s_pre[tt0 + 2 <= ns ? tt0 + 2 : ns]);
-                const uint32_t p3 = __builtin_amdgcn_readfirstlane(s_pre[tt0 + 3 <= ns ? tt0 + 3 : ns]);
-                const uint32_t p4 = __builtin_amdgcn_readfirstlane(s_pre[tt0 + 4 <= ns ? tt0 + 4 : ns]);
-                quick = p4 >= e0 + 64 || tt0 + 4 >= ns;
-                if (quick) {
-                    const uint32_t i1 = tt0 + 1 < ns ? tt0 + 1 : tt0, i2 = tt0 + 2 < ns ? tt0 + 2 : tt0, i3 = tt0 + 3 < ns ? tt0 + 3 : tt0;
-                    const uint32_t q0 = __builtin_amdgcn_readfirstlane(s_pre[tt0]);
-                    const uint32_t k0 = __builtin_amdgcn_readfirstlane(s_k[tt0]), k1 = __builtin_amdgcn_readfirstlane(s_k[i1]);
-                    const uint32_t k2 = __builtin_amdgcn_readfirstlane(s_k[i2]), k3 = __builtin_amdgcn_readfirstlane(s_k[i3]);
-                    const uint32_t o0 = __builtin_amdgcn_readfirstlane(s_pos[tt0]), o1 = __builtin_amdgcn_readfirstlane(s_pos[i1]);
-                    const uint32_t o2 = __builtin_amdgcn_readfirstlane(s_pos[i2]), o3 = __builtin_amdgcn_readfirstlane(s_pos[i3]);
-                    if (e < E) {
-                        const uint32_t sel = (e >= p1 ? 1u : 0u) + (e >= p2 ? 1u : 0u) + (e >= p3 ? 1u : 0u);
-                        t = tt0 + sel;
-                        const uint32_t pb = sel == 0 ? q0 : sel == 1 ? p1 : sel == 2 ? p2 : p3;
-                        aa[u] = (sel == 0 ? k0 : sel == 1 ? k1 : sel == 2 ? k2 : k3) + (e - pb);
-                        sp[u] = sel == 0 ? o0 : sel == 1 ? o1 : sel == 2 ? o2 : o3;
-                    }
-                }
-            }
-            if (!quick && e < E) {
-                uint32_t lo = 0, hi = ns; while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (s_pre[mid] <= e) lo = mid; else hi = mid; }
-                t = lo;
-                aa[u] = s_k[t] + (e - s_pre[t]); sp[u] = s_pos[t];
+            if (e < E) {
+                if (base == 0) { t = s_chunk[e >> 5]; while (t + 1 < ns && s_pre[t + 1] <= e) ++t; }
+                else { uint32_t lo = 0, hi = ns; while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (s_pre[mid] <= e) lo = mid; else hi = mid; } t = lo; }
             }
             ttv[u] = t;
-            if (!use_full_sa && t != 0xFFFFFFFFu) aa[u] = e;          // sampled mode: coords[] is already in flat hit order
         }
         uint32_t cc[GMB_U];
 #pragma unroll
         for (int u = 0; u < GMB_U; ++u) {            // all loads in flight together
             cc[u] = 0;
-            if (ttv[u] != 0xFFFFFFFFu) cc[u] = use_full_sa ? ix.full_sa[aa[u]] : b.coords[coff0 + aa[u]];
+            if (ttv[u] != 0xFFFFFFFFu) cc[u] = use_full_sa ? ix.full_sa[s_k[ttv[u]] + (ee[u] - s_pre[ttv[u]])] : b.coords[coff0 + ee[u]];
         }
 #pragma unroll
-        for (int u = 0; u < GMB_U; ++u) bpv[u] = (cc[u] <= sp[u]) ? 0u : cc[u] - sp[u];                       // :267
+        for (int u = 0; u < GMB_U; ++u) {
+            uint32_t sp = ttv[u] != 0xFFFFFFFFu ? s_pos[ttv[u]] : 0u;
+            bpv[u] = (cc[u] <= sp) ? 0u : cc[u] - sp;                       // :267
+        }
     };
     if (p.dbg & 1) {                                 // timing experiment: loads only
         uint32_t acc = 0;
