@@ -87,6 +87,12 @@ struct gm_batch {
     unsigned long long counters_host[GMK_N] = { 0 };
     GmDevBatch dev{};
     std::vector<uint16_t> len_host;
+    // sub-batch pipeline (gm_map_batch_device on large batches): streams + per-stream retry tables + host counter sums
+    static const int NS = 3;
+    hipStream_t sub_streams[NS] = { nullptr, nullptr, nullptr };
+    hipEvent_t sub_ready = nullptr;
+    DevBuf sub_gk[NS], sub_gv[NS], sub_counters, sub_small, sub_shards;
+    bool counters_on_host = false;
     // HIP-event profiling of the kernels of gm_map_batch_device
     bool profiling = false;
     struct Ev { int which; hipEvent_t a, b; };
@@ -368,6 +374,9 @@ extern "C" void gm_batch_destroy(gm_batch* b) {
                       &b->cands, &b->hit_count, &b->hit_begin, &b->hit_cursor, &b->raw_hits, &b->counters, &b->small, &b->shards, &b->tb_items, &b->tb_ops,
                       &b->tb_len, &b->dep_pos, &b->dep_span, &b->dep_w };
     for (DevBuf* d : all) d->release();
+    for (int i = 0; i < gm_batch::NS; ++i) { if (b->sub_streams[i]) (void)hipStreamDestroy(b->sub_streams[i]); b->sub_gk[i].release(); b->sub_gv[i].release(); }
+    if (b->sub_ready) (void)hipEventDestroy(b->sub_ready);
+    b->sub_counters.release(); b->sub_small.release(); b->sub_shards.release();
     for (auto& ev : b->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (auto ev : b->pool) (void)hipEventDestroy(ev);
     delete b;
@@ -391,7 +400,7 @@ static int ensure_batch_buffers(gm_batch* b, const gm_params* p) {
 
 static void fill_dev_batch(gm_batch* b) {
     GmDevBatch& d = b->dev;
-    d.n = b->n; d.stride = b->stride; d.max_seeds = b->max_seeds; d.illumina_until = b->illumina_until;
+    d.n = b->n; d.stride = b->stride; d.max_seeds = b->max_seeds; d.illumina_until = b->illumina_until; d.read_base = 0;
     d.bases = b->bases.as<uint8_t>(); d.quals = b->quals.as<uint8_t>(); d.len = b->len.as<uint16_t>();
     d.status = b->status.as<int8_t>(); d.self_score = b->self_score.as<float>(); d.min_score = b->min_score.as<double>();
     d.top_score = b->top_score.as<float>(); d.seeds = b->seeds.as<GmSeed>(); d.n_seeds = b->n_seeds.as<uint16_t>();
@@ -440,6 +449,109 @@ extern "C" int gm_batch_upload(gm_batch* b, const gm_params* p, const gm_reads* 
     return GM_OK;
 }
 
+// Large batches in full-SA mode: the batch is cut into sub-batches that go through prep -> seed -> vote -> NW on NS
+// streams, so that the LDS-bound vote kernel of one sub-batch runs beside the seed / NW kernels of its neighbours.
+// Returns 1 when a candidate shard overflowed (the caller then takes the single-pass path, which can grow the list).
+static int map_pipelined(gm_index* ix, const gm_params* p, const GmDevParams& dp, gm_batch* b, hipStream_t st, int dense, uint32_t sub_n) {
+    const uint32_t n = b->n;
+    const uint32_t nsb = (n + sub_n - 1) / sub_n;
+    for (int i = 0; i < gm_batch::NS; ++i)
+        if (!b->sub_streams[i]) HIPCHK(hipStreamCreateWithFlags(&b->sub_streams[i], hipStreamNonBlocking));
+    if (!b->sub_ready) HIPCHK(hipEventCreateWithFlags(&b->sub_ready, hipEventDisableTiming));
+    const size_t shard_bytes = (size_t)GM_NSHARD * GM_SHARD_STRIDE * 4;
+    if (b->sub_counters.ensure((size_t)nsb * GMK_N * 8) || b->sub_small.ensure((size_t)nsb * 64) || b->sub_shards.ensure((size_t)nsb * shard_bytes)) return GM_E_NOMEM;
+    fill_dev_batch(b);
+    const uint32_t region = (b->cand_cap / nsb) / GM_NSHARD;          // per sub-batch, per shard
+    if (region < 16) return 1;
+    HIPCHK(hipEventRecord(b->sub_ready, st));                          // the upload / earlier work on the caller's stream
+    std::vector<GmDevBatch> view(nsb);
+    std::vector<uint32_t> ncand(nsb, 0);
+    std::vector<uint32_t> shard_host((size_t)GM_NSHARD * GM_SHARD_STRIDE);
+    bool overflow = false;
+    auto make_view = [&](uint32_t i) {
+        GmDevBatch v = b->dev;
+        const uint32_t lo = i * sub_n, cnt = std::min(sub_n, n - lo);
+        v.n = cnt; v.read_base = lo;
+        v.illumina_until = b->illumina_until > lo ? std::min(b->illumina_until - lo, cnt) : 0;
+        v.bases += (size_t)lo * b->stride; v.quals += (size_t)lo * b->stride; v.len += lo;
+        v.status += lo; v.self_score += lo; v.min_score += lo; v.top_score += lo;
+        v.seeds += (size_t)2 * lo * b->max_seeds; v.n_seeds += 2 * (size_t)lo; v.n_entries += 2 * (size_t)lo;
+        v.rs_overflow += 2 * (size_t)lo; v.retry_list += 2 * (size_t)lo; v.retry_off += 2 * (size_t)lo;
+        v.cands += (size_t)i * region * GM_NSHARD; v.cand_cap = region * GM_NSHARD; v.cand_region = region;
+        v.shard_cnt = b->sub_shards.as<uint32_t>() + (size_t)i * GM_NSHARD * GM_SHARD_STRIDE;
+        v.hit_count += lo; v.hit_begin += lo; v.hit_cursor += lo;
+        v.counters = b->sub_counters.as<unsigned long long>() + (size_t)i * GMK_N;
+        v.n_retry = b->sub_small.as<uint32_t>() + (size_t)i * 16 + 1;
+        return v;
+    };
+    auto finish = [&](uint32_t i) -> int {                            // vote(i) is done: size check, retry, then NW
+        const int s = (int)(i % gm_batch::NS);
+        hipStream_t ss = b->sub_streams[s];
+        uint32_t small[2]; unsigned long long ctr[GMK_N];
+        HIPCHK(hipMemcpyAsync(small, b->sub_small.as<uint32_t>() + (size_t)i * 16, 8, hipMemcpyDeviceToHost, ss));
+        HIPCHK(hipMemcpyAsync(ctr, view[i].counters, sizeof ctr, hipMemcpyDeviceToHost, ss));
+        HIPCHK(hipMemcpyAsync(shard_host.data(), view[i].shard_cnt, shard_bytes, hipMemcpyDeviceToHost, ss));
+        HIPCHK(hipStreamSynchronize(ss));
+        if (ctr[GMK_BAD_QUAL]) { gm_set_error("Invalid Fastq Character? (negative base probability)"); return GM_E_BAD_QUAL; }
+        auto tally = [&](uint64_t& total, uint32_t& mx) { total = 0; mx = 0; for (int q = 0; q < GM_NSHARD; ++q) { uint32_t c = shard_host[(size_t)q * GM_SHARD_STRIDE]; total += c; mx = std::max(mx, c); } };
+        uint64_t total; uint32_t mx;
+        tally(total, mx);
+        if (small[1] && mx <= region) {
+            size_t slots = (size_t)ctr[GMK_HEAVY_SLOTS];
+            if (b->sub_gk[s].ensure(slots * 4) || b->sub_gv[s].ensure(slots * 4)) return GM_E_NOMEM;
+            view[i].gtab_keys = b->sub_gk[s].as<uint32_t>(); view[i].gtab_vals = b->sub_gv[s].as<uint32_t>();
+            HIPCHK(hipMemsetAsync(b->sub_gk[s].p, 0xFF, slots * 4, ss));
+            HIPCHK(hipMemsetAsync(b->sub_gv[s].p, 0, slots * 4, ss));
+            { KTimer t(b, GM_K_VOTE_RETRY, ss); KCHK(gmk_vote_retry(ix->dev, dp, view[i], 1, small[1], ss)); }
+            HIPCHK(hipMemcpyAsync(shard_host.data(), view[i].shard_cnt, shard_bytes, hipMemcpyDeviceToHost, ss));
+            HIPCHK(hipStreamSynchronize(ss));
+            tally(total, mx);
+        }
+        if (mx > region) { overflow = true; return GM_OK; }
+        ncand[i] = (uint32_t)total;
+        { KTimer t(b, GM_K_NW, ss); KCHK(gmk_nw(ix->dev, dp, view[i], ss)); }
+        return GM_OK;
+    };
+    uint32_t next_finish = 0;
+    for (uint32_t i = 0; i < nsb && !overflow; ++i) {
+        view[i] = make_view(i);
+        hipStream_t ss = b->sub_streams[i % gm_batch::NS];
+        if (i < (uint32_t)gm_batch::NS) HIPCHK(hipStreamWaitEvent(ss, b->sub_ready, 0));
+        HIPCHK(hipMemsetAsync(view[i].counters, 0, GMK_N * 8, ss));
+        HIPCHK(hipMemsetAsync(b->sub_small.as<uint32_t>() + (size_t)i * 16, 0, 64, ss));
+        HIPCHK(hipMemsetAsync(view[i].shard_cnt, 0, shard_bytes, ss));
+        HIPCHK(hipMemsetAsync(view[i].rs_overflow, 0, 2 * (size_t)view[i].n, ss));
+        { KTimer t(b, GM_K_PREP, ss); KCHK(gmk_prep(ix->dev, dp, view[i], ss)); }
+        { KTimer t(b, GM_K_SEED, ss); KCHK(gmk_seed(ix->dev, dp, view[i], ss)); }
+        { KTimer t(b, GM_K_VOTE, ss); KCHK(gmk_vote(ix->dev, dp, view[i], 1, dense, ss)); }
+        if (i + 1 >= (uint32_t)gm_batch::NS) { int rc = finish(next_finish++); if (rc) return rc; }
+    }
+    while (next_finish < nsb && !overflow) { int rc = finish(next_finish++); if (rc) return rc; }
+    for (int s = 0; s < gm_batch::NS; ++s) HIPCHK(hipStreamSynchronize(b->sub_streams[s]));
+    if (overflow) return 1;
+    // counters of all sub-batches, summed on the host
+    std::vector<unsigned long long> all((size_t)nsb * GMK_N);
+    HIPCHK(hipMemcpy(all.data(), b->sub_counters.p, all.size() * 8, hipMemcpyDeviceToHost));
+    memset(b->counters_host, 0, sizeof b->counters_host);
+    for (uint32_t i = 0; i < nsb; ++i) for (int q = 0; q < GMK_N; ++q) b->counters_host[q] += all[(size_t)i * GMK_N + q];
+    b->counters_on_host = true;
+    uint64_t total_c = 0;
+    for (uint32_t i = 0; i < nsb; ++i) total_c += ncand[i];
+    b->n_cands = (uint32_t)std::min<uint64_t>(total_c, 0xFFFFFFFFull);
+    if (b->raw_cap < total_c + 16ull) b->raw_cap = total_c + 16ull;
+    if (b->raw_hits.ensure(b->raw_cap * sizeof(GmRawHit))) return GM_E_NOMEM;
+    fill_dev_batch(b);
+    { KTimer t(b, GM_K_COMPACT, st); KCHK(gmk_scan_hits(b->dev, st)); }
+    for (uint32_t i = 0; i < nsb; ++i) {
+        view[i].raw_hits = b->dev.raw_hits; view[i].raw_cap = b->dev.raw_cap;
+        uint32_t grid = std::max<uint32_t>(64, std::min<uint32_t>(2048, (ncand[i] + 255) / 256));
+        KTimer t(b, GM_K_COMPACT, st);
+        KCHK(gmk_scatter(view[i], grid, st));
+    }
+    b->mapped = true;
+    return GM_OK;
+}
+
 extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b, void* stream) {
     if (!ix || !p || !b || !p->finalized || b->ix != ix) return GM_E_ARG;
     HIPCHK(hipSetDevice(ix->device));
@@ -458,6 +570,15 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         if (p->max_kmer_hits > 0) per_seed = std::min(per_seed, (double)p->max_kmer_hits);
         dense = per_seed >= 8.0;
         if (const char* ev = getenv("GM_VOTE")) dense = !strcmp(ev, "block") ? 1 : !strcmp(ev, "wave") ? 0 : dense;
+    }
+    b->counters_on_host = false;
+    {   // sub-batch pipeline over several streams for large full-SA batches (GM_PIPELINE=0 disables, =<n> sets the sub-batch size)
+        uint32_t sub_n = 262144;
+        if (const char* ev = getenv("GM_PIPELINE")) sub_n = (uint32_t)atoi(ev);
+        if (use_full && sub_n >= 4096 && b->n >= 3 * (uint64_t)sub_n) {
+            int prc = map_pipelined(ix, p, dp, b, st, dense, sub_n);
+            if (prc <= 0) return prc;                    // done, or a real error
+        }
     }
     fill_dev_batch(b);
     HIPCHK(hipMemsetAsync(b->counters.p, 0, GMK_N * 8, st));
@@ -531,7 +652,8 @@ extern "C" int gm_batch_counters(gm_batch* b, gm_counters* o) {
     if (!b || !o) return GM_E_ARG;
     HIPCHK(hipSetDevice(b->ix->device));
     unsigned long long c[GMK_N];
-    HIPCHK(hipMemcpy(c, b->counters.p, sizeof c, hipMemcpyDeviceToHost));
+    if (b->counters_on_host) memcpy(c, b->counters_host, sizeof c);
+    else HIPCHK(hipMemcpy(c, b->counters.p, sizeof c, hipMemcpyDeviceToHost));
     memset(o, 0, sizeof *o);
     o->reads = b->n; o->kmers_searched = c[GMK_KMERS]; o->occ_calls = c[GMK_OCC]; o->occ_blocks = c[GMK_OCC_BLOCKS];
     o->seeds_used = c[GMK_SEEDS]; o->sa_hits = c[GMK_SA_HITS];

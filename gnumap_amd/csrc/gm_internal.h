@@ -64,6 +64,7 @@ enum {
 
 struct GmDevBatch {
     uint32_t n, stride, max_seeds, illumina_until;
+    uint32_t read_base;             // index of read 0 of this (sub-)batch in the caller's batch (raw hits carry absolute indices)
     const uint8_t* bases;
     const uint8_t* quals;
     const uint16_t* len;
@@ -107,6 +108,8 @@ int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, in
 int gmk_vote_retry(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, uint32_t n_retry, void* stream);
 int gmk_nw(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream);
 int gmk_compact(const GmDevBatch& b, void* stream);
+int gmk_scan_hits(const GmDevBatch& b, void* stream);
+int gmk_scatter(const GmDevBatch& b, uint32_t grid, void* stream);
 int gmk_sa_interval(const GmDevIndex& ix, const uint8_t* kmers, uint32_t n, uint32_t m, uint32_t* start, uint32_t* end, void* stream);
 int gmk_locate(const GmDevIndex& ix, const uint32_t* ranks, uint32_t n, int use_full_sa, uint32_t* out, void* stream);
 int gmk_traceback(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, const GmCand* items, uint32_t n,

@@ -1561,7 +1561,7 @@ __global__ void __launch_bounds__(256) k_scatter_hits(GmDevBatch b) {
         uint64_t slot = b.hit_begin[r] + atomicAdd(&b.hit_cursor[r], 1u);
         if (slot < b.raw_cap) {
             GmRawHit h;
-            h.read = r; h.pos = c.b; h.score = c.score; h.step = c.step; h.strand = (uint8_t)(c.rs & 1); h.pad = 0;
+            h.read = b.read_base + r; h.pos = c.b; h.score = c.score; h.step = c.step; h.strand = (uint8_t)(c.rs & 1); h.pad = 0;
             b.raw_hits[slot] = h;
         }
     }
@@ -1820,12 +1820,21 @@ int gmk_nw(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void
     return (int)hipGetLastError();
 }
 
-int gmk_compact(const GmDevBatch& b, void* stream) {
+int gmk_scan_hits(const GmDevBatch& b, void* stream) {
     if (b.n == 0) return 0;
-    int e = scan_u32(b.hit_count, b.n, b.hit_begin, reinterpret_cast<unsigned long long*>(b.retry_off), stream);
-    if (e) return e;
-    hipLaunchKernelGGL(k_scatter_hits, dim3(2048), dim3(256), 0, S_(stream), b);
+    return scan_u32(b.hit_count, b.n, b.hit_begin, reinterpret_cast<unsigned long long*>(b.retry_off), stream);
+}
+
+int gmk_scatter(const GmDevBatch& b, uint32_t grid, void* stream) {
+    if (b.n == 0) return 0;
+    hipLaunchKernelGGL(k_scatter_hits, dim3(grid), dim3(256), 0, S_(stream), b);
     return (int)hipGetLastError();
+}
+
+int gmk_compact(const GmDevBatch& b, void* stream) {
+    int e = gmk_scan_hits(b, stream);
+    if (e) return e;
+    return gmk_scatter(b, 2048, stream);
 }
 
 int gmk_sa_interval(const GmDevIndex& ix, const uint8_t* kmers, uint32_t n, uint32_t m, uint32_t* start, uint32_t* end, void* stream) {
