@@ -572,8 +572,10 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         if (const char* ev = getenv("GM_VOTE")) dense = !strcmp(ev, "block") ? 1 : !strcmp(ev, "wave") ? 0 : dense;
     }
     b->counters_on_host = false;
-    {   // sub-batch pipeline over several streams for large full-SA batches (GM_PIPELINE=0 disables, =<n> sets the sub-batch size)
-        uint32_t sub_n = 262144;
+    {   // optional sub-batch pipeline over several streams for large full-SA batches (GM_PIPELINE=<sub-batch size>).  Measured
+        // +4 % at configs[1]: three vote kernels end up sharing the LDS rather than hiding seed / NW work, and per-kernel
+        // timings stop being attributable, so it is off by default.
+        uint32_t sub_n = 0;
         if (const char* ev = getenv("GM_PIPELINE")) sub_n = (uint32_t)atoi(ev);
         if (use_full && sub_n >= 4096 && b->n >= 3 * (uint64_t)sub_n) {
             int prc = map_pipelined(ix, p, dp, b, st, dense, sub_n);

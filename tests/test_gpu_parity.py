@@ -326,3 +326,29 @@ def test_coverage_device_view_for_rccl(ix_full):
     host = ix_full.coverage_download()
     assert host[5] == 2.5 and host[-1] == 1.0 and host.sum() == 3.5
     ix_full.coverage_reset(8)
+
+
+def test_pipelined_sub_batches_equal_single_pass(ix_full, syn_reads, packed, monkeypatch):
+    """GM_PIPELINE=<n>: sub-batches over three streams must give the same raw hits as the single pass"""
+    B, Q, Ln = packed
+    p = g.Params()
+    reps = 40                                   # 551 x 40 reads so that several sub-batches of 4096 exist
+    Bb = np.tile(B, (reps, 1)); Qb = np.tile(Q, (reps, 1)); Lb = np.tile(Ln, reps)
+    out = []
+    for env in (None, "4096"):
+        if env is None:
+            monkeypatch.delenv("GM_PIPELINE", raising=False)
+        else:
+            monkeypatch.setenv("GM_PIPELINE", env)
+        batch = g.Batch(ix_full, len(Lb), Bb.shape[1])
+        batch.upload(p, Bb, Qb, Lb)
+        batch.map_device(p)
+        hits, status, self_score, top = batch.raw_hits()
+        out.append((hits.tobytes(), status.tobytes(), self_score.tobytes(), top.tobytes(), batch.counters()))
+        batch.destroy()
+    assert out[0][:4] == out[1][:4]
+    assert out[0][4]["sa_hits"] == out[1][4]["sa_hits"] and out[0][4]["candidates"] == out[1][4]["candidates"]
+    n = len(syn_reads)
+    h = np.frombuffer(out[1][0], dtype=g.api.RAW_HIT_DTYPE)
+    first = h[h["read"] < n]; last = h[h["read"] >= n * (reps - 1)]
+    assert len(first) == len(last) and np.array_equal(first["pos"], last["pos"])
