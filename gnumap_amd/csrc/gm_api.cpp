@@ -77,7 +77,7 @@ struct gm_batch {
     uint32_t max_reads = 0, max_len = 0;
     uint32_t n = 0, stride = 0, max_seeds = 0, illumina_until = 0;
     DevBuf bases, quals, len, status, self_score, min_score, top_score, seeds, n_seeds, n_entries, entry_off, coords,
-        rs_overflow, retry_list, retry_off, gtab_keys, gtab_vals, cands, hit_count, hit_begin, hit_cursor, raw_hits, counters, small, shards,
+        rs_overflow, retry_list, retry_off, gtab_keys, gtab_vals, cands, hit_count, hit_begin, hit_cursor, raw_hits, counters, small, shards, big_list,
         tb_items, tb_ops, tb_len, dep_pos, dep_span, dep_w;
     uint32_t cand_cap = 0;
     uint64_t raw_cap = 0;
@@ -371,7 +371,7 @@ extern "C" void gm_batch_destroy(gm_batch* b) {
     (void)hipSetDevice(b->ix->device);
     DevBuf* all[] = { &b->bases, &b->quals, &b->len, &b->status, &b->self_score, &b->min_score, &b->top_score, &b->seeds, &b->n_seeds,
                       &b->n_entries, &b->entry_off, &b->coords, &b->rs_overflow, &b->retry_list, &b->retry_off, &b->gtab_keys, &b->gtab_vals,
-                      &b->cands, &b->hit_count, &b->hit_begin, &b->hit_cursor, &b->raw_hits, &b->counters, &b->small, &b->shards, &b->tb_items, &b->tb_ops,
+                      &b->cands, &b->hit_count, &b->hit_begin, &b->hit_cursor, &b->raw_hits, &b->counters, &b->small, &b->shards, &b->big_list, &b->tb_items, &b->tb_ops,
                       &b->tb_len, &b->dep_pos, &b->dep_span, &b->dep_w };
     for (DevBuf* d : all) d->release();
     for (int i = 0; i < gm_batch::NS; ++i) { if (b->sub_streams[i]) (void)hipStreamDestroy(b->sub_streams[i]); b->sub_gk[i].release(); b->sub_gv[i].release(); }
@@ -390,7 +390,7 @@ static int ensure_batch_buffers(gm_batch* b, const gm_params* p) {
     rc |= b->status.ensure(n); rc |= b->self_score.ensure(n * 4); rc |= b->min_score.ensure(n * 8); rc |= b->top_score.ensure(n * 4);
     rc |= b->seeds.ensure(n2 * b->max_seeds * sizeof(GmSeed)); rc |= b->n_seeds.ensure(n2 * 2); rc |= b->n_entries.ensure(n2 * 4);
     rc |= b->entry_off.ensure((n2 + 1) * 8); rc |= b->rs_overflow.ensure(n2); rc |= b->retry_list.ensure(n2 * 4);
-    rc |= b->retry_off.ensure((n2 + 1024) * 8);
+    rc |= b->retry_off.ensure((n2 + 1024) * 8); rc |= b->big_list.ensure(n2 * 4 + 64);
     rc |= b->hit_count.ensure(n * 4); rc |= b->hit_begin.ensure((n + 1) * 8); rc |= b->hit_cursor.ensure(n * 4);
     rc |= b->counters.ensure(GMK_N * 8); rc |= b->small.ensure(64); rc |= b->shards.ensure((size_t)GM_NSHARD * GM_SHARD_STRIDE * 4);
     if (b->cand_cap < 16 * n + 64 * GM_NSHARD) { b->cand_cap = (uint32_t)std::min<size_t>(16 * n + 64 * GM_NSHARD, 0x7FFFFFFF); }
@@ -412,7 +412,7 @@ static void fill_dev_batch(gm_batch* b) {
     d.hit_count = b->hit_count.as<uint32_t>(); d.hit_begin = b->hit_begin.as<uint64_t>(); d.hit_cursor = b->hit_cursor.as<uint32_t>();
     d.raw_hits = b->raw_hits.as<GmRawHit>(); d.raw_cap = b->raw_cap;
     d.counters = b->counters.as<unsigned long long>();
-    d.n_retry = b->small.as<uint32_t>() + 1;
+    d.n_retry = b->small.as<uint32_t>() + 1; d.n_big = b->small.as<uint32_t>() + 2; d.big_list = b->big_list.as<uint32_t>();
 }
 
 extern "C" int gm_batch_upload(gm_batch* b, const gm_params* p, const gm_reads* r, void* stream) {
@@ -481,7 +481,8 @@ static int map_pipelined(gm_index* ix, const gm_params* p, const GmDevParams& dp
         v.shard_cnt = b->sub_shards.as<uint32_t>() + (size_t)i * GM_NSHARD * GM_SHARD_STRIDE;
         v.hit_count += lo; v.hit_begin += lo; v.hit_cursor += lo;
         v.counters = b->sub_counters.as<unsigned long long>() + (size_t)i * GMK_N;
-        v.n_retry = b->sub_small.as<uint32_t>() + (size_t)i * 16 + 1;
+        v.n_retry = b->sub_small.as<uint32_t>() + (size_t)i * 16 + 1; v.n_big = b->sub_small.as<uint32_t>() + (size_t)i * 16 + 2;
+        v.big_list += 2 * (size_t)lo;
         return v;
     };
     auto finish = [&](uint32_t i) -> int {                            // vote(i) is done: size check, retry, then NW

@@ -92,6 +92,8 @@ struct GmDevBatch {
     GmRawHit* raw_hits;  uint64_t raw_cap;
     unsigned long long* counters;   // GMK_N
     uint32_t* n_retry;              // device counter
+    uint32_t* n_big;                // device counter: read x strands handed from k_vote_sparse to k_vote_fast_list
+    uint32_t* big_list;             // 2n
 };
 
 // Launchers (gm_kernels.hip).  All asynchronous on `stream`; they return a hipError_t cast to int.

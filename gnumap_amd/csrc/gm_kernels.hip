@@ -16,6 +16,7 @@
 // Arithmetic: ranks/coordinates are u32 (reference < 2^32-1 ranks); scores are fp32 with the reference's operation
 // order and NO fused multiply-add (built with -ffp-contract=off; mul/add also go through __fmul_rn/__fadd_rn).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include "gm_internal.h"
@@ -642,7 +643,7 @@ __global__ void __launch_bounds__(256) k_vote(GmDevIndex ix, GmDevParams p, GmDe
 // hits of all seeds are one flat list: every lane keeps GMV_U coalesced loads in flight instead of one.
 #define GMV_U 4
 template <bool MASK64>
-__global__ void __launch_bounds__(256) k_vote_fast(GmDevIndex ix, GmDevParams p, GmDevBatch b, int use_full_sa) {
+__device__ __forceinline__ void gm_vote_fast_rs(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, uint32_t rs) {
     __shared__ uint32_t s_A[4][GMV_FWORDS];          // pass 1: "seen" bits; afterwards reused as the low step masks
     __shared__ uint32_t s_B[4][GMV_FWORDS];          // "seen twice" bits
     __shared__ uint32_t s_keys[4][GMV_TSIZE];
@@ -651,7 +652,6 @@ __global__ void __launch_bounds__(256) k_vote_fast(GmDevIndex ix, GmDevParams p,
     __shared__ uint32_t s_pre[4][66];                // exclusive prefix of the seeds' hit counts
     __shared__ uint32_t s_cnt0[4][64];               // votes of b = 0 per seed step
     const int wave = threadIdx.x >> 6, lane = gm_lane();
-    const uint32_t rs = blockIdx.x * 4 + wave;
     if (rs >= 2 * b.n) return;                       // wave-uniform; no block barriers below
     uint32_t ns = b.n_seeds[rs];
     if (ns == 0) return;
@@ -770,6 +770,66 @@ __global__ void __launch_bounds__(256) k_vote_fast(GmDevIndex ix, GmDevParams p,
         uint32_t step = p.nw ? (uint32_t)(__ffsll((long long)reached) - 1) : (total > 65535u ? 65535u : total);
         gm_emit<GmLdsTable>(b, emit, rs, 0u, step, 4);
     }
+}
+
+template <bool MASK64>
+__global__ void __launch_bounds__(256) k_vote_fast(GmDevIndex ix, GmDevParams p, GmDevBatch b, int use_full_sa) {
+    gm_vote_fast_rs<MASK64>(ix, p, b, use_full_sa, blockIdx.x * 4 + (threadIdx.x >> 6));
+}
+
+// the same, driven by the list of read x strands that k_vote_sparse found too large for its sub-wave groups
+template <bool MASK64>
+__global__ void __launch_bounds__(256) k_vote_fast_list(GmDevIndex ix, GmDevParams p, GmDevBatch b, int use_full_sa) {
+    const uint32_t n_big = *b.n_big;
+    for (uint32_t it = blockIdx.x * 4 + (threadIdx.x >> 6); it < n_big; it += gridDim.x * 4)
+        gm_vote_fast_rs<MASK64>(ix, p, b, use_full_sa, b.big_list[it]);
+}
+
+// ---- sparse seeds (a handful of SA hits per read x strand): 16 lanes per read x strand, votes by all-pairs compare ----
+// Lane e of a group holds hit e of the flat (seed-major) hit list.  rank = equal positions earlier in the list, cnt = equal
+// positions in all; the hit with rank == kmin-1 is the vote that makes the position reach -k, and its seed is the NW step
+// (flat order is seed order; this also covers the clamped b = 0 with several hits of one seed).  No LDS tables at all.
+__global__ void __launch_bounds__(256) k_vote_sparse(GmDevIndex ix, GmDevParams p, GmDevBatch b, int use_full_sa) {
+    const int lane = gm_lane(), l = lane & 15;
+    const uint32_t rs = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (uint32_t)(lane >> 4);
+    const bool in = rs < 2 * b.n;
+    uint32_t ns = in ? b.n_seeds[rs] : 0;
+    if (p.nw && p.fast && ns > 1) ns = 1;
+    GmSeed mine; mine.k = 0; mine.l = 0; mine.pos = 0;
+    uint32_t cnt = 0;
+    if ((uint32_t)l < ns && ns <= 16) { mine = b.seeds[(size_t)rs * b.max_seeds + l]; cnt = mine.l - mine.k + 1; }
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) { uint32_t t = __shfl_up(incl, off, 16); if (l >= off) incl += t; }
+    const uint32_t E = __shfl(incl, 15, 16);
+    const bool big = ns > 16 || E > 16;              // group-uniform
+    if (big && l == 0) { uint32_t at = atomicAdd(b.n_big, 1u); b.big_list[at] = rs; }
+    // which seed does hit e = l belong to
+    uint32_t t = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { uint32_t iq = __shfl(incl, q, 16); if ((uint32_t)q < ns && iq <= (uint32_t)l) t = (uint32_t)q + 1; }
+    const bool valid = in && !big && (uint32_t)l < E;
+    const uint32_t tt = t < 16 ? t : 15;
+    const uint32_t kt = __shfl(mine.k, (int)tt, 16), pt = __shfl(mine.pos, (int)tt, 16);
+    const uint32_t pre_t = __shfl(incl - cnt, (int)tt, 16);
+    uint32_t bp = 0;
+    if (valid) {
+        uint32_t c = use_full_sa ? ix.full_sa[kt + ((uint32_t)l - pre_t)] : b.coords[b.entry_off[rs] + (uint32_t)l];
+        bp = (c <= pt) ? 0u : c - pt;                 // :267
+    }
+    uint32_t rank = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        uint32_t ob = __shfl(bp, q, 16);
+        int ov = __shfl((int)valid, q, 16);
+        bool eq = valid && ov && ob == bp;
+        total += eq ? 1u : 0u;
+        rank += (eq && q < l) ? 1u : 0u;
+    }
+    bool emit; uint32_t step;
+    if (p.nw) { emit = valid && total >= (uint32_t)p.kmin && rank == (uint32_t)p.kmin - 1; step = tt; }
+    else { emit = valid && total >= (uint32_t)p.kmin && rank == 0; step = total; }
+    gm_emit<GmLdsTable>(b, emit, rs, bp, step, 0);
 }
 
 // ---- order-free vote kernel, one WORKGROUP per read x strand (dense seeds: tens of SA hits per seed and more) ----
@@ -1788,6 +1848,15 @@ int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, in
         else if (nt == 256) { if (m64) GM_LAUNCH_VB(true, 256); else GM_LAUNCH_VB(false, 256); }
         else { if (m64) GM_LAUNCH_VB(true, 128); else GM_LAUNCH_VB(false, 128); }
 #undef GM_LAUNCH_VB
+        return (int)hipGetLastError();
+    }
+    // sparse seeds: sub-wave groups first; what does not fit 16 hits goes to the wave-per-read x strand kernel through a list
+    static const bool sparse_form = [] { const char* e = getenv("GM_VOTE_SPARSE"); return !(e && !strcmp(e, "0")); }();
+    if (sparse_form && b.max_seeds <= 64) {
+        hipLaunchKernelGGL(k_vote_sparse, dim3(cdiv(2ull * b.n, 16)), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(cdiv(2ull * b.n, 4), 256 * 20);
+        if (b.max_seeds <= 32) hipLaunchKernelGGL(k_vote_fast_list<false>, dim3(grid), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
+        else hipLaunchKernelGGL(k_vote_fast_list<true>, dim3(grid), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
         return (int)hipGetLastError();
     }
     // order-free fast path while the seed steps fit a 64-bit mask; the ordered kernel is the general form

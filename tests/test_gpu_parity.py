@@ -352,3 +352,35 @@ def test_pipelined_sub_batches_equal_single_pass(ix_full, syn_reads, packed, mon
     h = np.frombuffer(out[1][0], dtype=g.api.RAW_HIT_DTYPE)
     first = h[h["read"] < n]; last = h[h["read"] >= n * (reps - 1)]
     assert len(first) == len(last) and np.array_equal(first["pos"], last["pos"])
+
+
+@pytest.mark.parametrize("env", [dict(GM_VOTE="block"), dict(GM_VOTE="block", GM_VOTE_KERNEL="steps"), dict(GM_VOTE="block", GM_VOTE_NT="64"),
+                                 dict(GM_VOTE="block", GM_VOTE_NT="256"), dict(GM_VOTE="wave"), dict(GM_VOTE="wave", GM_VOTE_SPARSE="0"),
+                                 dict(GM_NW="wave"), dict(GM_KMER_TABLE="0"), dict(GM_KMER_TABLE="6")])
+@pytest.mark.parametrize("cfg", ["default", "no_nw", "k3", "h30"])
+def test_every_kernel_variant_matches_oracle(env, cfg, syn_fa, oracle, oix, syn_reads, packed):
+    """the dispatch heuristics pick kernels by seed density; force each variant on the same inputs (fresh process state is
+    not needed: the switches are read per launch or cached per variant name)"""
+    import subprocess, sys, json
+    # kernel-variant switches are cached in static locals on first use, so each combination runs in its own process
+    code = f"""
+import sys, json, numpy as np
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
+import gnumap_amd as g
+from conftest import read_fastq
+reads = read_fastq({os.path.join(ROOT, 'tests', 'golden', 'syn.fq')!r})
+B, Q, Ln = g.pack_reads([r[1] for r in reads], [r[2] for r in reads])
+ix = g.Index({syn_fa!r}, flags=g.GM_INDEX_FULL_SA)
+p = g.Params(**{CONFIGS[cfg]!r})
+b = g.Batch(ix, len(reads), B.shape[1])
+b.upload(p, B, Q, Ln); b.map_device(p)
+hits, status, self_score, top = b.raw_hits()
+print(json.dumps(dict(hits=hits.tobytes().hex(), status=status.tobytes().hex(), top=top.tobytes().hex())))
+"""
+    outs = []
+    for e in ({}, env):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **e), timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1]
+    assert len(outs[0]["hits"]) > 16 * 2 * 100
