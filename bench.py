@@ -244,8 +244,9 @@ def main():
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
-                if j.get("workload_key") == f"{key}_r{a.reads}_L{a.read_len}_m{a.mer}_{a.locate}" and j.get("kernel") == dom:
-                    traffic = j.get("hbm_bytes_per_launch")
+                # PMC passes are taken at 1 M reads per launch; traffic scales linearly with the reads of a launch
+                if j.get("workload_key") == f"{key}_L{a.read_len}_m{a.mer}_{a.locate}" and j.get("kernel") == dom:
+                    traffic = int(j["hbm_bytes_per_read"] * a.reads / max(1, per_kernel[dom]["launches"] // a.steps))
             except Exception:
                 traffic = None
         roof = None
@@ -254,7 +255,7 @@ def main():
             roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5),
                         traffic=traffic, avg_kernel_ms=round(per_kernel[dom]["ms"], 4), alg_bytes_per_launch=int(per_kernel[dom]["alg_bytes"]))
         cpu = None
-        if a.cpu_seconds > 0:
+        if a.cpu_seconds > 0 and world == 1:         # rank 0 at N = 1 only
             threads = a.cpu_threads or min(16, os.cpu_count() or 1)
             cpu = cpu_baseline(fa, B, Q, Ln, a.read_len, kw, a.cpu_seconds, threads)
         out = {
