@@ -850,13 +850,16 @@ __global__ void __launch_bounds__(256) k_vote_sparse(GmDevIndex ix, GmDevParams 
 #define GMB_TLIMIT (GMB_TSIZE * 3 / 4)
 #define GMB_LCAP 768            // compacted list entries per workgroup
 #define GMB_FSAT 200u           // a filter byte this high could have wrapped: hand the read x strand to the retry kernel
-template <bool MASK64, int NT>
+template <bool MASK64, int NT, int TB>
 __global__ void __launch_bounds__(NT) k_vote_block(GmDevIndex ix, GmDevParams p, GmDevBatch b, int use_full_sa) {
     constexpr int GMB_U = GMB_ENTRIES / NT;
     constexpr int NW = NT / 64;
     constexpr int LSEG = GMB_LCAP / NW;
+    constexpr int TS1 = 1 << TB;                     // exact table of the one-round path: keys | vals | low masks live in s_r0
+    constexpr uint32_t TLIM1 = TB >= 10 ? TS1 * 3 / 4 : TS1 * 7 / 8;
+    static_assert(3 * TS1 <= 2048 || TB == 10, "table must fit the filter region");
     __shared__ uint32_t s_r0[2048];                  // 8 KB: counting filter, then keys[1024] + vals[1024]  (round path: A,B,keys,vals x 512)
-    __shared__ uint32_t s_mlo[GMB_TSIZE];            // low step masks
+    __shared__ uint32_t s_mlo[TB >= 10 ? GMB_TSIZE : 1];              // low step masks (TB = 9: in s_r0 / in the unused list memory on the round path)
     __shared__ uint32_t s_mhi[MASK64 ? GMB_TSIZE : 1];
     __shared__ uint32_t s_lbp[GMB_LCAP];
     __shared__ uint8_t s_lt[GMB_LCAP];
@@ -965,11 +968,13 @@ __global__ void __launch_bounds__(NT) k_vote_block(GmDevIndex ix, GmDevParams p,
         for (int q = tid; q < 2048; q += NT) {
             uint32_t w = s_r0[q];
             if (filter && ((w & 255u) >= GMB_FSAT || ((w >> 8) & 255u) >= GMB_FSAT || ((w >> 16) & 255u) >= GMB_FSAT || (w >> 24) >= GMB_FSAT)) s_full = 1;
-            s_r0[q] = q < GMB_TSIZE ? GM_EMPTY : 0u;
+            s_r0[q] = q < TS1 ? GM_EMPTY : 0u;
         }
-        for (int q = tid; q < GMB_TSIZE; q += NT) { s_mlo[q] = 0; if (MASK64) s_mhi[q] = 0; }
+        if (TB >= 10) for (int q = tid; q < TS1; q += NT) s_mlo[q] = 0;
+        if (MASK64) for (int q = tid; q < TS1; q += NT) s_mhi[q] = 0;
         __syncthreads();
-        tb.keys = s_r0; tb.vals = s_r0 + GMB_TSIZE; tb.mask = GMB_TSIZE - 1; tb.bits = GMB_TBITS;
+        tb.keys = s_r0; tb.vals = s_r0 + TS1; tb.mask = TS1 - 1; tb.bits = TB;
+        mlo = TB >= 10 ? s_mlo : s_r0 + 2 * TS1;
         if (!(p.dbg & 4)) {
             const uint32_t n_l = s_lcnt[wave];
             uint32_t nfresh = 0; bool full = false;
@@ -982,7 +987,7 @@ __global__ void __launch_bounds__(NT) k_vote_block(GmDevIndex ix, GmDevParams p,
                     if (slot == GM_EMPTY) full = true;
                     else {
                         atomicAdd(&tb.vals[slot], 1u);
-                        if (t < 32) atomicOr(&s_mlo[slot], 1u << t);
+                        if (t < 32) atomicOr(&mlo[slot], 1u << t);
                         else if (MASK64) atomicOr(&s_mhi[slot], 1u << (t - 32));
                     }
                 }
@@ -992,13 +997,14 @@ __global__ void __launch_bounds__(NT) k_vote_block(GmDevIndex ix, GmDevParams p,
             if (full) s_full = 1;
         }
         __syncthreads();
-        failed = s_full || s_nkeys > GMB_TLIMIT;
+        failed = s_full || s_nkeys > TLIM1;
     } else {
         // ------------------------------------------------------------ rounds of GMB_ENTRIES hits, bit filter (as k_vote_fast)
         uint32_t* A = s_r0; uint32_t* B = s_r0 + 512;
         tb.keys = s_r0 + 1024; tb.vals = s_r0 + 1536; tb.mask = GMV_TSIZE - 1; tb.bits = GMV_TBITS;
+        mlo = TB >= 10 ? s_mlo : s_lbp;
         const bool filter = p.kmin >= 2;
-        for (int q = tid; q < GMV_TSIZE; q += NT) { tb.keys[q] = GM_EMPTY; s_mlo[q] = 0; if (MASK64) s_mhi[q] = 0; }
+        for (int q = tid; q < GMV_TSIZE; q += NT) { tb.keys[q] = GM_EMPTY; mlo[q] = 0; if (MASK64) s_mhi[q] = 0; }
         __syncthreads();
         if (filter)
             for (uint32_t base = 0; base < E; base += (uint32_t)NT * GMB_U) {
@@ -1028,7 +1034,7 @@ __global__ void __launch_bounds__(NT) k_vote_block(GmDevIndex ix, GmDevParams p,
                         else {
                             nfresh += fresh ? 1u : 0u;
                             atomicAdd(&tb.vals[slot], 1u);
-                            if (t < 32) atomicOr(&s_mlo[slot], 1u << t);
+                            if (t < 32) atomicOr(&mlo[slot], 1u << t);
                             else if (MASK64) atomicOr(&s_mhi[slot], 1u << (t - 32));
                         }
                     }
@@ -1548,14 +1554,20 @@ __global__ void __launch_bounds__(256) k_nw_lane(GmDevIndex ix, GmDevParams p, G
             };
 #pragma unroll
             for (int d = 0; d < 7; ++d) { int j = Li - 1 + d - 3; W[d] = (j >= 0 && j < Li) ? wcode(j) : 0u; }
-            uint2 bw = make_uint2(0, 0), qw = make_uint2(0, 0); int chunk = -1;
+            // the read streams through 8-byte words; the NEXT word is requested one chunk ahead so its latency hides under 8 rows
+            const int src0 = strand ? 0 : Li - 1, cstep = strand ? 1 : -1, nchunk = (Li + 7) >> 3;
+            int chunk = src0 >> 3;
+            uint2 bw = *reinterpret_cast<const uint2*>(rb + (chunk << 3)), qw = *reinterpret_cast<const uint2*>(rq + (chunk << 3));
+            uint2 bn = bw, qn = qw;
+            { int nc = chunk + cstep; if (nc >= 0 && nc < nchunk) { bn = *reinterpret_cast<const uint2*>(rb + (nc << 3)); qn = *reinterpret_cast<const uint2*>(rq + (nc << 3)); } }
             for (int i = Li - 1; i >= 0; --i) {
                 // PWM row i in strand orientation (reverse_comp_cpy SequenceOperations.h:149-161)
                 const int src = strand ? Li - 1 - i : i;
                 if ((src >> 3) != chunk) {
                     chunk = src >> 3;
-                    bw = *reinterpret_cast<const uint2*>(rb + (chunk << 3));
-                    qw = *reinterpret_cast<const uint2*>(rq + (chunk << 3));
+                    bw = bn; qw = qn;
+                    int nc = chunk + cstep;
+                    if (nc >= 0 && nc < nchunk) { bn = *reinterpret_cast<const uint2*>(rb + (nc << 3)); qn = *reinterpret_cast<const uint2*>(rq + (nc << 3)); }
                 }
                 const uint32_t sh = (uint32_t)(src & 3) << 3;
                 const uint32_t ch = (((src & 4) ? bw.y : bw.x) >> sh) & 255u;
@@ -1843,10 +1855,14 @@ int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, in
 #undef GM_LAUNCH_VS
             return (int)hipGetLastError();
         }
-#define GM_LAUNCH_VB(M, N) hipLaunchKernelGGL((k_vote_block<M, N>), dim3(2 * b.n), dim3(N), 0, S_(stream), ix, p, b, use_full_sa)
-        if (nt == 64) { if (m64) GM_LAUNCH_VB(true, 64); else GM_LAUNCH_VB(false, 64); }
-        else if (nt == 256) { if (m64) GM_LAUNCH_VB(true, 256); else GM_LAUNCH_VB(false, 256); }
-        else { if (m64) GM_LAUNCH_VB(true, 128); else GM_LAUNCH_VB(false, 128); }
+        // one-round exact table: 512 slots (13 KB of LDS per workgroup, 12 workgroups per CU) or 1024 (17 KB, 9 per CU)
+        static const int tb = [] { const char* e = getenv("GM_VOTE_TB"); int v = e ? atoi(e) : 9; return v == 10 ? 10 : 9; }();
+#define GM_LAUNCH_VB(M, N, T) hipLaunchKernelGGL((k_vote_block<M, N, T>), dim3(2 * b.n), dim3(N), 0, S_(stream), ix, p, b, use_full_sa)
+#define GM_LAUNCH_VB2(M, N) do { if (tb == 10) GM_LAUNCH_VB(M, N, 10); else GM_LAUNCH_VB(M, N, 9); } while (0)
+        if (nt == 64) { if (m64) GM_LAUNCH_VB2(true, 64); else GM_LAUNCH_VB2(false, 64); }
+        else if (nt == 256) { if (m64) GM_LAUNCH_VB2(true, 256); else GM_LAUNCH_VB2(false, 256); }
+        else { if (m64) GM_LAUNCH_VB2(true, 128); else GM_LAUNCH_VB2(false, 128); }
+#undef GM_LAUNCH_VB2
 #undef GM_LAUNCH_VB
         return (int)hipGetLastError();
     }

@@ -355,7 +355,7 @@ def test_pipelined_sub_batches_equal_single_pass(ix_full, syn_reads, packed, mon
 
 
 @pytest.mark.parametrize("env", [dict(GM_VOTE="block"), dict(GM_VOTE="block", GM_VOTE_KERNEL="steps"), dict(GM_VOTE="block", GM_VOTE_NT="64"),
-                                 dict(GM_VOTE="block", GM_VOTE_NT="256"), dict(GM_VOTE="wave"), dict(GM_VOTE="wave", GM_VOTE_SPARSE="0"),
+                                 dict(GM_VOTE="block", GM_VOTE_NT="256"), dict(GM_VOTE="block", GM_VOTE_TB="10"), dict(GM_VOTE="wave"), dict(GM_VOTE="wave", GM_VOTE_SPARSE="0"),
                                  dict(GM_NW="wave"), dict(GM_KMER_TABLE="0"), dict(GM_KMER_TABLE="6")])
 @pytest.mark.parametrize("cfg", ["default", "no_nw", "k3", "h30"])
 def test_every_kernel_variant_matches_oracle(env, cfg, syn_fa, oracle, oix, syn_reads, packed):
