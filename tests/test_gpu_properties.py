@@ -1,5 +1,5 @@
 """Size-independent properties of the hot path at a scale the oracle cannot check read by read (a 20 Mbp reference built
-on the box, 400 k reads through the dense-seed kernels): exact reads recover their origin with score == self score,
+on the box, 400 k reads through the dense-seed kernels): exact reads recover their origin with the self score (up to fp32 rounding),
 strand symmetry, determinism, batch-order independence, and agreement with the oracle on a random sample."""
 import os
 
@@ -75,8 +75,9 @@ def test_exact_reads_recover_their_origin(big):
     got = np.zeros(n, bool); got[h["read"][at_origin]] = True
     assert got.all()
     sc = np.full(n, -1.0, np.float32); sc[h["read"][at_origin]] = h["score"][at_origin]
-    np.testing.assert_array_equal(sc.view(np.uint32), self_score.view(np.uint32))
-    np.testing.assert_array_equal(top.view(np.uint32), self_score.view(np.uint32))
+    # the DP sums the same per-base terms in the opposite order of the self score: equal up to fp32 rounding, not bit-equal
+    np.testing.assert_allclose(sc, self_score, rtol=2e-6)
+    np.testing.assert_array_equal(top.view(np.uint32), sc.view(np.uint32))       # and nothing scores higher than the origin
     # determinism: a second pass gives the same bytes; a shuffled batch gives the same hits per read
     batch.map_device(p)
     hits2, status2, _, _ = batch.raw_hits()
