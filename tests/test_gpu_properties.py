@@ -110,7 +110,7 @@ def test_strand_symmetry(big):
     batch.upload(p, Brc, Qrc, Ln); batch.map_device(p)
     h2, s2, self2, _ = batch.raw_hits()
     np.testing.assert_array_equal(s1, s2)
-    np.testing.assert_array_equal(self1.view(np.uint32), self2.view(np.uint32))
+    np.testing.assert_allclose(self1, self2, rtol=2e-6)             # same terms, reverse summation order
     k1 = set(zip(h1["read"].tolist(), h1["pos"].tolist(), h1["strand"].tolist()))
     k2 = set(zip(h2["read"].tolist(), h2["pos"].tolist(), (1 - h2["strand"]).tolist()))
     # the DP runs in the other direction on the other strand, so a score a hair off the -a threshold may flip: allow a few
