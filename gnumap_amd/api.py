@@ -81,7 +81,8 @@ EXPORTS = ["gm_last_error", "gm_version", "gm_index_build", "gm_index_open", "gm
            "gm_batch_upload", "gm_map_batch_device", "gm_batch_counters", "gm_batch_set_profiling", "gm_batch_kernel_times", "gm_kernel_name",
            "gm_batch_raw_hits", "gm_map_batch", "gm_output_batch",
            "gm_dev_sa_interval", "gm_dev_locate", "gm_dev_nw_score", "gm_dev_traceback", "gm_coverage_reset", "gm_coverage_bins",
-           "gm_coverage_device_ptr", "gm_coverage_add", "gm_coverage_download", "gm_coverage_allreduce", "gm_coverage_write_sgr"]
+           "gm_coverage_device_ptr", "gm_coverage_add", "gm_coverage_download", "gm_coverage_allreduce", "gm_coverage_write_sgr", "gm_coverage_enable_nuc", "gm_coverage_nuc_device_ptr",
+           "gm_coverage_download_nuc", "gm_coverage_write_gmp"]
 
 
 def library_path():
@@ -131,6 +132,10 @@ def load_library():
     L.gm_coverage_download.argtypes = [C.c_void_p, C.c_void_p]
     L.gm_coverage_allreduce.argtypes = [C.POINTER(C.c_void_p), C.c_int]
     L.gm_coverage_write_sgr.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+    L.gm_coverage_enable_nuc.argtypes = [C.c_void_p]
+    L.gm_coverage_nuc_device_ptr.argtypes = [C.c_void_p]; L.gm_coverage_nuc_device_ptr.restype = C.c_void_p
+    L.gm_coverage_download_nuc.argtypes = [C.c_void_p, C.c_void_p]
+    L.gm_coverage_write_gmp.argtypes = [C.c_void_p, C.POINTER(gm_params), C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
     _LIB = L
     return L
 

@@ -61,7 +61,8 @@ struct gm_index {
     int device = -1;
     bool host_only = false;
     bool full_sa = false;
-    DevBuf d_bwt, d_sa, d_full, d_pac, d_contig, d_cov, d_ptab, d_planes;
+    DevBuf d_bwt, d_sa, d_full, d_pac, d_contig, d_cov, d_ptab, d_planes, d_nuc;
+    bool nuc_on = false;
     GmDevIndex dev{};
     uint64_t cov_bins = 0;
     uint32_t cov_bin_size = 0;
@@ -78,7 +79,7 @@ struct gm_batch {
     uint32_t n = 0, stride = 0, max_seeds = 0, illumina_until = 0;
     DevBuf bases, quals, len, status, self_score, min_score, top_score, seeds, n_seeds, n_entries, entry_off, coords,
         rs_overflow, retry_list, retry_off, gtab_keys, gtab_vals, cands, hit_count, hit_begin, hit_cursor, raw_hits, counters, small, shards, big_list,
-        tb_items, tb_ops, tb_len, dep_pos, dep_span, dep_w;
+        tb_items, tb_ops, tb_len, dep_pos, dep_span, dep_w, dep_codes, dep_coff;
     uint32_t cand_cap = 0;
     uint64_t raw_cap = 0;
     uint32_t n_cands = 0;
@@ -301,7 +302,7 @@ extern "C" void gm_index_close(gm_index* ix) {
     if (!ix->host_only && ix->device >= 0) {
         (void)hipSetDevice(ix->device);
         ix->d_bwt.release(); ix->d_sa.release(); ix->d_full.release(); ix->d_pac.release(); ix->d_contig.release();
-        ix->d_cov.release(); ix->d_ptab.release(); ix->d_planes.release();
+        ix->d_cov.release(); ix->d_ptab.release(); ix->d_planes.release(); ix->d_nuc.release();
         for (auto& kv : ix->kmer_tabs) kv.second.release();
     }
     delete ix;
@@ -372,7 +373,7 @@ extern "C" void gm_batch_destroy(gm_batch* b) {
     DevBuf* all[] = { &b->bases, &b->quals, &b->len, &b->status, &b->self_score, &b->min_score, &b->top_score, &b->seeds, &b->n_seeds,
                       &b->n_entries, &b->entry_off, &b->coords, &b->rs_overflow, &b->retry_list, &b->retry_off, &b->gtab_keys, &b->gtab_vals,
                       &b->cands, &b->hit_count, &b->hit_begin, &b->hit_cursor, &b->raw_hits, &b->counters, &b->small, &b->shards, &b->big_list, &b->tb_items, &b->tb_ops,
-                      &b->tb_len, &b->dep_pos, &b->dep_span, &b->dep_w };
+                      &b->tb_len, &b->dep_pos, &b->dep_span, &b->dep_w, &b->dep_codes, &b->dep_coff };
     for (DevBuf* d : all) d->release();
     for (int i = 0; i < gm_batch::NS; ++i) { if (b->sub_streams[i]) (void)hipStreamDestroy(b->sub_streams[i]); b->sub_gk[i].release(); b->sub_gv[i].release(); }
     if (b->sub_ready) (void)hipEventDestroy(b->sub_ready);
@@ -883,7 +884,54 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
     std::vector<gm_sam_rec> recs;
     std::string pool;
     std::vector<uint64_t> dpos; std::vector<uint32_t> dspan; std::vector<float> dw;
+    std::vector<uint8_t> dcodes; std::vector<uint64_t> dcoff;     // -b / -d: nucleotide of every deposited base
+    const bool nuc = p->mode != GM_MODE_NORMAL && ix->nuc_on;
+    std::vector<float> lut;
+    if (nuc) { lut.resize(1024); build_lut(lut.data()); }
+    std::string al, cons;
     uint32_t max_span = 0;
+    // gapped read string of a match (bin_seq.cpp:578-698 on the argmax consensus, ScoredSeq.h:57-103), as g_gen_CONVERSION codes
+    auto aligned_codes = [&](const gm_match& mm, uint64_t midx, bool same_strand, std::vector<uint8_t>& out) {
+        const uint32_t r = mm.read, L = b->len_host[r];
+        const uint8_t* rb = reads->bases + (size_t)r * reads->stride; const uint8_t* rq = reads->quals + (size_t)r * reads->stride;
+        const float* lt = lut.data() + ((r < b->illumina_until) ? 512 : 0);
+        cons.resize(L);
+        for (uint32_t i = 0; i < L; ++i) {
+            uint32_t src = mm.first_strand ? L - 1 - i : i;
+            float pp = lt[2 * rq[src]], qq = lt[2 * rq[src] + 1];
+            int code; switch (rb[src]) { case 'a': case 'A': code = 0; break; case 'c': case 'C': code = 1; break; case 'g': case 'G': code = 2; break;
+                                         case 't': case 'T': code = 3; break; default: code = 4; }
+            if (mm.first_strand && code < 4) code = 3 - code;
+            float c[4] = { qq, qq, qq, qq };
+            if (code < 4) c[code] = pp;
+            char ch;                                                   // ScoredSeq::max_char
+            if (c[0] == c[1] && c[0] == c[2] && c[0] == c[3]) ch = 'n';
+            else if (c[0] >= c[1]) { if (c[0] >= c[2]) ch = c[0] >= c[3] ? 'a' : 't'; else ch = c[2] >= c[3] ? 'g' : 't'; }
+            else { if (c[1] >= c[2]) ch = c[1] >= c[3] ? 'c' : 't'; else ch = c[2] >= c[3] ? 'g' : 't'; }
+            cons[i] = ch;
+        }
+        const uint8_t* op = &ops[midx * ops_stride];
+        const uint32_t n_op = ops_len[midx];
+        al.resize(n_op);
+        uint32_t rr = 0;
+        for (uint32_t k = 0; k < n_op; ++k) {
+            if (op[k] == 'M') { al[k] = rr < L ? cons[rr] : '\0'; ++rr; }
+            else if (op[k] == 'I') { al[k] = rr + 1 < L ? cons[rr + 1] : '\0'; ++rr; }     // consense[i], sic (bin_seq.cpp:607)
+            else al[k] = '-';
+        }
+        for (uint32_t k = 0; k < n_op; ++k) {
+            char ch;
+            if (same_strand) ch = al[k];
+            else {
+                switch (al[n_op - 1 - k]) { case 'a': ch = 't'; break; case 't': ch = 'a'; break; case 'c': ch = 'g'; break; case 'g': ch = 'c'; break;
+                                            case '-': ch = '-'; break; default: ch = 'n'; }
+            }
+            uint8_t cv;
+            switch (ch) { case 'a': cv = 0; break; case 'c': cv = 1; break; case 'g': cv = 2; break; case 't': cv = 3; break; case 'n': cv = 4; break;
+                          case '\0': cv = 6; break; default: cv = 4; }
+            out.push_back(cv);
+        }
+    };
     auto emit = [&](uint32_t read, const gm_match& mm, uint64_t midx, double den) {
         double total = exp((double)mm.score) / den;                    // ScoredSeq.h:300
         int mapq;
@@ -922,6 +970,7 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
             for (uint32_t q = mm.pos_begin; q < mm.pos_end; ++q) {
                 dpos.push_back(hits->positions[q].pos); dspan.push_back(ops_len[m]); dw.push_back(wgt);
                 max_span = std::max<uint32_t>(max_span, ops_len[m]);
+                if (nuc) { dcoff.push_back(dcodes.size()); aligned_codes(mm, m, hits->positions[q].strand == mm.first_strand, dcodes); }
             }
             if (p->print_all_sam) emit(i, mm, m, den);
             if (lg > best_log) { best = (int64_t)m; best_log = lg; }  // is_greater: strict, first in key order wins
@@ -939,8 +988,14 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
         HIPCHK(hipMemcpyAsync(b->dep_pos.p, dpos.data(), nd * 8, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(b->dep_span.p, dspan.data(), nd * 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(b->dep_w.p, dw.data(), nd * 4, hipMemcpyHostToDevice, st));
+        if (nuc) {
+            if (b->dep_codes.ensure(dcodes.size() + 16) || b->dep_coff.ensure(nd * 8)) return GM_E_NOMEM;
+            HIPCHK(hipMemcpyAsync(b->dep_codes.p, dcodes.data(), dcodes.size(), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(b->dep_coff.p, dcoff.data(), nd * 8, hipMemcpyHostToDevice, st));
+        }
         KCHK(gmk_coverage_add(ix->d_cov.as<float>(), ix->cov_bins, ix->cov_bin_size, b->dep_pos.as<uint64_t>(), b->dep_span.as<uint32_t>(),
-                              b->dep_w.as<float>(), (uint32_t)nd, max_span, st));
+                              b->dep_w.as<float>(), (uint32_t)nd, max_span, nuc ? ix->d_nuc.as<float>() : nullptr,
+                              nuc ? b->dep_codes.as<uint8_t>() : nullptr, nuc ? b->dep_coff.as<uint64_t>() : nullptr, st));
         HIPCHK(hipStreamSynchronize(st));
     }
     if (!recs.empty()) memcpy(out->recs, recs.data(), recs.size() * sizeof(gm_sam_rec));
@@ -1098,7 +1153,7 @@ extern "C" int gm_coverage_add(gm_index* ix, const uint64_t* pos, const uint32_t
         if (hipMemcpyAsync(dp_.p, pos, (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess) { rc = GM_E_HIP; break; }
         if (hipMemcpyAsync(ds_.p, span, (size_t)n * 4, hipMemcpyHostToDevice, st) != hipSuccess) { rc = GM_E_HIP; break; }
         if (hipMemcpyAsync(dw_.p, w, (size_t)n * 4, hipMemcpyHostToDevice, st) != hipSuccess) { rc = GM_E_HIP; break; }
-        if (gmk_coverage_add(ix->d_cov.as<float>(), ix->cov_bins, ix->cov_bin_size, dp_.as<uint64_t>(), ds_.as<uint32_t>(), dw_.as<float>(), n, max_span, st)) { rc = GM_E_HIP; break; }
+        if (gmk_coverage_add(ix->d_cov.as<float>(), ix->cov_bins, ix->cov_bin_size, dp_.as<uint64_t>(), ds_.as<uint32_t>(), dw_.as<float>(), n, max_span, nullptr, nullptr, nullptr, st)) { rc = GM_E_HIP; break; }
         if (hipStreamSynchronize(st) != hipSuccess) { rc = GM_E_HIP; break; }
     } while (0);
     dp_.release(); ds_.release(); dw_.release();
@@ -1126,6 +1181,50 @@ extern "C" int gm_coverage_write_sgr(gm_index* ix, const float* bins, const char
         for (; count < next; count += bs)
             if ((double)bins[count / bs] > 0.001)     // MIN_PRINT, GenomeBwt.cpp:928
                 fprintf(f, "%s\t%ld\t%.5f\n", h.contigs[i].name.c_str(), (long)(count - h.contigs[i].offset) + 1, bins[count / bs]);
+    }
+    fclose(f);
+    return GM_OK;
+}
+
+extern "C" int gm_coverage_enable_nuc(gm_index* ix) {
+    if (!ix || !ix->cov_bins) { gm_set_error("gm_coverage_reset first"); return GM_E_ARG; }
+    HIPCHK(hipSetDevice(ix->device));
+    if (ix->d_nuc.ensure(5 * ix->cov_bins * 4)) return GM_E_NOMEM;
+    HIPCHK(hipMemset(ix->d_nuc.p, 0, 5 * ix->cov_bins * 4));
+    ix->nuc_on = true;
+    return GM_OK;
+}
+
+extern "C" void* gm_coverage_nuc_device_ptr(gm_index* ix) { return ix && ix->nuc_on ? ix->d_nuc.p : nullptr; }
+
+extern "C" int gm_coverage_download_nuc(gm_index* ix, float* host) {
+    if (!ix || !host || !ix->nuc_on) return GM_E_ARG;
+    HIPCHK(hipSetDevice(ix->device));
+    HIPCHK(hipMemcpy(host, ix->d_nuc.p, 5 * ix->cov_bins * 4, hipMemcpyDeviceToHost));
+    return GM_OK;
+}
+
+extern "C" int gm_coverage_write_gmp(gm_index* ix, const gm_params* p, const float* bins, const float* nuc, const char* path, int append) {
+    // GenomeBwt::PrintFinalBisulfite src/GenomeBwt.cpp:1092-1210
+    if (!ix || !p || !bins || !nuc || !path || !ix->cov_bin_size || p->mode == GM_MODE_NORMAL) return GM_E_ARG;
+    FILE* f = fopen(path, append ? "a" : "w");
+    if (!f) { gm_set_error(std::string("cannot write ") + path); return GM_E_IO; }
+    const GmHostIndex& h = ix->h;
+    const uint64_t bs = ix->cov_bin_size, nb = ix->cov_bins;
+    const char want = p->mode == GM_MODE_BS ? 'c' : p->mode == GM_MODE_BS2 ? 'g' : p->mode == GM_MODE_ATOG ? 'a' : 't';
+    uint64_t count = 0;
+    for (size_t i = 0; i < h.contigs.size(); ++i) {
+        uint64_t next = i + 1 < h.contigs.size() ? h.contigs[i + 1].offset : h.l_pac;
+        for (; count < next; count += bs) {
+            char at = "acgt"[(h.pac[count >> 2] >> ((~count & 3) << 1)) & 3];
+            if (at != want) continue;
+            uint64_t locus = count / bs;
+            if (bins[locus] > 0.0f) {
+                fprintf(f, "%s\t%ld\t%f", h.contigs[i].name.c_str(), (long)(count - h.contigs[i].offset) + 1, bins[locus]);
+                for (int c = 0; c < 5; ++c) fprintf(f, "\t%.5f", nuc[(size_t)c * nb + locus]);
+                fprintf(f, "\n");
+            }
+        }
     }
     fclose(f);
     return GM_OK;

@@ -117,6 +117,6 @@ int gmk_locate(const GmDevIndex& ix, const uint32_t* ranks, uint32_t n, int use_
 int gmk_traceback(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, const GmCand* items, uint32_t n,
                   uint8_t* ops, uint32_t ops_stride, uint16_t* ops_len, void* stream);
 int gmk_coverage_add(float* cov, uint64_t bins, uint32_t bin_size, const uint64_t* pos, const uint32_t* span, const float* w,
-                     uint32_t n, uint32_t max_span, void* stream);
+                     uint32_t n, uint32_t max_span, float* nuc, const uint8_t* codes, const uint64_t* code_off, void* stream);
 }
 #endif

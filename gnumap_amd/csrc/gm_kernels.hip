@@ -1750,12 +1750,18 @@ __global__ void __launch_bounds__(256) k_traceback(GmDevIndex ix, GmDevParams p,
 // coverage: one thread per deposited base
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_coverage_add(float* cov, uint64_t bins, uint32_t bin_size, const uint64_t* pos,
-                                                      const uint32_t* span, const float* w, uint32_t n, uint32_t max_span) {
+                                                      const uint32_t* span, const float* w, uint32_t n, uint32_t max_span,
+                                                      float* nuc, const uint8_t* codes, const uint64_t* code_off) {
     uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t dep = (uint32_t)(gid / max_span), t = (uint32_t)(gid % max_span);
     if (dep >= n || t >= span[dep]) return;
     uint64_t bin = (pos[dep] + t) / bin_size;
-    if (bin < bins) atomicAdd(&cov[bin], w[dep]);
+    if (bin >= bins) return;
+    atomicAdd(&cov[bin], w[dep]);
+    if (nuc) {                                       // -b / -d: reads[base][loc] += w (GenomeBwt::AddSeqScore src/GenomeBwt.cpp:556-603)
+        uint32_t c = codes[code_off[dep] + t];
+        if (c < 5) atomicAdd(&nuc[(size_t)c * bins + bin], w[dep]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1949,9 +1955,10 @@ int gmk_traceback(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& 
 }
 
 int gmk_coverage_add(float* cov, uint64_t bins, uint32_t bin_size, const uint64_t* pos, const uint32_t* span, const float* w,
-                     uint32_t n, uint32_t max_span, void* stream) {
+                     uint32_t n, uint32_t max_span, float* nuc, const uint8_t* codes, const uint64_t* code_off, void* stream) {
     if (n == 0 || max_span == 0) return 0;
     uint64_t total = (uint64_t)n * max_span;
-    hipLaunchKernelGGL(k_coverage_add, dim3(cdiv(total, 256)), dim3(256), 0, S_(stream), cov, bins, bin_size, pos, span, w, n, max_span);
+    hipLaunchKernelGGL(k_coverage_add, dim3(cdiv(total, 256)), dim3(256), 0, S_(stream), cov, bins, bin_size, pos, span, w, n, max_span,
+                       nuc, codes, code_off);
     return (int)hipGetLastError();
 }

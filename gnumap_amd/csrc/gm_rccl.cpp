@@ -28,6 +28,15 @@ extern "C" int gm_coverage_allreduce(gm_index** per_gpu, int n_gpu) {
         if (ncclAllReduce(ptrs[(size_t)i], ptrs[(size_t)i], bins, ncclFloat, ncclSum, comms[(size_t)i], nullptr) != ncclSuccess) rc = GM_E_HIP;
     }
     ncclGroupEnd();
+    if (gm_coverage_nuc_device_ptr(per_gpu[0])) {           // -b / -d: the five per-nucleotide arrays (src/Driver.cpp:1719-1768)
+        ncclGroupStart();
+        for (int i = 0; i < n_gpu; ++i) {
+            (void)hipSetDevice(devs[(size_t)i]);
+            void* q = gm_coverage_nuc_device_ptr(per_gpu[i]);
+            if (!q || ncclAllReduce(q, q, 5 * bins, ncclFloat, ncclSum, comms[(size_t)i], nullptr) != ncclSuccess) rc = GM_E_HIP;
+        }
+        ncclGroupEnd();
+    }
     for (int i = 0; i < n_gpu; ++i) {
         (void)hipSetDevice(devs[(size_t)i]);
         if (hipDeviceSynchronize() != hipSuccess) rc = GM_E_HIP;

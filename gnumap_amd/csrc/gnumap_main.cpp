@@ -286,6 +286,7 @@ int main(int argc, char** argv) {
     }
     for (int g = 0; g < o.gpus; ++g) {
         if (gm_coverage_reset(workers[(size_t)g].ix, (uint32_t)o.p.bin_size) != GM_OK ||
+            (o.p.mode != GM_MODE_NORMAL && gm_coverage_enable_nuc(workers[(size_t)g].ix) != GM_OK) ||
             gm_batch_create(workers[(size_t)g].ix, o.batch, 4096, &workers[(size_t)g].batch) != GM_OK) { fprintf(stderr, "ERROR: %s\n", gm_last_error()); return 1; }
     }
     gm_index_info info;
@@ -336,9 +337,16 @@ int main(int argc, char** argv) {
     for (auto& w : workers) all.push_back(w.ix);
     if (gm_coverage_allreduce(all.data(), o.gpus) != GM_OK) { fprintf(stderr, "ERROR: %s\n", gm_last_error()); return 1; }
     std::vector<float> cov(gm_coverage_bins(workers[0].ix));
-    if (gm_coverage_download(workers[0].ix, cov.data()) != GM_OK || gm_coverage_write_sgr(workers[0].ix, cov.data(), (o.output + ".sgr").c_str(), 0) != GM_OK) {
-        fprintf(stderr, "ERROR: %s\n", gm_last_error());
-        return 1;
+    if (gm_coverage_download(workers[0].ix, cov.data()) != GM_OK) { fprintf(stderr, "ERROR: %s\n", gm_last_error()); return 1; }
+    if (o.p.mode == GM_MODE_NORMAL) {                                  // GenomeBwt::PrintFinal src/GenomeBwt.cpp:915-926
+        if (gm_coverage_write_sgr(workers[0].ix, cov.data(), (o.output + ".sgr").c_str(), 0) != GM_OK) { fprintf(stderr, "ERROR: %s\n", gm_last_error()); return 1; }
+    } else {
+        std::vector<float> nuc(5 * cov.size());
+        if (gm_coverage_download_nuc(workers[0].ix, nuc.data()) != GM_OK ||
+            gm_coverage_write_gmp(workers[0].ix, &o.p, cov.data(), nuc.data(), (o.output + ".gmp").c_str(), 0) != GM_OK) {
+            fprintf(stderr, "ERROR: %s\n", gm_last_error());
+            return 1;
+        }
     }
     uint64_t n_reads = 0, n_matched = 0, n_records = 0;
     for (auto& w : workers) { n_reads += w.n_reads; n_matched += w.n_matched; n_records += w.n_records; gm_batch_destroy(w.batch); gm_index_close(w.ix); }

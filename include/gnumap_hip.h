@@ -211,6 +211,13 @@ int gm_coverage_add(gm_index*, const uint64_t* pos, const uint32_t* span, const 
 int gm_coverage_download(gm_index*, float* host /* bins */);
 int gm_coverage_allreduce(gm_index** per_gpu, int n_gpu);        /* single-process multi-GPU: ncclAllReduce(sum) over xGMI */
 int gm_coverage_write_sgr(gm_index*, const float* host_bins, const char* path, int append);
+/* -b / -d (bisulfite, A->G): the per-nucleotide track reads[A,C,G,T,N][loc] of BSScoredSeq::score (src/BSScoredSeq.cpp:24-88,
+ * GenomeBwt::AddSeqScore src/GenomeBwt.cpp:556-603), 5 x bins floats in HBM, filled by gm_output_batch once enabled, and the
+ * .gmp writer (GenomeBwt::PrintFinalBisulfite src/GenomeBwt.cpp:1092-1210; these modes write <out>.gmp INSTEAD of <out>.sgr) */
+int gm_coverage_enable_nuc(gm_index*);
+void* gm_coverage_nuc_device_ptr(gm_index*);
+int gm_coverage_download_nuc(gm_index*, float* host /* 5 x bins */);
+int gm_coverage_write_gmp(gm_index*, const gm_params*, const float* host_bins, const float* host_nuc, const char* path, int append);
 
 #ifdef __cplusplus
 }

@@ -735,7 +735,28 @@ int gmo_read_output(const gmo_index* ix, const gmo_params* p, const gmo_result* 
         double total = exp(hit->score) / r->denominator;
         for (int q = 0; q < hit->n_pos; ++q) {
             if (n_deps == cap_deps) { cap_deps = cap_deps ? cap_deps * 2 : 4; deps = (gmo_deposit*)realloc(deps, sizeof(gmo_deposit) * (size_t)cap_deps); }
-            deps[n_deps].pos = hit->pos[q].pos; deps[n_deps].span = (uint32_t)alen; deps[n_deps].w = (float)total;
+            deps[n_deps].pos = hit->pos[q].pos; deps[n_deps].span = (uint32_t)alen; deps[n_deps].w = (float)total; deps[n_deps].codes = NULL;
+            if (p->mode != GMO_MODE_NORMAL) {
+                /* BSScoredSeq::score BSScoredSeq.cpp:24-88: the gapped read string for positions on the first strand, its
+                 * reverse_comp for the others; AddSeqScore(pos+i, w, g_gen_CONVERSION[char]) */
+                uint8_t* codes = (uint8_t*)malloc((size_t)alen + 1);
+                for (int t = 0; t < alen; ++t) {
+                    char ch;
+                    if (hit->pos[q].strand == hit->first_strand) ch = aligned[t];
+                    else {
+                        char c0 = aligned[alen - 1 - t];               /* reverse_comp SequenceOperations.h:56-96 */
+                        switch (c0) { case 'a': ch = 't'; break; case 'A': ch = 'T'; break; case 't': ch = 'a'; break; case 'T': ch = 'A'; break;
+                                      case 'c': ch = 'g'; break; case 'C': ch = 'G'; break; case 'g': ch = 'c'; break; case 'G': ch = 'C'; break;
+                                      case '-': ch = '-'; break; default: ch = 'n'; break; }
+                    }
+                    uint8_t cv;                                        /* g_gen_CONVERSION Driver.cpp:912-925 */
+                    switch (ch) { case 'a': case 'A': cv = 0; break; case 'c': case 'C': cv = 1; break; case 'g': case 'G': cv = 2; break;
+                                  case 't': case 'T': cv = 3; break; case 'n': case 'N': cv = 4; break; case '\n': case '\r': case 11: case 12: cv = 5; break;
+                                  case '\0': cv = 6; break; case '>': cv = 7; break; default: cv = 4; break; }
+                    codes[t] = cv;
+                }
+                deps[n_deps].codes = codes;
+            }
             n_deps++;
         }
         if (p->print_all_sam) emit_sam(ix, p, r, hit, pwm, rpwm, cons, rcons, L, aligned, &recs, &n_recs, &cap_recs, ctr);
@@ -877,6 +898,8 @@ int gmo_run(const gmo_index* ix, const gmo_params* p, const char* fastq, const c
     }
     size_t nbins = ix->l_pac / (uint64_t)p->bin_size + 64;
     float* cov = (float*)calloc(nbins, sizeof(float));
+    float* nuc[5] = { 0, 0, 0, 0, 0 };                       /* reads[A,C,G,T,N][loc], make_extra_arrays GenomeBwt.cpp:198-280 */
+    if (p->mode != GMO_MODE_NORMAL) for (int c = 0; c < 5; ++c) nuc[c] = (float*)calloc(nbins, sizeof(float));
     for (uint64_t i = 0; i < n; ++i) {
         read_out* ro = &w.outs[i];
         st->n_matched += (uint64_t)ro->matched;
@@ -888,13 +911,39 @@ int gmo_run(const gmo_index* ix, const gmo_params* p, const char* fastq, const c
         for (int d = 0; d < ro->n_deps; ++d)              /* AddScore GenomeBwt.cpp:483-490 */
             for (uint32_t t = 0; t < ro->deps[d].span; ++t) {
                 uint64_t bin = (ro->deps[d].pos + t) / (uint64_t)p->bin_size;
-                if (bin < nbins) cov[bin] += ro->deps[d].w;
+                if (bin < nbins) {
+                    cov[bin] += ro->deps[d].w;
+                    /* AddSeqScore(pos, amt, which) GenomeBwt.cpp:556-603; which >= 5 ('\0' of the consense[i] quirk) indexes past
+                     * reads[] in the reference (undefined behaviour): not deposited here */
+                    if (ro->deps[d].codes && ro->deps[d].codes[t] < 5) nuc[ro->deps[d].codes[t]][bin] += ro->deps[d].w;
+                }
             }
+        for (int d = 0; d < ro->n_deps; ++d) free(ro->deps[d].codes);
         free(ro->sam); free(ro->deps);
     }
     st->n_reads = n;
     if (sam) fclose(sam);
-    if (out_prefix) {                                     /* PrintFinalSGR GenomeBwt.cpp:1212-1273 */
+    if (out_prefix && p->mode != GMO_MODE_NORMAL) {       /* PrintFinalBisulfite GenomeBwt.cpp:1092-1210 (PrintFinal :915-926: .gmp INSTEAD of .sgr) */
+        snprintf(fn, sizeof fn, "%s.gmp", out_prefix);
+        FILE* gm = fopen(fn, "w");
+        if (!gm) return -3;
+        char want = p->mode == GMO_MODE_BS ? 'c' : p->mode == GMO_MODE_BS2 ? 'g' : p->mode == GMO_MODE_ATOG ? 'a' : 't';
+        uint64_t count = 0;
+        for (int i = 0; i < ix->n_seqs; ++i) {
+            uint64_t next = (i + 1 < ix->n_seqs) ? ix->contigs[i + 1].offset : ix->l_pac;
+            for (; count < next; count += (uint64_t)p->bin_size) {
+                char at = "acgt"[ix->pac[count >> 2] >> ((~count & 3) << 1) & 3];
+                if (at != want) continue;
+                uint64_t locus = count / (uint64_t)p->bin_size;
+                if (cov[locus] > 0.0f) {
+                    fprintf(gm, "%s\t%ld\t%f", ix->contigs[i].name, (long)(count - ix->contigs[i].offset) + 1, cov[locus]);
+                    for (int c = 0; c < 5; ++c) fprintf(gm, "\t%.5f", nuc[c][locus]);
+                    fprintf(gm, "\n");
+                }
+            }
+        }
+        fclose(gm);
+    } else if (out_prefix) {                              /* PrintFinalSGR GenomeBwt.cpp:1212-1273 */
         snprintf(fn, sizeof fn, "%s.sgr", out_prefix);
         FILE* sg = fopen(fn, "w");
         if (!sg) return -3;
@@ -908,6 +957,7 @@ int gmo_run(const gmo_index* ix, const gmo_params* p, const char* fastq, const c
         fclose(sg);
     }
     free(cov);
+    for (int c = 0; c < 5; ++c) free(nuc[c]);
     for (uint64_t i = 0; i < n; ++i) { free(recs[i].name); free(recs[i].seq); free(recs[i].qual); }
     free(recs); free(w.outs);
     pthread_mutex_destroy(&w.mu);

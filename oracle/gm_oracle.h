@@ -83,7 +83,7 @@ typedef struct {
     float a_score, post_prob; int sim_matches;
 } gmo_sam;
 
-typedef struct { uint64_t pos; uint32_t span; float w; } gmo_deposit;
+typedef struct { uint64_t pos; uint32_t span; float w; uint8_t* codes; /* -b/-d: g_gen_CONVERSION of the gapped read string per base, else NULL */ } gmo_deposit;
 
 /* ---- index ---- */
 gmo_index* gmo_index_load(const char* fasta_prefix);
