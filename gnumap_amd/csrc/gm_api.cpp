@@ -8,9 +8,11 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <set>
+#include <thread>
 
 static thread_local std::string g_err;
 void gm_set_error(const std::string& s) { g_err = s; }
@@ -52,6 +54,22 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+struct PinBuf {                              // page-locked host staging: device <-> host copies at link rate, no zero fill
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return GM_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) { gm_set_error(std::string("hipHostMalloc: ") + hipGetErrorString(e)); p = nullptr; return GM_E_NOMEM; }
+        cap = want;
+        return GM_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
 inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace
@@ -80,6 +98,7 @@ struct gm_batch {
     DevBuf bases, quals, len, status, self_score, min_score, top_score, seeds, n_seeds, n_entries, entry_off, coords,
         rs_overflow, retry_list, retry_off, gtab_keys, gtab_vals, cands, hit_count, hit_begin, hit_cursor, raw_hits, counters, small, shards, big_list,
         tb_items, tb_ops, tb_len, dep_pos, dep_span, dep_w, dep_codes, dep_coff;
+    PinBuf h_ops, h_ops_len, h_raw;
     uint32_t cand_cap = 0;
     uint64_t raw_cap = 0;
     uint32_t n_cands = 0;
@@ -751,34 +770,90 @@ static inline char comp_base(char c) {      // reverse_comp SequenceOperations.h
     switch (c) { case 'a': return 't'; case 't': return 'a'; case 'c': return 'g'; case 'g': return 'c'; default: return 'n'; }
 }
 
+// host-side bookkeeping of a batch is independent per read: cut the reads into contiguous chunks, one host thread each
+// (GM_HOST_THREADS, default min(16, cores)); results are concatenated in read order, so the output does not depend on it
+static unsigned host_threads() {
+    static const unsigned n = [] {
+        const char* e = getenv("GM_HOST_THREADS");
+        unsigned v = e ? (unsigned)atoi(e) : std::min(16u, std::thread::hardware_concurrency());
+        return std::max(1u, v);
+    }();
+    return n;
+}
+template <class F> static unsigned parallel_chunks(uint32_t n, uint32_t grain, unsigned want, F&& fn) {   // fn(chunk, lo, hi); returns #chunks
+    unsigned T = (unsigned)std::min<uint64_t>(want, std::max<uint32_t>(1, n / std::max<uint32_t>(1, grain)));
+    if (T <= 1) { fn(0u, 0u, n); return 1; }
+    std::vector<std::thread> th;
+    const uint64_t per = (n + T - 1) / T;
+    for (unsigned c = 1; c < T; ++c)
+        th.emplace_back([&, c] { uint32_t lo = (uint32_t)std::min<uint64_t>(n, c * per), hi = (uint32_t)std::min<uint64_t>(n, (c + 1) * per); fn(c, lo, hi); });
+    fn(0u, 0u, (uint32_t)std::min<uint64_t>(n, per));
+    for (auto& x : th) x.join();
+    return T;
+}
+
 struct HostMatch {
     float score; uint64_t first_pos; uint8_t first_strand;
     std::set<std::pair<uint64_t, int>> positions;
 };
 
+struct PhaseClock {                         // GM_TIMING=1: host-side phase times of the two batch calls on stderr
+    bool on; const char* what; std::chrono::steady_clock::time_point t0; std::string line;
+    explicit PhaseClock(const char* w) : on(getenv("GM_TIMING") && atoi(getenv("GM_TIMING"))), what(w), t0(std::chrono::steady_clock::now()) {}
+    void lap(const char* name) {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        char buf[64]; snprintf(buf, sizeof buf, " %s %.2f ms", name, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        line += buf; t0 = t1;
+    }
+    ~PhaseClock() { if (on) fprintf(stderr, "[gm_timing] %s:%s\n", what, line.c_str()); }
+};
+
 extern "C" int gm_map_batch(gm_index* ix, const gm_params* p, gm_batch* b, const gm_reads* reads, gm_hits* out, void* stream) {
     if (!ix || !p || !b || !reads || !out) return GM_E_ARG;
+    PhaseClock pc("gm_map_batch");
     int rc = gm_batch_upload(b, p, reads, stream);
     if (rc) return rc;
+    pc.lap("upload");
     rc = gm_map_batch_device(ix, p, b, stream);
     if (rc) return rc;
+    pc.lap("device");
     RawDownload r;
     rc = download_raw(b, r, S_(stream), !p->nw);
     if (rc) return rc;
+    pc.lap("download+sort");
     const uint32_t n = b->n;
     out->n = n;
-    std::vector<gm_match> matches;
-    std::vector<gm_pos> positions;
-    std::vector<uint64_t> mbegin(n + 1, 0);
-    std::string w, key;
-    for (uint32_t i = 0; i < n; ++i) {
-        mbegin[i] = matches.size();
+    struct Chunk { std::vector<gm_match> matches; std::vector<gm_pos> positions; uint32_t lo = 0, hi = 0; };
+    const unsigned want = host_threads();
+    std::vector<Chunk> chunks(want);
+    std::vector<uint32_t> mcount(n, 0);
+    const unsigned T = parallel_chunks(n, 4096, want, [&](unsigned ci, uint32_t lo, uint32_t hi) {
+      Chunk& ch = chunks[ci]; ch.lo = lo; ch.hi = hi;
+      std::vector<gm_match>& matches = ch.matches; std::vector<gm_pos>& positions = ch.positions;
+      std::string w, key;
+      for (uint32_t i = lo; i < hi; ++i) {
+        const size_t m0 = matches.size();
         out->status[i] = r.status[i];
         out->self_score[i] = r.self_score[i];
         out->denominator[i] = 0;
         out->top_score[i] = r.status[i] == GM_READ_TOO_SHORT ? -2.0 : r.status[i] == GM_READ_TOO_POOR ? -3.0 : 0.0;
         if (r.status[i] != 0) continue;
         const uint32_t L = b->len_host[i];
+        if (r.begin[i + 1] - r.begin[i] == 1 && !(p->nw && 1 > p->max_matches)) {
+            // one accepted hit: the unique map has one key whatever the window string is
+            const GmRawHit& h = r.hits[r.begin[i]];
+            out->denominator[i] = 0.0 + exp((double)h.score);
+            out->top_score[i] = (double)r.top[i];
+            gm_match m;
+            m.read = i; m.score = h.score; m.first_pos = h.pos; m.first_strand = h.strand;
+            m.pos_begin = (uint32_t)positions.size();
+            gm_pos q; q.pos = h.pos; q.strand = h.strand; positions.push_back(q);
+            m.pos_end = (uint32_t)positions.size();
+            matches.push_back(m);
+            mcount[i] = 1;
+            continue;
+        }
         std::map<std::string, HostMatch> uniq;
         double den = 0.0;
         bool too_many = false;
@@ -819,14 +894,30 @@ extern "C" int gm_map_batch(gm_index* ix, const gm_params* p, gm_batch* b, const
             m.pos_end = (uint32_t)positions.size();
             matches.push_back(m);
         }
-    }
-    mbegin[n] = matches.size();
-    uint64_t need_m = matches.size(), need_p = positions.size();
+        mcount[i] = (uint32_t)(matches.size() - m0);
+      }
+    });
+    pc.lap("unique-map");
+    uint64_t need_m = 0, need_p = 0;
+    for (unsigned c = 0; c < T; ++c) { need_m += chunks[c].matches.size(); need_p += chunks[c].positions.size(); }
     bool fits = need_m <= out->matches_cap && need_p <= out->positions_cap;
     if (!fits) { out->matches_cap = need_m; out->positions_cap = need_p; gm_set_error("output buffers too small"); return GM_E_CAPACITY; }
-    memcpy(out->match_begin, mbegin.data(), (n + 1) * 8);
-    if (need_m) memcpy(out->matches, matches.data(), need_m * sizeof(gm_match));
-    if (need_p) memcpy(out->positions, positions.data(), need_p * sizeof(gm_pos));
+    if (need_p > 0xFFFFFFFFull) { gm_set_error("more than 2^32 positions in one batch"); return GM_E_CAPACITY; }
+    uint64_t acc = 0;
+    for (uint32_t i = 0; i < n; ++i) { out->match_begin[i] = acc; acc += mcount[i]; }
+    out->match_begin[n] = acc;
+    uint64_t mo = 0, po = 0;
+    for (unsigned c = 0; c < T; ++c) {
+        Chunk& ch = chunks[c];
+        for (size_t k = 0; k < ch.matches.size(); ++k) {
+            gm_match m = ch.matches[k];
+            m.pos_begin += (uint32_t)po; m.pos_end += (uint32_t)po;
+            out->matches[mo + k] = m;
+        }
+        if (!ch.positions.empty()) memcpy(out->positions + po, ch.positions.data(), ch.positions.size() * sizeof(gm_pos));
+        mo += ch.matches.size(); po += ch.positions.size();
+    }
+    pc.lap("merge");
     return GM_OK;
 }
 
@@ -856,6 +947,7 @@ static void fix_cigar_for_deletions(std::string& c) {                  // Sequen
 extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, const gm_reads* reads, const gm_hits* hits, gm_sam_out* out, void* stream) {
     if (!ix || !p || !b || !reads || !hits || !out) return GM_E_ARG;
     if (hits->n != b->n) { gm_set_error("hits do not belong to the batch"); return GM_E_ARG; }
+    PhaseClock pc("gm_output_batch");
     HIPCHK(hipSetDevice(ix->device));
     hipStream_t st = S_(stream);
     GmDevParams dp;
@@ -876,20 +968,31 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
     HIPCHK(hipMemcpyAsync(b->tb_items.p, items.data(), n_m * sizeof(GmCand), hipMemcpyHostToDevice, st));
     fill_dev_batch(b);
     KCHK(gmk_traceback(ix->dev, dp, b->dev, b->tb_items.as<GmCand>(), (uint32_t)n_m, b->tb_ops.as<uint8_t>(), ops_stride, b->tb_len.as<uint16_t>(), st));
-    std::vector<uint8_t> ops(n_m * ops_stride);
-    std::vector<uint16_t> ops_len(n_m);
-    HIPCHK(hipMemcpyAsync(ops.data(), b->tb_ops.p, ops.size(), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(ops_len.data(), b->tb_len.p, n_m * 2, hipMemcpyDeviceToHost, st));
+    if (b->h_ops.ensure(n_m * ops_stride) || b->h_ops_len.ensure(n_m * 2)) return GM_E_NOMEM;
+    const uint8_t* ops = b->h_ops.as<uint8_t>();
+    const uint16_t* ops_len = b->h_ops_len.as<uint16_t>();
+    HIPCHK(hipMemcpyAsync(b->h_ops.p, b->tb_ops.p, n_m * ops_stride, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(b->h_ops_len.p, b->tb_len.p, n_m * 2, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    std::vector<gm_sam_rec> recs;
-    std::string pool;
-    std::vector<uint64_t> dpos; std::vector<uint32_t> dspan; std::vector<float> dw;
-    std::vector<uint8_t> dcodes; std::vector<uint64_t> dcoff;     // -b / -d: nucleotide of every deposited base
+    pc.lap("traceback");
+    struct OutChunk {
+        std::vector<gm_sam_rec> recs; std::string pool;
+        std::vector<uint64_t> dpos; std::vector<uint32_t> dspan; std::vector<float> dw;
+        std::vector<uint8_t> dcodes; std::vector<uint64_t> dcoff;     // -b / -d: nucleotide of every deposited base
+        uint32_t max_span = 0;
+    };
     const bool nuc = p->mode != GM_MODE_NORMAL && ix->nuc_on;
     std::vector<float> lut;
     if (nuc) { lut.resize(1024); build_lut(lut.data()); }
+    const unsigned want = host_threads();
+    std::vector<OutChunk> chunks(want);
+    const unsigned T = parallel_chunks(n, 4096, want, [&](unsigned ci, uint32_t lo, uint32_t hi) {
+    OutChunk& oc = chunks[ci];
+    std::vector<gm_sam_rec>& recs = oc.recs; std::string& pool = oc.pool;
+    std::vector<uint64_t>& dpos = oc.dpos; std::vector<uint32_t>& dspan = oc.dspan; std::vector<float>& dw = oc.dw;
+    std::vector<uint8_t>& dcodes = oc.dcodes; std::vector<uint64_t>& dcoff = oc.dcoff;
+    uint32_t& max_span = oc.max_span;
     std::string al, cons;
-    uint32_t max_span = 0;
     // gapped read string of a match (bin_seq.cpp:578-698 on the argmax consensus, ScoredSeq.h:57-103), as g_gen_CONVERSION codes
     auto aligned_codes = [&](const gm_match& mm, uint64_t midx, bool same_strand, std::vector<uint8_t>& out) {
         const uint32_t r = mm.read, L = b->len_host[r];
@@ -958,7 +1061,7 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
             recs.push_back(s);
         }
     };
-    for (uint32_t i = 0; i < n; ++i) {
+    for (uint32_t i = lo; i < hi; ++i) {
         if (hits->status[i] != GM_READ_OK) continue;
         const double den = hits->denominator[i];
         int64_t best = -1;
@@ -978,6 +1081,32 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
         if (!p->print_all_sam && best >= 0 && (double)hits->matches[best].score > hits->top_score[i] - 0.00001)   // Driver.cpp:695
             emit(i, hits->matches[best], (uint64_t)best, den);
     }
+    });
+    // concatenate in read order
+    std::vector<gm_sam_rec> recs; std::string pool;
+    std::vector<uint64_t> dpos; std::vector<uint32_t> dspan; std::vector<float> dw; std::vector<uint8_t> dcodes; std::vector<uint64_t> dcoff;
+    uint32_t max_span = 0;
+    if (T == 1) {
+        OutChunk& oc = chunks[0];
+        recs.swap(oc.recs); pool.swap(oc.pool); dpos.swap(oc.dpos); dspan.swap(oc.dspan); dw.swap(oc.dw); dcodes.swap(oc.dcodes); dcoff.swap(oc.dcoff);
+        max_span = oc.max_span;
+    } else {
+        size_t nr = 0, np_ = 0, nd = 0, nc = 0;
+        for (unsigned c = 0; c < T; ++c) { nr += chunks[c].recs.size(); np_ += chunks[c].pool.size(); nd += chunks[c].dpos.size(); nc += chunks[c].dcodes.size(); }
+        recs.reserve(nr); pool.reserve(np_); dpos.reserve(nd); dspan.reserve(nd); dw.reserve(nd); dcodes.reserve(nc); dcoff.reserve(nuc ? nd : 0);
+        for (unsigned c = 0; c < T; ++c) {
+            OutChunk& oc = chunks[c];
+            const uint32_t poff = (uint32_t)pool.size(); const uint64_t coff = dcodes.size();
+            for (gm_sam_rec s : oc.recs) { s.cigar_off += poff; recs.push_back(s); }
+            pool += oc.pool;
+            dpos.insert(dpos.end(), oc.dpos.begin(), oc.dpos.end()); dspan.insert(dspan.end(), oc.dspan.begin(), oc.dspan.end());
+            dw.insert(dw.end(), oc.dw.begin(), oc.dw.end());
+            for (uint64_t v : oc.dcoff) dcoff.push_back(v + coff);
+            dcodes.insert(dcodes.end(), oc.dcodes.begin(), oc.dcodes.end());
+            max_span = std::max(max_span, oc.max_span);
+        }
+    }
+    pc.lap("posterior+cigar");
     // capacity first: a call that is going to be repeated with larger buffers must not deposit coverage twice
     bool fits = recs.size() <= out->recs_cap && pool.size() <= out->cigar_cap;
     out->n_recs = recs.size(); out->cigar_len = pool.size();
@@ -997,6 +1126,7 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
                               b->dep_w.as<float>(), (uint32_t)nd, max_span, nuc ? ix->d_nuc.as<float>() : nullptr,
                               nuc ? b->dep_codes.as<uint8_t>() : nullptr, nuc ? b->dep_coff.as<uint64_t>() : nullptr, st));
         HIPCHK(hipStreamSynchronize(st));
+        pc.lap("coverage");
     }
     if (!recs.empty()) memcpy(out->recs, recs.data(), recs.size() * sizeof(gm_sam_rec));
     if (!pool.empty()) memcpy(out->cigar_pool, pool.data(), pool.size());
@@ -1168,6 +1298,8 @@ extern "C" int gm_coverage_download(gm_index* ix, float* host) {
     return GM_OK;
 }
 
+enum { MAX_SGR_LINE = 1200 };
+
 extern "C" int gm_coverage_write_sgr(gm_index* ix, const float* bins, const char* path, int append) {
     // GenomeBwt::PrintFinalSGR src/GenomeBwt.cpp:1212-1273: bins run over the CONCATENATED coordinate
     if (!ix || !bins || !path || !ix->cov_bin_size) return GM_E_ARG;
@@ -1175,12 +1307,27 @@ extern "C" int gm_coverage_write_sgr(gm_index* ix, const float* bins, const char
     if (!f) { gm_set_error(std::string("cannot write ") + path); return GM_E_IO; }
     const GmHostIndex& h = ix->h;
     const uint64_t bs = ix->cov_bin_size;
-    uint64_t count = 0;
-    for (size_t i = 0; i < h.contigs.size(); ++i) {
-        uint64_t next = i + 1 < h.contigs.size() ? h.contigs[i + 1].offset : h.l_pac;
-        for (; count < next; count += bs)
-            if ((double)bins[count / bs] > 0.001)     // MIN_PRINT, GenomeBwt.cpp:928
-                fprintf(f, "%s\t%ld\t%.5f\n", h.contigs[i].name.c_str(), (long)(count - h.contigs[i].offset) + 1, bins[count / bs]);
+    // the reference walks `count` over the concatenated coordinate in steps of bin_size without resetting it per contig,
+    // so bin k is printed under the contig that holds k * bin_size; text is produced in parallel slices, written in order
+    const uint64_t nb = (h.l_pac + bs - 1) / bs;
+    const uint64_t slab = 1u << 22;
+    for (uint64_t s0 = 0; s0 < nb; s0 += slab * host_threads()) {
+        const uint32_t span = (uint32_t)std::min<uint64_t>(nb - s0, slab * host_threads());
+        std::vector<std::string> parts(host_threads());
+        const unsigned T = parallel_chunks(span, 65536, host_threads(), [&](unsigned c, uint32_t lo, uint32_t hi) {
+            std::string& out = parts[c];
+            char buf[MAX_SGR_LINE];
+            int i = lo < hi ? host_pos2rid(h, (s0 + lo) * bs) : 0;
+            for (uint64_t k = s0 + lo; k < s0 + hi; ++k) {
+                const uint64_t count = k * bs;
+                while ((size_t)i + 1 < h.contigs.size() && count >= h.contigs[(size_t)i + 1].offset) ++i;
+                if ((double)bins[k] > 0.001) {      // MIN_PRINT, GenomeBwt.cpp:928
+                    int len = snprintf(buf, sizeof buf, "%s\t%ld\t%.5f\n", h.contigs[(size_t)i].name.c_str(), (long)(count - h.contigs[(size_t)i].offset) + 1, bins[k]);
+                    out.append(buf, (size_t)std::min<int>(len, (int)sizeof buf - 1));
+                }
+            }
+        });
+        for (unsigned c = 0; c < T; ++c) if (!parts[c].empty()) fwrite(parts[c].data(), 1, parts[c].size(), f);
     }
     fclose(f);
     return GM_OK;
@@ -1212,19 +1359,29 @@ extern "C" int gm_coverage_write_gmp(gm_index* ix, const gm_params* p, const flo
     const GmHostIndex& h = ix->h;
     const uint64_t bs = ix->cov_bin_size, nb = ix->cov_bins;
     const char want = p->mode == GM_MODE_BS ? 'c' : p->mode == GM_MODE_BS2 ? 'g' : p->mode == GM_MODE_ATOG ? 'a' : 't';
-    uint64_t count = 0;
-    for (size_t i = 0; i < h.contigs.size(); ++i) {
-        uint64_t next = i + 1 < h.contigs.size() ? h.contigs[i + 1].offset : h.l_pac;
-        for (; count < next; count += bs) {
-            char at = "acgt"[(h.pac[count >> 2] >> ((~count & 3) << 1)) & 3];
-            if (at != want) continue;
-            uint64_t locus = count / bs;
-            if (bins[locus] > 0.0f) {
-                fprintf(f, "%s\t%ld\t%f", h.contigs[i].name.c_str(), (long)(count - h.contigs[i].offset) + 1, bins[locus]);
-                for (int c = 0; c < 5; ++c) fprintf(f, "\t%.5f", nuc[(size_t)c * nb + locus]);
-                fprintf(f, "\n");
+    const uint64_t nbk = (h.l_pac + bs - 1) / bs;
+    const uint64_t slab = 1u << 22;
+    for (uint64_t s0 = 0; s0 < nbk; s0 += slab * host_threads()) {
+        const uint32_t span = (uint32_t)std::min<uint64_t>(nbk - s0, slab * host_threads());
+        std::vector<std::string> parts(host_threads());
+        const unsigned T = parallel_chunks(span, 65536, host_threads(), [&](unsigned c, uint32_t lo, uint32_t hi) {
+            std::string& out = parts[c];
+            char buf[MAX_SGR_LINE];
+            int i = lo < hi ? host_pos2rid(h, (s0 + lo) * bs) : 0;
+            for (uint64_t k = s0 + lo; k < s0 + hi; ++k) {
+                const uint64_t count = k * bs;
+                while ((size_t)i + 1 < h.contigs.size() && count >= h.contigs[(size_t)i + 1].offset) ++i;
+                char at = "acgt"[(h.pac[count >> 2] >> ((~count & 3) << 1)) & 3];
+                if (at != want) continue;
+                if (bins[k] > 0.0f) {
+                    int len = snprintf(buf, sizeof buf, "%s\t%ld\t%f\t%.5f\t%.5f\t%.5f\t%.5f\t%.5f\n", h.contigs[(size_t)i].name.c_str(),
+                                       (long)(count - h.contigs[(size_t)i].offset) + 1, bins[k], nuc[k], nuc[nb + k], nuc[2 * nb + k], nuc[3 * nb + k],
+                                       nuc[4 * nb + k]);
+                    out.append(buf, (size_t)std::min<int>(len, (int)sizeof buf - 1));
+                }
             }
-        }
+        });
+        for (unsigned c = 0; c < T; ++c) if (!parts[c].empty()) fwrite(parts[c].data(), 1, parts[c].size(), f);
     }
     fclose(f);
     return GM_OK;

@@ -3,11 +3,17 @@
 // path through the C ABI of libgnumap_hip.so only.  Per batch it mirrors parallel_thread_run (src/Driver.cpp:2303-2407):
 //     parse FASTQ block -> gm_map_batch (= loop over set_top_matches) -> gm_output_batch (= loop over create_match_output)
 //     -> SAM text.
-// Multi-GPU (--gpus N): one host thread and one index replica per GPU, read blocks dealt round-robin, per-GPU SAM
-// text concatenated in block order, coverage tracks combined with one RCCL all-reduce (gm_coverage_allreduce).
+// I/O at rate: the FASTQ file is memory-mapped and cut into blocks by one scanner thread (memchr only, no
+// copies); per GPU `--workers` host threads (default 2, each with its own gm_batch and HIP stream) pack a block, run the
+// two batch calls and hand the records to formatter threads; SAM text is written in block order by one writer thread.
+// The number of blocks in flight is bounded by a fixed pool of Block objects.
+// Multi-GPU (--gpus N): one index replica per GPU, blocks dealt to whichever worker is free, coverage tracks combined
+// with one RCCL all-reduce (gm_coverage_allreduce).
 #include "gnumap_hip.h"
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -20,6 +26,10 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #define MAX_NAME_SZ 1024        // inc/const_include.h:46
 
@@ -28,6 +38,8 @@ struct Options {
     gm_params p;
     int gpus = 1, locate_sampled = 0, verbose = 1;
     uint32_t batch = 262144;
+    int workers = 2;            // host threads (and gm_batch objects) per GPU
+    int fmt_threads = 0;        // SAM formatter threads per block (0 = min(8, cores))
     int threads = 1;            // -c: accepted for compatibility (the GPU replaces the pthread pool)
 };
 
@@ -51,7 +63,7 @@ static void usage(int rc, const char* msg) {
             "  -b, --bs_seq / --b2 / -d, --a_to_g   bisulfite / A-to-G scoring\n"
             "      --no_nw                  use k-mer hit counts instead of Needleman-Wunsch alignments\n"
             "      --fast, --print_all_sam, --illumina, --up_strand, --down_strand, --bin_size=INT\n"
-            "  MI355X options: --gpus=N  --batch=N  --locate=sampled|full\n");
+            "  MI355X options: --gpus=N  --batch=N  --workers=N  --fmt_threads=N  --locate=sampled|full\n");
     exit(rc);
 }
 
@@ -93,6 +105,8 @@ static void parse_args(int argc, char** argv, Options& o) {
             else if (!strcmp(s, "down_strand")) { o.p.pos_strand = 0; o.p.neg_strand = 1; }
             else if (starts(s, "gpus=")) o.gpus = atoi(s + 5);
             else if (starts(s, "batch=")) o.batch = (uint32_t)atoi(s + 6);
+            else if (starts(s, "workers=")) o.workers = atoi(s + 8);
+            else if (starts(s, "fmt_threads=")) o.fmt_threads = atoi(s + 12);
             else if (starts(s, "locate=")) o.locate_sampled = !strcmp(s + 7, "sampled");
             else if (!strcmp(s, "help")) usage(0, "");
             else { fprintf(stderr, "No matching arg in: %s\n", a); exit(1); }
@@ -136,109 +150,213 @@ static void parse_args(int argc, char** argv, Options& o) {
     if (gm_params_finalize(&o.p) != GM_OK) { fprintf(stderr, "%s\n", gm_last_error()); exit(1); }
     if (o.gpus < 1) o.gpus = 1;
     if (o.batch < 1) o.batch = 1;
+    if (o.workers < 1) o.workers = 1;
+    if (o.fmt_threads < 1) o.fmt_threads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
 }
 
-// ---- FASTQ block reader (SeqReader::get_more_fastq src/SeqReader.cpp:1023-1292: 4-line records, blank names skipped) ----
+// ---- blocks ------------------------------------------------------------------------------------------------------
 struct Block {
     uint64_t index = 0;
-    std::vector<std::string> names, seqs, quals;
-    std::vector<uint8_t> bases, qbuf;
+    uint32_t n = 0, maxlen = 0, stride = 8;
+    // views into the memory-mapped FASTQ text (no per-read strings)
+    std::vector<const char*> name, seq, qual;
+    std::vector<uint32_t> name_len, qual_len;
     std::vector<uint16_t> len;
-    uint32_t stride = 0;
+    // packed for gm_reads
+    std::vector<uint8_t> bases, qbuf;
+    // results of the two batch calls
+    std::vector<gm_sam_rec> recs; std::vector<char> pool; uint64_t n_recs = 0;
+    int gpu = 0;
+    std::vector<std::string> text;          // SAM text, one piece per formatter thread
+    bool failed = false;
 };
 
-struct FastqReader {
-    std::ifstream in;
+template <class T> struct Queue {             // unbounded MPMC queue; the Block pool bounds what is in flight
+    std::mutex mu; std::condition_variable cv; std::deque<T> q; bool closed = false;
+    void push(T v) { { std::lock_guard<std::mutex> lk(mu); q.push_back(v); } cv.notify_one(); }
+    bool pop(T& v) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !q.empty() || closed; });
+        if (q.empty()) return false;
+        v = q.front(); q.pop_front();
+        return true;
+    }
+    void close() { { std::lock_guard<std::mutex> lk(mu); closed = true; } cv.notify_all(); }
+};
+
+// ---- FASTQ scanner (SeqReader::get_more_fastq src/SeqReader.cpp:1023-1292: 4-line records, blank lines before a name skipped)
+struct FastqScanner {
+    const char* base = nullptr; size_t size = 0, at = 0;
+    int fd = -1; bool mapped = false; std::vector<char> heap;
     bool done = false;
-    explicit FastqReader(const std::string& fn) : in(fn.c_str()) {}
-    bool ok() const { return in.is_open(); }
+    bool open(const std::string& fn) {
+        fd = ::open(fn.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
+            size = (size_t)st.st_size;
+            if (size == 0) { base = ""; return true; }
+            void* p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (p != MAP_FAILED) { base = (const char*)p; mapped = true; madvise(p, size, MADV_SEQUENTIAL); return true; }
+        }
+        char buf[1 << 16]; ssize_t k;                       // pipes and the like: slurp
+        while ((k = ::read(fd, buf, sizeof buf)) > 0) heap.insert(heap.end(), buf, buf + k);
+        base = heap.data(); size = heap.size();
+        return true;
+    }
+    ~FastqScanner() { if (mapped) munmap((void*)base, size); if (fd >= 0) ::close(fd); }
+    // one line [p, p+len), without the newline; false at end of input
+    inline bool line(const char*& p, size_t& len) {
+        if (at >= size) return false;
+        const char* s = base + at;
+        const char* e = (const char*)memchr(s, '\n', size - at);
+        if (!e) { p = s; len = size - at; at = size; return true; }
+        p = s; len = (size_t)(e - s); at = (size_t)(e - base) + 1;
+        return true;
+    }
     bool next(Block& b, uint32_t max_reads) {
-        b.names.clear(); b.seqs.clear(); b.quals.clear();
+        b.n = 0; b.maxlen = 0;
+        b.name.clear(); b.seq.clear(); b.qual.clear(); b.name_len.clear(); b.qual_len.clear(); b.len.clear();
         if (done) return false;
-        std::string name, seq, plus, qual;
-        uint32_t maxlen = 0;
-        while (b.names.size() < max_reads) {
-            if (!std::getline(in, name)) { done = true; break; }
-            while (name.empty() && !in.eof()) std::getline(in, name);
-            if (in.eof() && name.empty()) { done = true; break; }
-            std::getline(in, seq); std::getline(in, plus); std::getline(in, qual);
-            if (name.empty() || name[0] != '@' || plus.empty() || plus[0] != '+' || seq.size() > qual.size()) {
-                fprintf(stderr, "--ERROR at sequence %s (malformed FASTQ record); stopping here\n", name.c_str());
+        while (b.n < max_reads) {
+            const char *nm, *sq = nullptr, *pl = nullptr, *ql = nullptr; size_t nl, sl = 0, pll = 0, qll = 0;
+            if (!line(nm, nl)) { done = true; break; }
+            bool eof = false;
+            while (nl == 0) { if (!line(nm, nl)) { eof = true; break; } }
+            if (eof) { done = true; break; }
+            if (!line(sq, sl)) { sq = ""; sl = 0; }
+            if (!line(pl, pll)) { pl = ""; pll = 0; }
+            if (!line(ql, qll)) { ql = ""; qll = 0; }
+            if (nm[0] != '@' || pll == 0 || pl[0] != '+' || sl > qll) {
+                fprintf(stderr, "--ERROR at sequence %.*s (malformed FASTQ record); stopping here\n", (int)std::min<size_t>(nl, 200), nm);
                 done = true;
                 break;
             }
-            if (seq.size() > 2048) { fprintf(stderr, "read %s longer than 2048 bases\n", name.c_str()); done = true; break; }
-            b.names.push_back(name.substr(1));
-            maxlen = std::max<uint32_t>(maxlen, (uint32_t)seq.size());
-            b.seqs.push_back(seq); b.quals.push_back(qual);
+            if (sl > 2048) { fprintf(stderr, "read %.*s longer than 2048 bases\n", (int)std::min<size_t>(nl, 200), nm); done = true; break; }
+            b.name.push_back(nm + 1); b.name_len.push_back((uint32_t)(nl - 1));
+            b.seq.push_back(sq); b.len.push_back((uint16_t)sl);
+            b.qual.push_back(ql); b.qual_len.push_back((uint32_t)qll);
+            b.maxlen = std::max<uint32_t>(b.maxlen, (uint32_t)sl);
+            ++b.n;
         }
-        const size_t n = b.names.size();
-        b.stride = std::max<uint32_t>(8, (maxlen + 7u) & ~7u);
-        b.bases.assign(n * b.stride, 0); b.qbuf.assign(n * b.stride, 0); b.len.resize(n);
-        for (size_t i = 0; i < n; ++i) {
-            b.len[i] = (uint16_t)b.seqs[i].size();
-            memcpy(&b.bases[i * b.stride], b.seqs[i].data(), b.seqs[i].size());
-            memcpy(&b.qbuf[i * b.stride], b.quals[i].data(), b.seqs[i].size());
-        }
-        return n > 0;
+        b.stride = std::max<uint32_t>(8, (b.maxlen + 7u) & ~7u);
+        return b.n > 0;
     }
 };
 
-static std::string reverse_comp(const std::string& s) {           // SequenceOperations.h:56-96
-    std::string t(s.size(), 'n');
-    for (size_t i = 0; i < s.size(); ++i) {
-        char c = s[s.size() - 1 - i], r;
-        switch (c) {
-            case 'a': r = 't'; break; case 'A': r = 'T'; break; case 't': r = 'a'; break; case 'T': r = 'A'; break;
-            case 'c': r = 'g'; break; case 'C': r = 'G'; break; case 'g': r = 'c'; break; case 'G': r = 'C'; break;
-            case '-': r = '-'; break; default: r = 'n'; break;
+template <class F> static void run_slices(uint32_t n, int threads, uint32_t grain, F&& fn) {          // fn(slice, lo, hi)
+    int T = (int)std::min<uint64_t>((uint64_t)threads, std::max<uint32_t>(1, n / std::max<uint32_t>(1, grain)));
+    if (T <= 1) { fn(0, 0u, n); return; }
+    const uint64_t per = (n + (uint64_t)T - 1) / (uint64_t)T;
+    std::vector<std::thread> th;
+    for (int s = 1; s < T; ++s)
+        th.emplace_back([&, s] { fn(s, (uint32_t)std::min<uint64_t>(n, s * per), (uint32_t)std::min<uint64_t>(n, (s + 1) * per)); });
+    fn(0, 0u, (uint32_t)std::min<uint64_t>(n, per));
+    for (auto& x : th) x.join();
+}
+
+static void pack_block(Block& b, int threads) {          // rows of `stride` bytes, zero padded, as gm_reads wants them
+    const size_t bytes = (size_t)b.n * b.stride;
+    if (b.bases.size() < bytes) { b.bases.resize(bytes); b.qbuf.resize(bytes); }
+    run_slices(b.n, threads, 8192, [&](int, uint32_t lo, uint32_t hi) {
+        for (uint32_t i = lo; i < hi; ++i) {
+            uint8_t* pb = &b.bases[(size_t)i * b.stride]; uint8_t* pq = &b.qbuf[(size_t)i * b.stride];
+            const uint32_t L = b.len[i];
+            memcpy(pb, b.seq[i], L); memset(pb + L, 0, b.stride - L);
+            memcpy(pq, b.qual[i], L); memset(pq + L, 0, b.stride - L);
         }
-        t[i] = r;
-    }
-    return t;
+    });
 }
 
-static std::string reverse_cigar(const char* s) {                  // SequenceOperations.h:109-123
-    std::string out, number;
-    for (size_t i = 0; i < strlen(s); ++i) {
-        if (s[i] >= 48 && s[i] <= 58) number += s[i];
-        else { out = number + s[i] + out; number.clear(); }
+// ---- SAM text (src/Driver.cpp:2146-2217) ---------------------------------------------------------------------------
+static inline char comp_char(char c) {                   // reverse_comp, SequenceOperations.h:56-96
+    switch (c) {
+        case 'a': return 't'; case 'A': return 'T'; case 't': return 'a'; case 'T': return 'A';
+        case 'c': return 'g'; case 'C': return 'G'; case 'g': return 'c'; case 'G': return 'C';
+        case '-': return '-'; default: return 'n';
     }
-    return out;
 }
 
-static void format_sam(std::string& out, const gm_index* ix, const gm_params& p, const gm_sam_rec& r, const char* cigar,
-                       const std::string& name, const std::string& seq, const std::string& qual) {
-    char buf[256];
-    out.append(name, 0, std::min<size_t>(name.size(), MAX_NAME_SZ - 1));
-    out += r.strand == GM_POS_STRAND ? "\t0\t" : "\t16\t";
-    out += gm_index_contig_name(ix, r.contig);
-    snprintf(buf, sizeof buf, "\t%lu\t%d\t", (unsigned long)r.chr_pos, r.mapq);
-    out += buf;
-    if (r.strand == GM_POS_STRAND) { out += cigar; out += "\t*\t0\t0\t"; out += seq; out += '\t'; out += qual; out += '\t'; }
-    else {
-        out += reverse_cigar(cigar); out += "\t*\t0\t0\t"; out += reverse_comp(seq); out += '\t';
-        out.append(qual.rbegin(), qual.rend()); out += '\t';
+static size_t reverse_cigar(const char* s, char* out) {  // SequenceOperations.h:109-123 (':' counts as a digit there, 48..58)
+    const size_t n = strlen(s);
+    size_t w = n, tok = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (s[i] >= 48 && s[i] <= 58) continue;
+        const size_t len = i + 1 - tok;                    // digits + the operation character
+        w -= len;
+        memcpy(out + w, s + tok, len);
+        tok = i + 1;
     }
-    snprintf(buf, sizeof buf, "XA:f:%g\tXP:f:%g\tX0:i:%d\n", (double)(float)r.a_score * (1.0 / p.adjust), (double)(float)r.post_prob, r.sim_matches);
-    out += buf;
+    // trailing digits without an operation are dropped by the reference
+    const size_t used = n - w;
+    memmove(out, out + w, used);
+    return used;
 }
 
+static inline char* put_u64(char* p, uint64_t v) {
+    char tmp[24]; int k = 0;
+    do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (k) *p++ = tmp[--k];
+    return p;
+}
+
+static void format_sam(std::string& out, const gm_index* ix, const gm_params& p, const gm_sam_rec& r, const char* cigar, const Block& b) {
+    const uint32_t i = r.read;
+    const uint32_t L = b.len[i], QL = b.qual_len[i];
+    const uint32_t nl = std::min<uint32_t>(b.name_len[i], MAX_NAME_SZ - 1);
+    const char* cn = gm_index_contig_name(ix, r.contig);
+    const size_t cl = strlen(cn), gl = strlen(cigar);
+    const size_t old = out.size();
+    out.resize(old + nl + cl + gl + L + QL + 160);
+    char* w = &out[old];
+    memcpy(w, b.name[i], nl); w += nl;
+    if (r.strand == GM_POS_STRAND) { memcpy(w, "\t0\t", 3); w += 3; } else { memcpy(w, "\t16\t", 4); w += 4; }
+    memcpy(w, cn, cl); w += cl;
+    *w++ = '\t'; w = put_u64(w, r.chr_pos); *w++ = '\t';
+    if (r.mapq < 0) { *w++ = '-'; w = put_u64(w, (uint64_t)(-(int64_t)r.mapq)); } else w = put_u64(w, (uint64_t)r.mapq);
+    *w++ = '\t';
+    if (r.strand == GM_POS_STRAND) {
+        memcpy(w, cigar, gl); w += gl;
+        memcpy(w, "\t*\t0\t0\t", 7); w += 7;
+        memcpy(w, b.seq[i], L); w += L; *w++ = '\t';
+        memcpy(w, b.qual[i], QL); w += QL; *w++ = '\t';
+    } else {
+        w += reverse_cigar(cigar, w);
+        memcpy(w, "\t*\t0\t0\t", 7); w += 7;
+        const char* s = b.seq[i];
+        for (uint32_t k = 0; k < L; ++k) w[k] = comp_char(s[L - 1 - k]);
+        w += L; *w++ = '\t';
+        const char* q = b.qual[i];
+        for (uint32_t k = 0; k < QL; ++k) w[k] = q[QL - 1 - k];
+        w += QL; *w++ = '\t';
+    }
+    w += snprintf(w, 120, "XA:f:%g\tXP:f:%g\tX0:i:%d\n", (double)(float)r.a_score * (1.0 / p.adjust), (double)(float)r.post_prob, r.sim_matches);
+    out.resize((size_t)(w - out.data()));
+}
+
+// ---- per worker: the two batch calls ---------------------------------------------------------------------------------
 struct Worker {
+    int gpu = 0;
     gm_index* ix = nullptr;
     gm_batch* batch = nullptr;
     std::vector<int8_t> status; std::vector<float> self_score; std::vector<double> top, den; std::vector<uint64_t> mbegin;
-    std::vector<gm_match> matches; std::vector<gm_pos> positions; std::vector<gm_sam_rec> recs; std::vector<char> pool;
+    std::vector<gm_match> matches; std::vector<gm_pos> positions;
     uint64_t n_reads = 0, n_matched = 0, n_records = 0;
+    double t_pack = 0, t_map = 0, t_out = 0;
 };
 
-static int process_block(Worker& w, const Options& o, const Block& b, std::string& sam) {
-    const uint32_t n = (uint32_t)b.names.size();
+static double secs_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+
+static int process_block(Worker& w, const Options& o, Block& b) {
+    const uint32_t n = b.n;
+    auto c0 = std::chrono::steady_clock::now();
+    pack_block(b, 4);
     gm_reads reads; reads.n = n; reads.stride = b.stride; reads.bases = b.bases.data(); reads.quals = b.qbuf.data(); reads.len = b.len.data();
     w.status.resize(n); w.self_score.resize(n); w.top.resize(n); w.den.resize(n); w.mbegin.resize(n + 1);
-    if (w.matches.size() < 4 * (size_t)n + 64) w.matches.resize(4 * (size_t)n + 64);
-    if (w.positions.size() < 8 * (size_t)n + 64) w.positions.resize(8 * (size_t)n + 64);
+    if (w.matches.size() < 2 * (size_t)n + 64) w.matches.resize(2 * (size_t)n + 64);
+    if (w.positions.size() < 2 * (size_t)n + 64) w.positions.resize(2 * (size_t)n + 64);
     gm_hits hits;
+    auto c1 = std::chrono::steady_clock::now();
     for (;;) {
         hits.n = n; hits.status = w.status.data(); hits.self_score = w.self_score.data(); hits.top_score = w.top.data();
         hits.denominator = w.den.data(); hits.match_begin = w.mbegin.data();
@@ -249,20 +367,19 @@ static int process_block(Worker& w, const Options& o, const Block& b, std::strin
         if (rc != GM_OK) { fprintf(stderr, "ERROR: gm_map_batch: %s\n", gm_last_error()); return rc; }
         break;
     }
-    if (w.recs.size() < 2 * (size_t)n + 64) w.recs.resize(2 * (size_t)n + 64);
-    if (w.pool.size() < 16 * (size_t)n + 1024) w.pool.resize(16 * (size_t)n + 1024);
+    auto c2 = std::chrono::steady_clock::now();
+    if (b.recs.size() < (size_t)n + (size_t)n / 4 + 64) b.recs.resize((size_t)n + (size_t)n / 4 + 64);
+    if (b.pool.size() < 8 * (size_t)n + 1024) b.pool.resize(8 * (size_t)n + 1024);
     gm_sam_out so;
     for (;;) {
-        so.recs = w.recs.data(); so.recs_cap = w.recs.size(); so.cigar_pool = w.pool.data(); so.cigar_cap = w.pool.size();
+        so.recs = b.recs.data(); so.recs_cap = b.recs.size(); so.cigar_pool = b.pool.data(); so.cigar_cap = b.pool.size();
         int rc = gm_output_batch(w.ix, &o.p, w.batch, &reads, &hits, &so, nullptr);
-        if (rc == GM_E_CAPACITY) { w.recs.resize(so.recs_cap + 64); w.pool.resize(so.cigar_cap + 64); continue; }
+        if (rc == GM_E_CAPACITY) { b.recs.resize(so.recs_cap + 64); b.pool.resize(so.cigar_cap + 64); continue; }
         if (rc != GM_OK) { fprintf(stderr, "ERROR: gm_output_batch: %s\n", gm_last_error()); return rc; }
         break;
     }
-    for (uint64_t k = 0; k < so.n_recs; ++k) {
-        const gm_sam_rec& r = w.recs[k];
-        format_sam(sam, w.ix, o.p, r, w.pool.data() + r.cigar_off, b.names[r.read], b.seqs[r.read], b.quals[r.read]);
-    }
+    b.n_recs = so.n_recs; b.gpu = w.gpu;
+    w.t_pack += std::chrono::duration<double>(c1 - c0).count(); w.t_map += std::chrono::duration<double>(c2 - c1).count(); w.t_out += secs_since(c2);
     w.n_reads += n; w.n_records += so.n_recs;
     for (uint32_t i = 0; i < n; ++i) w.n_matched += (w.status[i] == GM_READ_OK || w.status[i] == GM_READ_TOO_MANY);
     return GM_OK;
@@ -275,84 +392,164 @@ int main(int argc, char** argv) {
     for (int i = 0; i < argc; ++i) { cl += argv[i]; cl += " "; }      // Driver.cpp:1032-1039
     auto t0 = std::chrono::steady_clock::now();
     const int flags = GM_INDEX_BUILD | (o.locate_sampled ? 0 : GM_INDEX_FULL_SA);
-    std::vector<Worker> workers((size_t)o.gpus);
+    std::vector<gm_index*> gpu_ix((size_t)o.gpus, nullptr);
     {   // build once if missing, then one replica per GPU
-        gm_index* probe = nullptr;
-        int rc = gm_index_open(o.genome.c_str(), 0, flags, &probe);
-        if (rc != GM_OK) { fprintf(stderr, "ERROR: %s\n", gm_last_error()); return 1; }
-        workers[0].ix = probe;
+        if (gm_index_open(o.genome.c_str(), 0, flags, &gpu_ix[0]) != GM_OK) { fprintf(stderr, "ERROR: %s\n", gm_last_error()); return 1; }
         for (int g = 1; g < o.gpus; ++g)
-            if (gm_index_open(o.genome.c_str(), g, flags, &workers[(size_t)g].ix) != GM_OK) { fprintf(stderr, "ERROR: GPU %d: %s\n", g, gm_last_error()); return 1; }
+            if (gm_index_open(o.genome.c_str(), g, flags, &gpu_ix[(size_t)g]) != GM_OK) { fprintf(stderr, "ERROR: GPU %d: %s\n", g, gm_last_error()); return 1; }
     }
+    std::vector<Worker> workers((size_t)o.gpus * (size_t)o.workers);
     for (int g = 0; g < o.gpus; ++g) {
-        if (gm_coverage_reset(workers[(size_t)g].ix, (uint32_t)o.p.bin_size) != GM_OK ||
-            (o.p.mode != GM_MODE_NORMAL && gm_coverage_enable_nuc(workers[(size_t)g].ix) != GM_OK) ||
-            gm_batch_create(workers[(size_t)g].ix, o.batch, 4096, &workers[(size_t)g].batch) != GM_OK) { fprintf(stderr, "ERROR: %s\n", gm_last_error()); return 1; }
+        if (gm_coverage_reset(gpu_ix[(size_t)g], (uint32_t)o.p.bin_size) != GM_OK ||
+            (o.p.mode != GM_MODE_NORMAL && gm_coverage_enable_nuc(gpu_ix[(size_t)g]) != GM_OK)) { fprintf(stderr, "ERROR: %s\n", gm_last_error()); return 1; }
+        for (int k = 0; k < o.workers; ++k) {
+            Worker& w = workers[(size_t)g * (size_t)o.workers + (size_t)k];
+            w.gpu = g; w.ix = gpu_ix[(size_t)g];
+            if (gm_batch_create(w.ix, o.batch, 4096, &w.batch) != GM_OK) { fprintf(stderr, "ERROR: %s\n", gm_last_error()); return 1; }
+        }
     }
     gm_index_info info;
-    gm_index_get_info(workers[0].ix, &info);
+    gm_index_get_info(gpu_ix[0], &info);
+    const double t_index = secs_since(t0);
     if (o.verbose > 0)
         fprintf(stderr, "gnumap-mi355x: genome %s (%lu bp, %u contigs), %s locate, %d GPU(s), index %.1f MB in HBM\n", o.genome.c_str(),
                 (unsigned long)info.l_pac, info.n_seqs, info.full_sa ? "full-SA" : "sampled-SA", o.gpus, info.hbm_bytes / 1e6);
-    std::ofstream of((o.output + ".sam").c_str(), std::ofstream::out | std::ofstream::binary);
-    if (!of) { fprintf(stderr, "ERROR: cannot write %s.sam\n", o.output.c_str()); return 1; }
-    for (uint32_t i = 0; i < info.n_seqs; ++i)                         // Driver.cpp:2322-2327
-        of << "@SQ\tSN:" << gm_index_contig_name(workers[0].ix, i) << "\tLN:"
-           << (gm_index_contig_offset(workers[0].ix, i + 1) - gm_index_contig_offset(workers[0].ix, i)) << "\n";
-    of << "@PG\tID:gnumap\tPN:gnumap\tVN:4.0.0 BETA\tCL:" << cl << std::endl;
-
-    FastqReader fq(o.reads);
-    if (!fq.ok()) { fprintf(stderr, "ERROR: cannot open %s\n", o.reads.c_str()); return 1; }
-    std::mutex rd_mu, wr_mu;
-    std::map<uint64_t, std::string> pending;
-    uint64_t next_block = 0, next_write = 0;
-    std::atomic<int> failed{ 0 };
-    auto run = [&](int g) {
-        Worker& w = workers[(size_t)g];
-        Block b;
-        for (;;) {
-            {
-                std::lock_guard<std::mutex> lk(rd_mu);                // the reference serialises FASTQ parsing too (read_lock)
-                if (!fq.next(b, o.batch)) break;
-                b.index = next_block++;
-            }
-            std::string sam;
-            if (process_block(w, o, b, sam) != GM_OK) { failed = 1; break; }
-            std::lock_guard<std::mutex> lk(wr_mu);
-            pending[b.index] = std::move(sam);
-            while (!pending.empty() && pending.begin()->first == next_write) {
-                of << pending.begin()->second;
-                pending.erase(pending.begin());
-                ++next_write;
-            }
-        }
+    const int ofd = ::open((o.output + ".sam").c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (ofd < 0) { fprintf(stderr, "ERROR: cannot write %s.sam\n", o.output.c_str()); return 1; }
+    auto write_all = [&](const char* p, size_t n) {
+        while (n) { ssize_t k = ::write(ofd, p, n); if (k <= 0) return false; p += k; n -= (size_t)k; }
+        return true;
     };
-    std::vector<std::thread> th;
-    for (int g = 0; g < o.gpus; ++g) th.emplace_back(run, g);
-    for (auto& t : th) t.join();
+    {
+        std::ostringstream hd;
+        for (uint32_t i = 0; i < info.n_seqs; ++i)                     // Driver.cpp:2322-2327
+            hd << "@SQ\tSN:" << gm_index_contig_name(gpu_ix[0], i) << "\tLN:"
+               << (gm_index_contig_offset(gpu_ix[0], i + 1) - gm_index_contig_offset(gpu_ix[0], i)) << "\n";
+        hd << "@PG\tID:gnumap\tPN:gnumap\tVN:4.0.0 BETA\tCL:" << cl << "\n";
+        const std::string s = hd.str();
+        if (!write_all(s.data(), s.size())) { fprintf(stderr, "ERROR: write failed\n"); return 1; }
+    }
+
+    auto t_pipe0 = std::chrono::steady_clock::now();
+    FastqScanner fq;
+    if (!fq.open(o.reads)) { fprintf(stderr, "ERROR: cannot open %s\n", o.reads.c_str()); return 1; }
+    const size_t n_blocks = workers.size() * 2 + 4;                    // blocks in flight
+    std::vector<Block> blocks(n_blocks);
+    Queue<Block*> free_q, map_q, fmt_q;
+    for (auto& b : blocks) free_q.push(&b);
+    std::atomic<int> failed{ 0 };
+    double t_scan = 0, t_fmt = 0, t_write = 0;
+    std::mutex fmt_mu;
+
+    std::thread scanner([&] {
+        uint64_t idx = 0;
+        Block* b;
+        while (!failed && free_q.pop(b)) {
+            auto s0 = std::chrono::steady_clock::now();
+            bool more = fq.next(*b, o.batch);
+            t_scan += secs_since(s0);
+            if (!more) { free_q.push(b); break; }
+            b->index = idx++; b->failed = false;
+            map_q.push(b);
+        }
+        map_q.close();
+    });
+    std::vector<std::thread> wth;
+    std::atomic<int> live_workers{ (int)workers.size() };
+    for (size_t k = 0; k < workers.size(); ++k)
+        wth.emplace_back([&, k] {
+            Worker& w = workers[k];
+            Block* b;
+            while (map_q.pop(b)) {
+                if (!failed && process_block(w, o, *b) != GM_OK) { failed = 1; }
+                if (failed) { b->failed = true; b->n_recs = 0; }
+                fmt_q.push(b);
+            }
+            if (--live_workers == 0) fmt_q.close();
+        });
+    // formatters: a block is cut into slices of records, one string each; the writer emits blocks in index order
+    std::mutex wr_mu; std::condition_variable wr_cv; std::map<uint64_t, Block*> ready; bool fmt_done = false;
+    const int n_fmt = 2;
+    std::atomic<int> live_fmt{ n_fmt };
+    std::vector<std::thread> fth;
+    for (int f = 0; f < n_fmt; ++f)
+        fth.emplace_back([&] {
+            Block* b;
+            while (fmt_q.pop(b)) {
+                auto f0 = std::chrono::steady_clock::now();
+                const gm_index* ix = gpu_ix[(size_t)b->gpu];
+                const uint32_t nr = (uint32_t)b->n_recs;
+                const int T = o.fmt_threads;
+                if ((int)b->text.size() < T) b->text.resize((size_t)T);
+                for (auto& s : b->text) s.clear();
+                run_slices(nr, T, 4096, [&](int s, uint32_t lo, uint32_t hi) {
+                    std::string& out = b->text[(size_t)s];
+                    out.reserve((size_t)(hi - lo) * 300);
+                    for (uint32_t k = lo; k < hi; ++k) { const gm_sam_rec& r = b->recs[k]; format_sam(out, ix, o.p, r, b->pool.data() + r.cigar_off, *b); }
+                });
+                { std::lock_guard<std::mutex> lk(fmt_mu); t_fmt += secs_since(f0); }
+                { std::lock_guard<std::mutex> lk(wr_mu); ready[b->index] = b; }
+                wr_cv.notify_all();
+            }
+            if (--live_fmt == 0) { { std::lock_guard<std::mutex> lk(wr_mu); fmt_done = true; } wr_cv.notify_all(); }
+        });
+    std::thread writer([&] {
+        uint64_t next = 0;
+        for (;;) {
+            Block* b = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(wr_mu);
+                wr_cv.wait(lk, [&] { return (!ready.empty() && ready.begin()->first == next) || (fmt_done && ready.empty()) || (fmt_done && failed); });
+                if (ready.empty() || ready.begin()->first != next) break;
+                b = ready.begin()->second; ready.erase(ready.begin());
+            }
+            auto w0 = std::chrono::steady_clock::now();
+            if (!b->failed)
+                for (auto& s : b->text) if (!s.empty() && !write_all(s.data(), s.size())) { fprintf(stderr, "ERROR: write failed\n"); failed = 1; }
+            t_write += secs_since(w0);
+            ++next;
+            free_q.push(b);
+        }
+        free_q.close();
+    });
+    scanner.join();
+    for (auto& x : wth) x.join();
+    for (auto& x : fth) x.join();
+    writer.join();
+    ::close(ofd);
     if (failed) return 1;
-    of.close();
-    // coverage: all-reduce over the GPUs, then PrintFinalSGR
-    std::vector<gm_index*> all;
-    for (auto& w : workers) all.push_back(w.ix);
-    if (gm_coverage_allreduce(all.data(), o.gpus) != GM_OK) { fprintf(stderr, "ERROR: %s\n", gm_last_error()); return 1; }
-    std::vector<float> cov(gm_coverage_bins(workers[0].ix));
-    if (gm_coverage_download(workers[0].ix, cov.data()) != GM_OK) { fprintf(stderr, "ERROR: %s\n", gm_last_error()); return 1; }
+    const double t_pipe = secs_since(t_pipe0);
+    auto t_cov0 = std::chrono::steady_clock::now();
+    // coverage: all-reduce over the GPUs, then PrintFinalSGR / PrintFinalBisulfite
+    if (gm_coverage_allreduce(gpu_ix.data(), o.gpus) != GM_OK) { fprintf(stderr, "ERROR: %s\n", gm_last_error()); return 1; }
+    std::vector<float> cov(gm_coverage_bins(gpu_ix[0]));
+    if (gm_coverage_download(gpu_ix[0], cov.data()) != GM_OK) { fprintf(stderr, "ERROR: %s\n", gm_last_error()); return 1; }
     if (o.p.mode == GM_MODE_NORMAL) {                                  // GenomeBwt::PrintFinal src/GenomeBwt.cpp:915-926
-        if (gm_coverage_write_sgr(workers[0].ix, cov.data(), (o.output + ".sgr").c_str(), 0) != GM_OK) { fprintf(stderr, "ERROR: %s\n", gm_last_error()); return 1; }
+        if (gm_coverage_write_sgr(gpu_ix[0], cov.data(), (o.output + ".sgr").c_str(), 0) != GM_OK) { fprintf(stderr, "ERROR: %s\n", gm_last_error()); return 1; }
     } else {
         std::vector<float> nuc(5 * cov.size());
-        if (gm_coverage_download_nuc(workers[0].ix, nuc.data()) != GM_OK ||
-            gm_coverage_write_gmp(workers[0].ix, &o.p, cov.data(), nuc.data(), (o.output + ".gmp").c_str(), 0) != GM_OK) {
+        if (gm_coverage_download_nuc(gpu_ix[0], nuc.data()) != GM_OK ||
+            gm_coverage_write_gmp(gpu_ix[0], &o.p, cov.data(), nuc.data(), (o.output + ".gmp").c_str(), 0) != GM_OK) {
             fprintf(stderr, "ERROR: %s\n", gm_last_error());
             return 1;
         }
     }
     uint64_t n_reads = 0, n_matched = 0, n_records = 0;
-    for (auto& w : workers) { n_reads += w.n_reads; n_matched += w.n_matched; n_records += w.n_records; gm_batch_destroy(w.batch); gm_index_close(w.ix); }
-    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (o.verbose > 0)
-        fprintf(stderr, "Finished: %lu reads, %lu matched, %lu SAM records, %.2f s total\n", (unsigned long)n_reads, (unsigned long)n_matched,
-                (unsigned long)n_records, secs);
+    double t_pack = 0, t_map = 0, t_out = 0;
+    for (auto& w : workers) {
+        n_reads += w.n_reads; n_matched += w.n_matched; n_records += w.n_records; t_pack += w.t_pack; t_map += w.t_map; t_out += w.t_out;
+        gm_batch_destroy(w.batch);
+    }
+    const double t_cov = secs_since(t_cov0);
+    for (auto ix : gpu_ix) gm_index_close(ix);
+    double secs = secs_since(t0);
+    if (o.verbose > 0) {
+        fprintf(stderr, "stage seconds (summed over threads): index %.2f, scan %.2f, pack %.2f, gm_map_batch %.2f, gm_output_batch %.2f, SAM format %.2f, write %.2f\n",
+                t_index, t_scan, t_pack, t_map, t_out, t_fmt, t_write);
+        fprintf(stderr, "wall seconds: index %.2f, FASTQ->SAM pipeline %.2f (%.3f M reads/s), coverage all-reduce + track file %.2f\n", t_index, t_pipe,
+                n_reads / std::max(t_pipe, 1e-9) / 1e6, t_cov);
+        fprintf(stderr, "Finished: %lu reads, %lu matched, %lu SAM records, %.2f s total (%.2f s after the index was resident)\n", (unsigned long)n_reads,
+                (unsigned long)n_matched, (unsigned long)n_records, secs, secs - t_index);
+    }
     return 0;
 }
