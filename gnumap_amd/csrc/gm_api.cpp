@@ -638,6 +638,12 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         uint64_t total = 0; uint32_t mx = 0;
         rc = read_shards(total, mx);
         if (rc) return rc;
+        if (dp.dbg & 64) {                           // sampled phase clocks of the vote kernel (cycles of one lane per sampled workgroup)
+            const double ns = (double)std::max<unsigned long long>(1, ctr[GMK_DBG8]);
+            fprintf(stderr, "[gm_dbg] vote phases (mean cycles per sampled read x strand, %llu samples): desc %.0f, loads+window %.0f, pass1 %.0f, pass2a %.0f, scan %.0f, "
+                            "filter2 %.0f, table %.0f, emit %.0f\n", ctr[GMK_DBG8], ctr[GMK_DBG0] / ns, ctr[GMK_DBG1] / ns, ctr[GMK_DBG2] / ns, ctr[GMK_DBG3] / ns, ctr[GMK_DBG4] / ns,
+                    ctr[GMK_DBG5] / ns, ctr[GMK_DBG6] / ns, ctr[GMK_DBG7] / ns);
+        }
         if (ctr[GMK_BAD_QUAL]) { gm_set_error("Invalid Fastq Character? (negative base probability)"); return GM_E_BAD_QUAL; }
         uint32_t n_retry = small[1];
         if (n_retry && mx <= b->dev.cand_region) {

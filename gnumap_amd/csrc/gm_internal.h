@@ -59,7 +59,9 @@ struct GmRawHit { uint32_t read; uint32_t pos; float score; uint16_t step; uint8
 // device-side counters, one u64 each (see gm_counters in the public header)
 enum {
     GMK_KMERS = 0, GMK_OCC, GMK_SEEDS, GMK_SA_HITS, GMK_LF_STEPS, GMK_CANDS, GMK_NW_CELLS, GMK_ACCEPTED,
-    GMK_OVERFLOW_RS, GMK_BAD_QUAL, GMK_HEAVY_SLOTS, GMK_OCC_BLOCKS, GMK_TAB_LOOKUPS, GMK_N
+    GMK_OVERFLOW_RS, GMK_BAD_QUAL, GMK_HEAVY_SLOTS, GMK_OCC_BLOCKS, GMK_TAB_LOOKUPS,
+    GMK_DBG0, GMK_DBG1, GMK_DBG2, GMK_DBG3, GMK_DBG4, GMK_DBG5, GMK_DBG6, GMK_DBG7, GMK_DBG8,      // GM_DBG & 64: sampled phase clocks of the vote kernel
+    GMK_N
 };
 
 struct GmDevBatch {

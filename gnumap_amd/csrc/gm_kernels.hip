@@ -1084,6 +1084,521 @@ __global__ void __launch_bounds__(NT) k_vote_block(GmDevIndex ix, GmDevParams p,
     }
 }
 
+// ---- k_vote_pipe: the dense-seed vote kernel, a workgroup walks R consecutive read x strands ----------------------
+// Same algorithm as k_vote_block (counting filter -> compacted list -> exact table), rebuilt around what the counters
+// show (rocprofv3 --pmc, 1 M reads): the kernel is VALU-bound - 66 % VALU busy, ~100 vector instructions per hit, LDS only
+// 33 % busy - not latency- or LDS-bound.  So:
+//   * per-hit work is branch-light: a sentinel seed ends the prefix walk, invalid entries carry tag 64 whose read offset
+//     is 0xFFFFFFFF so their window start saturates to 0 and they drop out with the `b != 0` test every pass needs anyway;
+//   * the per-read x strand fixed cost is cut: 0 is the empty key (b = 0 never enters the table), so the zeroed filter
+//     IS the empty table; the filter is scanned and zeroed with 16-byte LDS operations; inserted slots are remembered in a
+//     list, and emit + clean-up touch only those - no 512-slot sweep, no re-zeroing of 8 KB;
+//   * the located positions of read x strand i+1 (and the seeds of i+2, by wave 0) are loaded while i is voted on;
+//     barriers are LDS-only (s_waitcnt lgkmcnt(0); s_barrier) so that they do not wait for those loads.
+// Read x strands with more than GMB_ENTRIES hits go to k_vote_fast_list through b.big_list.
+#define GMP_R 16
+#define GMP_KCAP 448                     // distinct positions the 512-slot table takes
+__device__ __forceinline__ void gm_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <bool MASK64, bool FULL, int R, int NT>
+__global__ void __launch_bounds__(NT, NT == 256 ? (R > 1 ? 6 : 8) : 5) k_vote_pipe(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
+    constexpr int U = GMB_ENTRIES / NT, TS = 512, NW = NT / 64, LSEG = GMB_LCAP / NW, ZK = 512 / NT;
+    __shared__ uint4 s_r0v[512];                     // 8 KB: counting filter (8192 x 8 bit), then keys | vals | low masks | high masks x 512
+    __shared__ uint32_t s_lbp[GMB_LCAP];
+    __shared__ uint8_t s_lt[GMB_LCAP];
+    __shared__ uint2 s_sd[2][66];                    // per seed {end of its entries in the flat hit list, SA rank of entry 0 minus its start}
+    __shared__ uint32_t s_pos[2][66], s_chunk[2][64], s_cnt0[64];
+    __shared__ uint16_t s_klist[GMP_KCAP];
+    __shared__ unsigned long long s_coff[2];
+    __shared__ uint32_t s_ns[2], s_E[2], s_nkeys[2], s_full[2], s_lcnt[NW];
+    uint32_t* const s_r0 = reinterpret_cast<uint32_t*>(s_r0v);
+    const int tid = threadIdx.x, lane = gm_lane(), wave = tid >> 6;
+    const uint32_t rs0 = blockIdx.x * R;
+    const uint32_t rs_end = (rs0 + R < 2 * b.n) ? rs0 + R : 2 * b.n;
+
+    // ---- wave 0: seeds of a read x strand, global -> registers (fetch) -> LDS buffer (commit)
+    GmSeed nx; nx.k = 0; nx.l = 0; nx.pos = 0;
+    uint32_t nx_ns = 0; unsigned long long nx_coff = 0;
+    auto fetch_seeds = [&](uint32_t rs) {
+        nx.k = 0; nx.l = 0; nx.pos = 0; nx_ns = 0; nx_coff = 0;
+        if (rs < rs_end) {
+            nx_ns = b.n_seeds[rs];
+            if ((uint32_t)lane < b.max_seeds) nx = b.seeds[(size_t)rs * b.max_seeds + lane];     // lanes >= n_seeds are masked at commit
+            if (!FULL) nx_coff = b.entry_off[rs];
+        }
+    };
+    auto commit_seeds = [&](int buf, uint32_t rs) {
+        uint32_t ns = nx_ns;
+        if (p.nw && p.fast && ns > 1) ns = 1;
+        uint32_t cnt = (uint32_t)lane < ns ? nx.l - nx.k + 1 : 0;
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+        uint32_t E0 = __shfl(incl, 63);
+        if (E0 > GMB_ENTRIES) {                      // wave-uniform: too many hits for the register path
+            if (lane == 0) { uint32_t at = atomicAdd(b.n_big, 1u); b.big_list[at] = rs; }
+            ns = 0; E0 = 0;
+        }
+        const bool real = (uint32_t)lane < ns;       // entries >= ns are sentinels: they end the walk and give offset 0xFFFFFFFF
+        s_sd[buf][lane] = real ? make_uint2(incl, nx.k - (incl - cnt)) : make_uint2(0xFFFFFFFFu, 0u);
+        s_pos[buf][lane] = real ? nx.pos : 0xFFFFFFFFu;
+        if (lane == 0) {
+            s_sd[buf][64] = make_uint2(0xFFFFFFFFu, 0u); s_pos[buf][64] = 0xFFFFFFFFu;
+            s_ns[buf] = ns; s_E[buf] = E0; s_coff[buf] = nx_coff;
+        }
+        // seed of the first entry of every 32-entry chunk; s_sd[buf] was written by this same wave, LDS operations of one
+        // wave complete in order
+        const uint32_t e = (uint32_t)lane * 32u;
+        uint32_t lo = 0, hi = ns;
+        while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (s_sd[buf][mid].x <= e) lo = mid + 1; else hi = mid; }
+        s_chunk[buf][lane] = lo;
+    };
+
+    uint32_t cc[U], tp_next[U / 4];                  // located positions in flight, their seed tags (4 x 8 bit per register)
+    auto issue = [&](int buf) {                      // loads of the read x strand whose seeds are in LDS buffer `buf`
+        const uint32_t E = s_E[buf];
+        const uint32_t* src = FULL ? ix.full_sa : b.coords + s_coff[buf];
+#pragma unroll
+        for (int q = 0; q < U / 4; ++q) tp_next[q] = 0;
+        // entry e = u * NT + tid: the seed index only grows with u, so each lane walks the seed array once
+        uint32_t t = s_chunk[buf][tid >> 5];
+        uint2 sd = s_sd[buf][t];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                // each load leaves as soon as its address is known; nothing waits for it here
+            const uint32_t e = (uint32_t)u * NT + (uint32_t)tid;
+            while (sd.x <= e) { ++t; sd = s_sd[buf][t]; }
+            const bool in = e < E;
+            cc[u] = src[in ? (FULL ? sd.y + e : e) : 0u];
+            tp_next[u >> 2] |= (in ? t : 64u) << ((u & 3) * 8);
+        }
+    };
+
+    // ---- prologue
+    if (wave == 0) {
+        fetch_seeds(rs0); commit_seeds(0, rs0);
+        if (R > 1) { fetch_seeds(rs0 + 1); commit_seeds(1, rs0 + 1); fetch_seeds(rs0 + 2); }
+    }
+#pragma unroll
+    for (int k = 0; k < ZK; ++k) s_r0v[tid + NT * k] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 64) s_cnt0[tid] = 0;
+    if (tid < 2) { s_nkeys[tid] = 0; s_full[tid] = 0; }
+    gm_lds_barrier();
+    issue(0);
+
+    for (uint32_t rs = rs0; rs < rs_end; ++rs) {
+        const int cur = (int)((rs - rs0) & 1u);
+        const uint32_t E = s_E[cur];
+        // ---- S1: take delivery of this read x strand's positions, then put the next one's loads in flight
+        uint32_t bpv[U], tp[U / 4];
+#pragma unroll
+        for (int q = 0; q < U / 4; ++q) tp[q] = tp_next[q];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t t = (tp[u >> 2] >> ((u & 3) * 8)) & 255u;
+            bpv[u] = __builtin_elementwise_sub_sat(cc[u], s_pos[cur][t]);      // :267; tag 64 (no entry) -> 0
+        }
+        if (R > 1 && rs + 1 < rs_end) issue(cur ^ 1);
+        if (E != 0) {                                // block-uniform
+            const bool filter = p.kmin >= 2 && E > 256;
+            uint32_t wcount = 0;                     // wave-uniform fill of this wave's list segment
+            if (filter) {
+                // ---- S2: pass 1, one non-returning ds_add per hit into the counting filter
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (bpv[u] != 0) {
+                        const uint32_t h = (bpv[u] * 0x9E3779B1u) >> (32 - GMB_FBITS);
+                        atomicAdd(&s_r0[h & 2047u], 1u << ((h >> 11) << 3));
+                    }
+                gm_lds_barrier();
+                // ---- S3: pass 2a, hits whose slot counted >= 2 -> list (ballot + plain stores)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    bool pass = false;
+                    if (bpv[u] != 0) {
+                        uint32_t bx = bpv[u];
+                        asm volatile("" : "+v"(bx));         // recompute the hash: 16 slot addresses kept alive from pass 1 cost 32 registers
+                        const uint32_t h = (bx * 0x9E3779B1u) >> (32 - GMB_FBITS);
+                        pass = ((s_r0[h & 2047u] >> ((h >> 11) << 3)) & 255u) >= 2u;
+                    } else {
+                        const uint32_t t = (tp[u >> 2] >> ((u & 3) * 8)) & 255u;
+                        if (t < 64u) atomicAdd(&s_cnt0[t], 1u);
+                    }
+                    const unsigned long long m = __ballot(pass);
+                    if (pass) {
+                        const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, wcount));
+                        if (at < (uint32_t)LSEG) { s_lbp[wave * LSEG + at] = bpv[u]; s_lt[wave * LSEG + at] = (uint8_t)((tp[u >> 2] >> ((u & 3) * 8)) & 255u); }
+                    }
+                    wcount += (uint32_t)__popcll(m);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool pass = bpv[u] != 0;
+                    const uint32_t t = (tp[u >> 2] >> ((u & 3) * 8)) & 255u;
+                    if (!pass && t < 64u) atomicAdd(&s_cnt0[t], 1u);
+                    const unsigned long long m = __ballot(pass);
+                    if (pass) {
+                        const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, wcount));
+                        if (at < (uint32_t)LSEG) { s_lbp[wave * LSEG + at] = bpv[u]; s_lt[wave * LSEG + at] = (uint8_t)t; }
+                    }
+                    wcount += (uint32_t)__popcll(m);
+                }
+            }
+            if (lane == 0) { s_lcnt[wave] = wcount < (uint32_t)LSEG ? wcount : (uint32_t)LSEG; if (wcount > (uint32_t)LSEG) s_full[cur] = 1; }
+            gm_lds_barrier();
+            if (filter) {
+                // ---- S4: the filter is dead: check it for saturation (a byte >= 128) and zero it - that is the empty table
+                uint32_t acc = 0;
+#pragma unroll
+                for (int k = 0; k < ZK; ++k) {
+                    const uint4 v = s_r0v[tid + NT * k];
+                    acc |= v.x | v.y | v.z | v.w;
+                    s_r0v[tid + NT * k] = make_uint4(0u, 0u, 0u, 0u);
+                }
+                if (acc & 0x80808080u) s_full[cur] = 1;
+                gm_lds_barrier();
+            }
+            // ---- S5: pass 2b, the list through the exact table (key 0 = empty)
+            uint32_t* const keys = s_r0; uint32_t* const vals = s_r0 + TS; uint32_t* const mlo = s_r0 + 2 * TS; uint32_t* const mhi = s_r0 + 3 * TS;
+            {
+                const uint32_t n_l = s_lcnt[wave];
+                bool full = false;
+                for (uint32_t i0 = 0; i0 < n_l; i0 += 64) {
+                    const uint32_t i = i0 + (uint32_t)lane;
+                    if (i < n_l) {
+                        const uint32_t bp = s_lbp[wave * LSEG + i], t = s_lt[wave * LSEG + i];
+                        uint32_t slot = (bp * 0x85EBCA6Bu) >> 23;
+                        bool found = false;
+                        for (int probe = 0; probe < TS; ++probe) {
+                            const uint32_t old = atomicCAS(&keys[slot], 0u, bp);
+                            if (old == 0u) {
+                                const uint32_t at = atomicAdd(&s_nkeys[cur], 1u);
+                                if (at < GMP_KCAP) s_klist[at] = (uint16_t)slot;
+                                found = true; break;
+                            }
+                            if (old == bp) { found = true; break; }
+                            slot = (slot + 1) & (TS - 1);
+                        }
+                        if (!found) full = true;
+                        else {
+                            atomicAdd(&vals[slot], 1u);
+                            if (t < 32) atomicOr(&mlo[slot], 1u << t);
+                            else if (MASK64) atomicOr(&mhi[slot], 1u << (t - 32));
+                        }
+                    }
+                }
+                if (full) s_full[cur] = 1;
+            }
+            gm_lds_barrier();
+            const uint32_t nk_all = s_nkeys[cur];
+            const bool failed = s_full[cur] || nk_all > GMP_KCAP;
+            // ---- S6: emit the inserted positions (NW step = kmin-th lowest step that voted) and zero their slots again
+            if (!failed) {
+                for (uint32_t i0 = 0; i0 < nk_all; i0 += NT) {       // block-uniform trip count
+                    const uint32_t i = i0 + (uint32_t)tid;
+                    bool emit = false; uint32_t key = 0, step = 0;
+                    if (i < nk_all) {
+                        const uint32_t slot = s_klist[i];
+                        key = keys[slot];
+                        const uint32_t v = vals[slot], ml = mlo[slot], mh = MASK64 ? mhi[slot] : 0u;
+                        keys[slot] = 0; vals[slot] = 0; mlo[slot] = 0; if (MASK64) mhi[slot] = 0;
+                        emit = v >= (uint32_t)p.kmin;
+                        if (emit) {
+                            if (p.nw) {
+                                unsigned long long m = (unsigned long long)ml | ((unsigned long long)mh << 32);
+                                for (int r = 1; r < p.kmin && m; ++r) m &= m - 1;
+                                step = m ? (uint32_t)(__ffsll((long long)m) - 1) : 0u;
+                            } else step = v > 65535u ? 65535u : v;
+                        }
+                    }
+                    gm_emit<GmLdsTable>(b, emit, rs, key, step, 4);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < ZK; ++k) s_r0v[tid + NT * k] = make_uint4(0u, 0u, 0u, 0u);
+            }
+            if (tid < 64) {                          // b = 0: cumulative per-step counts
+                uint32_t run = s_cnt0[tid];
+                s_cnt0[tid] = 0;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(run, off); if (lane >= off) run += t; }
+                const uint32_t total = __shfl(run, 63);
+                const unsigned long long reached = __ballot(run >= (uint32_t)p.kmin);
+                const bool emit = !failed && tid == 0 && total >= (uint32_t)p.kmin;
+                const uint32_t step = p.nw ? (uint32_t)(__ffsll((long long)reached) - 1) : (total > 65535u ? 65535u : total);
+                gm_emit<GmLdsTable>(b, emit, rs, 0u, step, 4);
+            }
+            if (failed && tid == 0) {                // hand this read x strand to the global-table kernel
+                b.rs_overflow[rs] = 1;
+                const uint32_t j = atomicAdd(b.n_retry, 1u);
+                const uint32_t need = 2 * E; uint32_t sz = 1024; while (sz < need && sz < 0x80000000u) sz <<= 1;
+                const unsigned long long off = atomicAdd(&b.counters[GMK_HEAVY_SLOTS], (unsigned long long)sz);
+                b.retry_list[j] = rs;
+                b.retry_off[j] = off;
+                atomicAdd(&b.counters[GMK_OVERFLOW_RS], 1ull);
+            }
+        } else if (R > 1) {
+            gm_lds_barrier();                        // everyone is done with s_pos[cur] before wave 0 overwrites the buffer
+        }
+        if (R > 1) {
+            if (tid == 0) { s_nkeys[cur ^ 1] = 0; s_full[cur ^ 1] = 0; }
+            if (wave == 0) { commit_seeds(cur, rs + 2); fetch_seeds(rs + 3); }
+            gm_lds_barrier();
+        }
+    }
+}
+
+// ---- k_vote_slots: the dense-seed vote kernel with wave-uniform seeds ------------------------------------------------
+// Counters (rocprofv3 --pmc, 1 M reads) show k_vote_block / k_vote_pipe issue ~85 vector and ~95 scalar instructions per
+// wave per 64 hits; most of it is per-lane bookkeeping (which seed does entry e belong to, is the entry valid, exec-mask
+// juggling).  Here the hit list of a read x strand is cut into SLOTS of up to 64 consecutive SA ranks of ONE seed
+// (ceil(hits / 64) slots per seed, seed-major).  Wave 0 turns the seeds into slot descriptors in LDS; a wave then handles
+// whole slots, so the seed (SA rank of lane 0, read offset, step tag, number of valid lanes) is wave-uniform: it lives in
+// scalar registers, the load address is `scalar base + 4 * lane`, validity is one lane compare, the b = 0 votes are one
+// ballot + popcount per slot, and every per-slot branch is a scalar branch.  The LDS phases are those of k_vote_pipe:
+// counting filter (non-returning ds_add) -> compacted list -> exact table with key 0 = empty and a list of inserted slots.
+// Read x strands that need more than GMS_SMAX slots go to k_vote_fast_list through b.big_list.
+#define GMS_SMAX 40                      // slots (64 lanes each) a read x strand may take in this kernel
+template <bool MASK64, bool FULL>
+__global__ void __launch_bounds__(128, 6) k_vote_slots(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
+    constexpr int NT = 128, NW = 2, U = GMS_SMAX / NW, TS = 512, LSEG = GMB_LCAP / NW, ZK = 512 / NT;
+    __shared__ uint4 s_r0v[512];                     // 8 KB: counting filter (8192 x 8 bit), then keys | vals | low masks | high masks x 512
+    __shared__ uint32_t s_lbp[GMB_LCAP];
+    __shared__ uint8_t s_lt[GMB_LCAP];
+    __shared__ uint2 s_desc[GMS_SMAX];               // {SA rank (flat entry index if !FULL) of lane 0, read offset | tag << 16 | (lanes - 1) << 24}
+    __shared__ uint32_t s_cnt0[64];
+    __shared__ uint32_t s_nslots, s_E, s_nkeys, s_full, s_lcnt[NW];
+    uint32_t* const s_r0 = reinterpret_cast<uint32_t*>(s_r0v);
+    const uint32_t rs = blockIdx.x;                  // grid = 2n
+    const int tid = threadIdx.x, lane = gm_lane();
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool prof = (p.dbg & 64) && (blockIdx.x & 63u) == 0 && tid == 0;      // sampled phase clocks (GM_DBG=64)
+    long long tck = prof ? clock64() : 0;
+    auto tick = [&](int slot) { if (prof) { long long now = clock64(); atomicAdd(&b.counters[GMK_DBG0 + slot], (unsigned long long)(now - tck)); tck = now; } };
+    if (wave == 0) {                                 // seeds -> slot descriptors
+        GmSeed sd; sd.k = 0; sd.l = 0; sd.pos = 0;
+        if ((uint32_t)lane < b.max_seeds) sd = b.seeds[(size_t)rs * b.max_seeds + lane];      // not waiting for n_seeds: one round trip
+        uint32_t ns = b.n_seeds[rs];
+        if (p.nw && p.fast && ns > 1) ns = 1;
+        const uint32_t cnt = (uint32_t)lane < ns ? sd.l - sd.k + 1 : 0u;
+        const uint32_t nsl = (cnt + 63u) >> 6;
+        uint32_t ie = cnt, is = nsl;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t te = __shfl_up(ie, off), ts = __shfl_up(is, off);
+            if (lane >= off) { ie += te; is += ts; }
+        }
+        uint32_t E0 = __shfl(ie, 63), S0 = __shfl(is, 63);
+        if (S0 > GMS_SMAX) {                         // wave-uniform: hand over to the list kernel
+            if (lane == 0) { const uint32_t at = atomicAdd(b.n_big, 1u); b.big_list[at] = rs; }
+            S0 = 0; E0 = 0;
+        } else {
+            const uint32_t s0 = is - nsl, e0 = ie - cnt;
+            for (uint32_t j = 0; j < nsl; ++j) {
+                const uint32_t left = cnt - 64u * j;
+                s_desc[s0 + j] = make_uint2((FULL ? sd.k : e0) + 64u * j, sd.pos | ((uint32_t)lane << 16) | ((left < 64u ? left : 64u) << 24));
+            }
+        }
+        if ((uint32_t)lane >= S0 && lane < GMS_SMAX) s_desc[lane] = make_uint2(0u, 0u);      // unused slots: no valid lane
+        s_cnt0[lane] = 0;
+        if (lane == 0) { s_nslots = S0; s_E = E0; s_nkeys = 0; s_full = 0; }
+    }
+#pragma unroll
+    for (int k = 0; k < ZK; ++k) s_r0v[tid + NT * k] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    tick(0);
+    const uint32_t nslots = s_nslots, E = s_E;
+    if (nslots == 0) return;                         // block-uniform: nothing to vote on, or handed over
+    const uint32_t* const src = FULL ? ix.full_sa : b.coords + b.entry_off[rs];
+    // ---- loads: slot s = j * NW + wave; everything about the slot is wave-uniform
+    uint32_t bpv[U], meta[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        // no branches on the slot index below: an unused slot has 0 valid lanes (its loads hit rank 0.., harmless).  Guarding
+        // the register-array updates with scalar branches makes the compiler treat the arrays as one wide vector and spill it.
+        const uint2 d = s_desc[j * NW + wave];
+        const uint32_t r0 = __builtin_amdgcn_readfirstlane(d.x);
+        meta[j] = __builtin_amdgcn_readfirstlane(d.y);
+        bpv[j] = src[r0 + (uint32_t)lane];         // lanes past the seed's last rank read the next ranks (buffers are padded); masked below
+    }
+    // ---- window starts; lanes without an entry become 0
+    uint32_t nvalid = 0;                             // entries this wave holds (scalar)
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const uint32_t pos = meta[j] & 0xFFFFu, nl = meta[j] >> 24;
+        nvalid += nl;
+        bpv[j] = (uint32_t)lane < nl ? __builtin_elementwise_sub_sat(bpv[j], pos) : 0u;      // :267
+    }
+    tick(1);
+    // b = 0 (a hit closer to the reference start than the seed's read offset) is the one position that can take several
+    // votes from one seed: counted per step.  It is rare, so it is only looked for when the number of non-zero window
+    // starts (one compare + popcount per slot) falls short of the number of entries.
+    uint32_t nnz = 0;
+#pragma unroll
+    for (int j = 0; j < U; ++j) nnz += (uint32_t)__popcll(__ballot(bpv[j] != 0u));
+    if (nnz != nvalid) {                             // wave-uniform, rare
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const uint32_t nl = meta[j] >> 24, t = (meta[j] >> 16) & 63u;
+            const unsigned long long z = __ballot((uint32_t)lane < nl && bpv[j] == 0u);
+            if (lane == 0 && z != 0ull) atomicAdd(&s_cnt0[t], (uint32_t)__popcll(z));
+        }
+    }
+    const bool filter = p.kmin >= 2 && E > 256;
+    const uint32_t thr1 = (uint32_t)(p.kmin < 100 ? p.kmin : 100);      // filter bytes saturate (>= 128 -> retry kernel), so cap the test
+    uint32_t wcount = 0;                             // wave-uniform fill of this wave's list segment
+    if (filter) {
+        // ---- pass 1: one non-returning ds_add per hit into the counting filter
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            if (bpv[j] != 0) {
+                const uint32_t h = bpv[j] ^ (bpv[j] >> 13);          // 13 slot bits: word = h[10:0], byte = h[12:11]
+                atomicAdd(&s_r0[h & 2047u], 1u << ((h >> 8) & 0x18u));
+            }
+        }
+        __syncthreads();
+        tick(2);
+        // ---- pass 2a: hits whose slot counted >= 2 -> list (ballot + plain stores)
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            bool pass = false;
+            if (bpv[j] != 0) {
+                uint32_t bx = bpv[j];
+                asm volatile("" : "+v"(bx));                 // recompute the hash instead of keeping 2 registers per slot alive
+                const uint32_t h = bx ^ (bx >> 13);
+                pass = ((s_r0[h & 2047u] >> ((h >> 8) & 0x18u)) & 255u) >= thr1;
+            }
+            const unsigned long long m = __ballot(pass);
+            if (pass) {
+                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, wcount));
+                if (at < (uint32_t)LSEG) { s_lbp[wave * LSEG + at] = bpv[j]; s_lt[wave * LSEG + at] = (uint8_t)((meta[j] >> 16) & 63u); }
+            }
+            wcount += (uint32_t)__popcll(m);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const bool pass = bpv[j] != 0;
+            const unsigned long long m = __ballot(pass);
+            if (pass) {
+                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, wcount));
+                if (at < (uint32_t)LSEG) { s_lbp[wave * LSEG + at] = bpv[j]; s_lt[wave * LSEG + at] = (uint8_t)((meta[j] >> 16) & 63u); }
+            }
+            wcount += (uint32_t)__popcll(m);
+        }
+    }
+    if (lane == 0) { s_lcnt[wave] = wcount < (uint32_t)LSEG ? wcount : (uint32_t)LSEG; if (wcount > (uint32_t)LSEG) s_full = 1; }
+    __syncthreads();
+    tick(3);
+    if (filter) {
+        // ---- the filter is dead: check it for saturation (a byte >= 128) and zero it - that is the empty table
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < ZK; ++k) {
+            const uint4 v = s_r0v[tid + NT * k];
+            acc |= v.x | v.y | v.z | v.w;
+            s_r0v[tid + NT * k] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        if (acc & 0x80808080u) s_full = 1;
+        __syncthreads();
+        tick(4);
+    }
+    // ---- pass 2b: the list is mostly single positions that shared a filter slot with another one; a linear-probing table
+    // loaded with all of them makes every wave step wait for its unluckiest lane (tens of dependent CAS round trips).  So
+    // the list goes through a second counting filter first (other hash, 16-bit counters: at most GMB_LCAP entries, no
+    // wrap), and only entries whose second slot also reached kmin enter the exact table, which then stays nearly empty.
+    // Both live in the zeroed filter memory: words [0,1024) = 2048 x 16-bit counters, words [1024,2048) = 256 slots of
+    // key | votes | low step mask | high step mask (key 0 = empty; b = 0 never gets here).
+    constexpr int T2 = 256;
+    uint32_t* const keys = s_r0 + 1024; uint32_t* const vals = keys + T2; uint32_t* const mlo = keys + 2 * T2; uint32_t* const mhi = keys + 3 * T2;
+    const uint32_t n_l = s_lcnt[wave];
+    const uint32_t thr = (uint32_t)(p.kmin < 1 ? 1 : p.kmin);
+    for (uint32_t i0 = 0; i0 < n_l; i0 += 64) {
+        const uint32_t i = i0 + (uint32_t)lane;
+        if (i < n_l) {
+            const uint32_t h2 = (s_lbp[wave * LSEG + i] * 0x85EBCA6Bu) >> 21;
+            atomicAdd(&s_r0[h2 & 1023u], 1u << ((h2 >> 10) << 4));
+        }
+    }
+    __syncthreads();
+    tick(5);
+    {
+        bool full = false;
+        uint32_t nfresh = 0;
+        for (uint32_t i0 = 0; i0 < n_l; i0 += 64) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            bool fresh = false;
+            if (i < n_l) {
+                const uint32_t bp = s_lbp[wave * LSEG + i];
+                const uint32_t h2 = (bp * 0x85EBCA6Bu) >> 21;
+                if (((s_r0[h2 & 1023u] >> ((h2 >> 10) << 4)) & 0xFFFFu) >= thr) {
+                    const uint32_t t = s_lt[wave * LSEG + i];
+                    uint32_t slot = (bp * 0x9E3779B1u) >> 24;
+                    bool found = false;
+                    for (int probe = 0; probe < T2; ++probe) {
+                        const uint32_t old = atomicCAS(&keys[slot], 0u, bp);
+                        if (old == 0u) { fresh = true; found = true; break; }
+                        if (old == bp) { found = true; break; }
+                        slot = (slot + 1) & (T2 - 1);
+                    }
+                    if (!found) full = true;
+                    else {
+                        atomicAdd(&vals[slot], 1u);
+                        if (t < 32) atomicOr(&mlo[slot], 1u << t);
+                        else if (MASK64) atomicOr(&mhi[slot], 1u << (t - 32));
+                    }
+                }
+            }
+            nfresh += (uint32_t)__popcll(__ballot(fresh));
+        }
+        if (lane == 0 && nfresh) atomicAdd(&s_nkeys, nfresh);
+        if (full) s_full = 1;
+    }
+    __syncthreads();
+    tick(6);
+    const bool failed = s_full || s_nkeys > (uint32_t)(T2 * 3 / 4);
+    if (failed) {                                    // hand this read x strand to the global-table kernel
+        if (tid == 0) {
+            b.rs_overflow[rs] = 1;
+            const uint32_t j = atomicAdd(b.n_retry, 1u);
+            const uint32_t need = 2 * E; uint32_t sz = 1024; while (sz < need && sz < 0x80000000u) sz <<= 1;
+            const unsigned long long off = atomicAdd(&b.counters[GMK_HEAVY_SLOTS], (unsigned long long)sz);
+            b.retry_list[j] = rs;
+            b.retry_off[j] = off;
+            atomicAdd(&b.counters[GMK_OVERFLOW_RS], 1ull);
+        }
+        return;
+    }
+    // ---- emit: NW step = kmin-th lowest step that voted
+#pragma unroll
+    for (int q = 0; q < T2 / NT; ++q) {
+        const uint32_t slot = (uint32_t)(q * NT + tid);
+        const uint32_t key = keys[slot], v = vals[slot];
+        const bool emit = key != 0u && v >= (uint32_t)p.kmin;
+        uint32_t step = 0;
+        if (emit) {
+            if (p.nw) {
+                unsigned long long m = (unsigned long long)mlo[slot] | (MASK64 ? ((unsigned long long)mhi[slot] << 32) : 0ull);
+                for (int r = 1; r < p.kmin && m; ++r) m &= m - 1;
+                step = m ? (uint32_t)(__ffsll((long long)m) - 1) : 0u;
+            } else step = v > 65535u ? 65535u : v;
+        }
+        gm_emit<GmLdsTable>(b, emit, rs, key, step, 4);
+    }
+    if (tid < 64) {                                  // b = 0: cumulative per-step counts
+        uint32_t run = s_cnt0[tid];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(run, off); if (lane >= off) run += t; }
+        const uint32_t total = __shfl(run, 63);
+        const unsigned long long reached = __ballot(run >= (uint32_t)p.kmin);
+        const bool emit = tid == 0 && total >= (uint32_t)p.kmin;
+        const uint32_t step = p.nw ? (uint32_t)(__ffsll((long long)reached) - 1) : (total > 65535u ? 65535u : total);
+        gm_emit<GmLdsTable>(b, emit, rs, 0u, step, 4);
+    }
+    tick(7);
+    if (prof) atomicAdd(&b.counters[GMK_DBG8], 1ull);
+}
+
 // ---- vote kernel v4 (dense seeds): seed-uniform load steps, tag filter with plain LDS stores ----------------------
 // The workgroup walks "steps": step s covers NT consecutive SA ranks of ONE seed, so the seed (its step index, SA base and
 // read offset) is wave-uniform and no per-hit table lookups are needed.  All steps' loads are issued back to back.
@@ -1859,6 +2374,34 @@ int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, in
             if (nt == 64) { if (m64) GM_LAUNCH_VS(true, 64); else GM_LAUNCH_VS(false, 64); }
             else { if (m64) GM_LAUNCH_VS(true, 128); else GM_LAUNCH_VS(false, 128); }
 #undef GM_LAUNCH_VS
+            return (int)hipGetLastError();
+        }
+        static const bool pipe_form = [] { const char* e = getenv("GM_VOTE_KERNEL"); return e && !strcmp(e, "pipe"); }();
+        static const bool slots_form = [] { const char* e = getenv("GM_VOTE_KERNEL"); return !e || !strcmp(e, "slots"); }();
+        if (slots_form) {                           // default: wave-uniform seed slots + the list kernel for what it hands over
+            const uint32_t lgrid = (uint32_t)std::min<uint64_t>(cdiv(2ull * b.n, 4), 256 * 20);
+#define GM_LAUNCH_VSL(M, F) hipLaunchKernelGGL((k_vote_slots<M, F>), dim3(2 * b.n), dim3(128), 0, S_(stream), ix, p, b)
+            if (m64) { if (use_full_sa) GM_LAUNCH_VSL(true, true); else GM_LAUNCH_VSL(true, false); }
+            else { if (use_full_sa) GM_LAUNCH_VSL(false, true); else GM_LAUNCH_VSL(false, false); }
+#undef GM_LAUNCH_VSL
+            if (m64) hipLaunchKernelGGL(k_vote_fast_list<true>, dim3(lgrid), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
+            else hipLaunchKernelGGL(k_vote_fast_list<false>, dim3(lgrid), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
+            return (int)hipGetLastError();
+        }
+        if (pipe_form) {                            // k_vote_pipe + the list kernel for what it hands over
+            static const int rr = [] { const char* e = getenv("GM_VOTE_R"); int v = e ? atoi(e) : GMP_R; return v == 1 ? 1 : GMP_R; }();
+            const uint32_t grid = (uint32_t)cdiv(2ull * b.n, (uint64_t)rr);
+            const uint32_t lgrid = (uint32_t)std::min<uint64_t>(cdiv(2ull * b.n, 4), 256 * 20);
+            static const int pnt = [] { const char* e = getenv("GM_VOTE_NT"); int v = e ? atoi(e) : 256; return v == 128 ? 128 : 256; }();
+#define GM_LAUNCH_VP(M, F, RR, N) hipLaunchKernelGGL((k_vote_pipe<M, F, RR, N>), dim3(grid), dim3(N), 0, S_(stream), ix, p, b)
+#define GM_LAUNCH_VP2(M, F) do { if (pnt == 128) { if (rr == 1) GM_LAUNCH_VP(M, F, 1, 128); else GM_LAUNCH_VP(M, F, GMP_R, 128); } \
+                                 else { if (rr == 1) GM_LAUNCH_VP(M, F, 1, 256); else GM_LAUNCH_VP(M, F, GMP_R, 256); } } while (0)
+            if (m64) { if (use_full_sa) GM_LAUNCH_VP2(true, true); else GM_LAUNCH_VP2(true, false); }
+            else { if (use_full_sa) GM_LAUNCH_VP2(false, true); else GM_LAUNCH_VP2(false, false); }
+#undef GM_LAUNCH_VP2
+#undef GM_LAUNCH_VP
+            if (m64) hipLaunchKernelGGL(k_vote_fast_list<true>, dim3(lgrid), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
+            else hipLaunchKernelGGL(k_vote_fast_list<false>, dim3(lgrid), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
             return (int)hipGetLastError();
         }
         // one-round exact table: 512 slots (13 KB of LDS per workgroup, 12 workgroups per CU) or 1024 (17 KB, 9 per CU)
