@@ -16,6 +16,7 @@
 // Arithmetic: ranks/coordinates are u32 (reference < 2^32-1 ranks); scores are fp32 with the reference's operation
 // order and NO fused multiply-add (built with -ffp-contract=off; mul/add also go through __fmul_rn/__fadd_rn).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -1359,12 +1360,14 @@ __global__ void __launch_bounds__(NT, NT == 256 ? (R > 1 ? 6 : 8) : 5) k_vote_pi
 // counting filter (non-returning ds_add) -> compacted list -> exact table with key 0 = empty and a list of inserted slots.
 // Read x strands that need more than GMS_SMAX slots go to k_vote_fast_list through b.big_list.
 #define GMS_SMAX 40                      // slots (64 lanes each) a read x strand may take in this kernel
+#define GMS_LCAP 540                     // compacted list entries per workgroup (more -> retry kernel)
 template <bool MASK64, bool FULL>
-__global__ void __launch_bounds__(128, 6) k_vote_slots(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
-    constexpr int NT = 128, NW = 2, U = GMS_SMAX / NW, TS = 512, LSEG = GMB_LCAP / NW, ZK = 512 / NT;
+__global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
+    constexpr int NT = 128, NW = 2, U = GMS_SMAX / NW, ZK = 512 / NT;
+    static_assert(NW == 2, "the list is two stacks growing towards each other");
     __shared__ uint4 s_r0v[512];                     // 8 KB: counting filter (8192 x 8 bit), then keys | vals | low masks | high masks x 512
-    __shared__ uint32_t s_lbp[GMB_LCAP];
-    __shared__ uint8_t s_lt[GMB_LCAP];
+    __shared__ uint32_t s_lbp[GMS_LCAP];
+    __shared__ uint8_t s_lt[GMS_LCAP];
     __shared__ uint2 s_desc[GMS_SMAX];               // {SA rank (flat entry index if !FULL) of lane 0, read offset | tag << 16 | (lanes - 1) << 24}
     __shared__ uint32_t s_cnt0[64];
     __shared__ uint32_t s_nslots, s_E, s_nkeys, s_full, s_lcnt[NW];
@@ -1471,7 +1474,7 @@ __global__ void __launch_bounds__(128, 6) k_vote_slots(GmDevIndex ix, GmDevParam
             const unsigned long long m = __ballot(pass);
             if (pass) {
                 const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, wcount));
-                if (at < (uint32_t)LSEG) { s_lbp[wave * LSEG + at] = bpv[j]; s_lt[wave * LSEG + at] = (uint8_t)((meta[j] >> 16) & 63u); }
+                if (at < (uint32_t)GMS_LCAP) { const uint32_t li = wave ? GMS_LCAP - 1 - at : at; s_lbp[li] = bpv[j]; s_lt[li] = (uint8_t)((meta[j] >> 16) & 63u); }
             }
             wcount += (uint32_t)__popcll(m);
         }
@@ -1482,12 +1485,14 @@ __global__ void __launch_bounds__(128, 6) k_vote_slots(GmDevIndex ix, GmDevParam
             const unsigned long long m = __ballot(pass);
             if (pass) {
                 const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, wcount));
-                if (at < (uint32_t)LSEG) { s_lbp[wave * LSEG + at] = bpv[j]; s_lt[wave * LSEG + at] = (uint8_t)((meta[j] >> 16) & 63u); }
+                if (at < (uint32_t)GMS_LCAP) { const uint32_t li = wave ? GMS_LCAP - 1 - at : at; s_lbp[li] = bpv[j]; s_lt[li] = (uint8_t)((meta[j] >> 16) & 63u); }
             }
             wcount += (uint32_t)__popcll(m);
         }
     }
-    if (lane == 0) { s_lcnt[wave] = wcount < (uint32_t)LSEG ? wcount : (uint32_t)LSEG; if (wcount > (uint32_t)LSEG) s_full = 1; }
+    // the list is one array used as two stacks: wave 0 grows up from 0, wave 1 down from the top; they only meet when the
+    // two together exceed GMS_LCAP, and then the read x strand goes to the retry kernel anyway
+    if (lane == 0) s_lcnt[wave] = wcount;
     __syncthreads();
     tick(3);
     if (filter) {
@@ -1505,18 +1510,19 @@ __global__ void __launch_bounds__(128, 6) k_vote_slots(GmDevIndex ix, GmDevParam
     }
     // ---- pass 2b: the list is mostly single positions that shared a filter slot with another one; a linear-probing table
     // loaded with all of them makes every wave step wait for its unluckiest lane (tens of dependent CAS round trips).  So
-    // the list goes through a second counting filter first (other hash, 16-bit counters: at most GMB_LCAP entries, no
+    // the list goes through a second counting filter first (other hash, 16-bit counters: at most GMS_LCAP entries, no
     // wrap), and only entries whose second slot also reached kmin enter the exact table, which then stays nearly empty.
     // Both live in the zeroed filter memory: words [0,1024) = 2048 x 16-bit counters, words [1024,2048) = 256 slots of
     // key | votes | low step mask | high step mask (key 0 = empty; b = 0 never gets here).
     constexpr int T2 = 256;
     uint32_t* const keys = s_r0 + 1024; uint32_t* const vals = keys + T2; uint32_t* const mlo = keys + 2 * T2; uint32_t* const mhi = keys + 3 * T2;
-    const uint32_t n_l = s_lcnt[wave];
+    const bool lfull = s_lcnt[0] + s_lcnt[1] > (uint32_t)GMS_LCAP;       // block-uniform
+    const uint32_t n_l = lfull ? 0u : s_lcnt[wave];
     const uint32_t thr = (uint32_t)(p.kmin < 1 ? 1 : p.kmin);
     for (uint32_t i0 = 0; i0 < n_l; i0 += 64) {
         const uint32_t i = i0 + (uint32_t)lane;
         if (i < n_l) {
-            const uint32_t h2 = (s_lbp[wave * LSEG + i] * 0x85EBCA6Bu) >> 21;
+            const uint32_t h2 = (s_lbp[wave ? GMS_LCAP - 1 - i : i] * 0x85EBCA6Bu) >> 21;
             atomicAdd(&s_r0[h2 & 1023u], 1u << ((h2 >> 10) << 4));
         }
     }
@@ -1529,10 +1535,11 @@ __global__ void __launch_bounds__(128, 6) k_vote_slots(GmDevIndex ix, GmDevParam
             const uint32_t i = i0 + (uint32_t)lane;
             bool fresh = false;
             if (i < n_l) {
-                const uint32_t bp = s_lbp[wave * LSEG + i];
+                const uint32_t li = wave ? GMS_LCAP - 1 - i : i;
+                const uint32_t bp = s_lbp[li];
                 const uint32_t h2 = (bp * 0x85EBCA6Bu) >> 21;
                 if (((s_r0[h2 & 1023u] >> ((h2 >> 10) << 4)) & 0xFFFFu) >= thr) {
-                    const uint32_t t = s_lt[wave * LSEG + i];
+                    const uint32_t t = s_lt[li];
                     uint32_t slot = (bp * 0x9E3779B1u) >> 24;
                     bool found = false;
                     for (int probe = 0; probe < T2; ++probe) {
@@ -1556,7 +1563,7 @@ __global__ void __launch_bounds__(128, 6) k_vote_slots(GmDevIndex ix, GmDevParam
     }
     __syncthreads();
     tick(6);
-    const bool failed = s_full || s_nkeys > (uint32_t)(T2 * 3 / 4);
+    const bool failed = lfull || s_full || s_nkeys > (uint32_t)(T2 * 3 / 4);
     if (failed) {                                    // hand this read x strand to the global-table kernel
         if (tid == 0) {
             b.rs_overflow[rs] = 1;
@@ -2075,7 +2082,10 @@ __global__ void __launch_bounds__(256) k_nw_lane(GmDevIndex ix, GmDevParams p, G
             uint2 bw = *reinterpret_cast<const uint2*>(rb + (chunk << 3)), qw = *reinterpret_cast<const uint2*>(rq + (chunk << 3));
             uint2 bn = bw, qn = qw;
             { int nc = chunk + cstep; if (nc >= 0 && nc < nchunk) { bn = *reinterpret_cast<const uint2*>(rb + (nc << 3)); qn = *reinterpret_cast<const uint2*>(rq + (nc << 3)); } }
-            for (int i = Li - 1; i >= 0; --i) {
+            // one DP row.  EDGE = the row touches column L, row L or column -1 (the first 4 and the last 3 rows); the rows in
+            // between - nearly all of them - need none of those tests
+            auto dp_row = [&](const int i, auto edge_tag) {
+                constexpr bool EDGE = decltype(edge_tag)::value;
                 // PWM row i in strand orientation (reverse_comp_cpy SequenceOperations.h:149-161)
                 const int src = strand ? Li - 1 - i : i;
                 if ((src >> 3) != chunk) {
@@ -2093,30 +2103,40 @@ __global__ void __launch_bounds__(256) k_nw_lane(GmDevIndex ix, GmDevParams p, G
                 float v4[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) v4[g] = gm_get_val(code, pq.x, pq.y, sg[g]);
-                const float lastcol = __fmul_rn(gap, (float)(unsigned)(Li - i));        // nm[i][L] = gGAP * (L - i)
+                const float lastcol = EDGE ? __fmul_rn(gap, (float)(unsigned)(Li - i)) : 0.0f;      // nm[i][L] = gGAP * (L - i)
 #pragma unroll
                 for (int d = 6; d >= 0; --d) {
                     const int j = i + d - 3;
-                    float val = W[d] == 0 ? v4[0] : W[d] == 1 ? v4[1] : W[d] == 2 ? v4[2] : v4[3];
-                    float up = d > 0 ? P[d - 1] : ((i + 1 == Li) ? gap4 : GM_NEG_INF);      // nm[i+1][j]
-                    float left = d < 6 ? C[d + 1] : ((j + 1 == Li) ? gap4 : GM_NEG_INF);     // nm[i][j+1]
-                    float mm = __fadd_rn(P[d], val);
-                    float g1 = __fadd_rn(up, gap);
-                    float g2 = __fadd_rn(left, gap);
-                    float best = gm_max3(mm, g1, g2);
-                    C[d] = (j >= 0 && j < Li) ? best : (j == Li ? lastcol : GM_NEG_INF);
-                }
-                {
-                    int lo = i - 3 < 0 ? 0 : i - 3, hi = i + 3 >= Li ? Li - 1 : i + 3;
-                    cells += (unsigned long long)(hi - lo + 1);
+                    const float lo = (W[d] & 1u) ? v4[1] : v4[0], hi = (W[d] & 1u) ? v4[3] : v4[2];
+                    const float val = (W[d] & 2u) ? hi : lo;
+                    const float up = d > 0 ? P[d - 1] : ((EDGE && i + 1 == Li) ? gap4 : GM_NEG_INF);        // nm[i+1][j]
+                    const float left = d < 6 ? C[d + 1] : ((EDGE && j + 1 == Li) ? gap4 : GM_NEG_INF);       // nm[i][j+1]
+                    const float mm = __fadd_rn(P[d], val);
+                    const float g1 = __fadd_rn(up, gap);
+                    const float g2 = __fadd_rn(left, gap);
+                    // bin_seq::max_flt (src/bin_seq.cpp:1013-1026) is a compare chain; on finite, never-negative-zero operands it
+                    // returns the same bits as max(): one v_max3_f32
+                    const float best = fmaxf(fmaxf(mm, g1), g2);
+                    if (EDGE) C[d] = (j >= 0 && j < Li) ? best : (j == Li ? lastcol : GM_NEG_INF);
+                    else C[d] = best;
                 }
 #pragma unroll
                 for (int d = 0; d < 7; ++d) P[d] = C[d];
                 // slide the window bases to row i-1
 #pragma unroll
                 for (int d = 6; d >= 1; --d) W[d] = W[d - 1];
-                W[0] = (i - 4 >= 0) ? wcode(i - 4) : 0u;
+                W[0] = (!EDGE || i - 4 >= 0) ? wcode(i - 4) : 0u;
+            };
+            {
+                int i = Li - 1;
+                const int mid_hi = Li - 5, mid_lo = 4;                          // rows [mid_lo, mid_hi] are interior (also wcode(i - 4) is in range)
+                for (; i >= 0 && i > mid_hi; --i) dp_row(i, std::true_type{});
+                for (; i >= mid_lo; --i) dp_row(i, std::false_type{});
+                for (; i >= 0; --i) dp_row(i, std::true_type{});
             }
+            // cells inside the band (counter only): sum over rows of min(i+3, L-1) - max(i-3, 0) + 1
+            if (Li >= 7) cells += (unsigned long long)(7 * Li - 12);
+            else for (int i = 0; i < Li; ++i) { int lo = i - 3 < 0 ? 0 : i - 3, hi = i + 3 >= Li ? Li - 1 : i + 3; cells += (unsigned long long)(hi - lo + 1); }
             result = P[3];                                                      // nm[0][0]
         } else if (!p.nw) {
             result = (float)c.step;                                             // --no_nw: the score is the vote count (:70-76)
