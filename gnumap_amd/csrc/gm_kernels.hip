@@ -1422,7 +1422,8 @@ __global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParam
         const uint2 d = s_desc[j * NW + wave];
         const uint32_t r0 = __builtin_amdgcn_readfirstlane(d.x);
         meta[j] = __builtin_amdgcn_readfirstlane(d.y);
-        bpv[j] = src[r0 + (uint32_t)lane];         // lanes past the seed's last rank read the next ranks (buffers are padded); masked below
+        const uint32_t* const sp = src + r0;       // scalar base + 4 * lane
+        bpv[j] = sp[lane];                         // lanes past the seed's last rank read the next ranks (buffers are padded); masked below
     }
     // ---- window starts; lanes without an entry become 0
     uint32_t nvalid = 0;                             // entries this wave holds (scalar)
@@ -1455,7 +1456,9 @@ __global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParam
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             if (bpv[j] != 0) {
-                const uint32_t h = bpv[j] ^ (bpv[j] >> 13);          // 13 slot bits: word = h[10:0], byte = h[12:11]
+                // slot = the low 13 bits of the window start as they are (SA hits are spread evenly; positions a multiple of
+                // 8192 apart share a slot, which only sends them on to the second filter): word = b[10:0], byte = b[12:11]
+                const uint32_t h = bpv[j];
                 atomicAdd(&s_r0[h & 2047u], 1u << ((h >> 8) & 0x18u));
             }
         }
@@ -1468,7 +1471,7 @@ __global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParam
             if (bpv[j] != 0) {
                 uint32_t bx = bpv[j];
                 asm volatile("" : "+v"(bx));                 // recompute the hash instead of keeping 2 registers per slot alive
-                const uint32_t h = bx ^ (bx >> 13);
+                const uint32_t h = bx;
                 pass = ((s_r0[h & 2047u] >> ((h >> 8) & 0x18u)) & 255u) >= thr1;
             }
             const unsigned long long m = __ballot(pass);
@@ -1519,27 +1522,43 @@ __global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParam
     const bool lfull = s_lcnt[0] + s_lcnt[1] > (uint32_t)GMS_LCAP;       // block-uniform
     const uint32_t n_l = lfull ? 0u : s_lcnt[wave];
     const uint32_t thr = (uint32_t)(p.kmin < 1 ? 1 : p.kmin);
-    for (uint32_t i0 = 0; i0 < n_l; i0 += 64) {
-        const uint32_t i = i0 + (uint32_t)lane;
-        if (i < n_l) {
-            const uint32_t h2 = (s_lbp[wave ? GMS_LCAP - 1 - i : i] * 0x85EBCA6Bu) >> 21;
-            atomicAdd(&s_r0[h2 & 1023u], 1u << ((h2 >> 10) << 4));
+    for (uint32_t i0 = 0; i0 < n_l; i0 += 256) {     // four wave steps at a time: their list reads are in flight together
+        uint32_t bp4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t i = i0 + 64u * q + (uint32_t)lane;
+            bp4[q] = i < n_l ? s_lbp[wave ? GMS_LCAP - 1 - i : i] : 0u;
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (bp4[q] != 0u) {
+                const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> 21;
+                atomicAdd(&s_r0[h2 & 1023u], 1u << ((h2 >> 10) << 4));
+            }
     }
     __syncthreads();
     tick(5);
     {
         bool full = false;
         uint32_t nfresh = 0;
-        for (uint32_t i0 = 0; i0 < n_l; i0 += 64) {
-            const uint32_t i = i0 + (uint32_t)lane;
-            bool fresh = false;
-            if (i < n_l) {
-                const uint32_t li = wave ? GMS_LCAP - 1 - i : i;
-                const uint32_t bp = s_lbp[li];
-                const uint32_t h2 = (bp * 0x85EBCA6Bu) >> 21;
-                if (((s_r0[h2 & 1023u] >> ((h2 >> 10) << 4)) & 0xFFFFu) >= thr) {
-                    const uint32_t t = s_lt[li];
+        for (uint32_t i0 = 0; i0 < n_l; i0 += 256) {
+            uint32_t bp4[4], c4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t i = i0 + 64u * q + (uint32_t)lane;
+                bp4[q] = i < n_l ? s_lbp[wave ? GMS_LCAP - 1 - i : i] : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> 21;
+                c4[q] = (s_r0[h2 & 1023u] >> ((h2 >> 10) << 4)) & 0xFFFFu;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bool fresh = false;
+                if (bp4[q] != 0u && c4[q] >= thr) {
+                    const uint32_t i = i0 + 64u * q + (uint32_t)lane;
+                    const uint32_t bp = bp4[q], t = s_lt[wave ? GMS_LCAP - 1 - i : i];
                     uint32_t slot = (bp * 0x9E3779B1u) >> 24;
                     bool found = false;
                     for (int probe = 0; probe < T2; ++probe) {
@@ -1555,8 +1574,8 @@ __global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParam
                         else if (MASK64) atomicOr(&mhi[slot], 1u << (t - 32));
                     }
                 }
+                nfresh += (uint32_t)__popcll(__ballot(fresh));
             }
-            nfresh += (uint32_t)__popcll(__ballot(fresh));
         }
         if (lane == 0 && nfresh) atomicAdd(&s_nkeys, nfresh);
         if (full) s_full = 1;
@@ -1576,21 +1595,44 @@ __global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParam
         }
         return;
     }
-    // ---- emit: NW step = kmin-th lowest step that voted
+    // ---- emit: NW step = kmin-th lowest step that voted.  Each lane looks at two table slots; the wave reserves room in its
+    // candidate shard for both with ONE returning global atomic (that round trip is the tail of the workgroup's life)
+    {
+        static_assert(T2 / NT == 2, "two table slots per lane");
+        bool em[2]; uint32_t ky[2], st[2];
 #pragma unroll
-    for (int q = 0; q < T2 / NT; ++q) {
-        const uint32_t slot = (uint32_t)(q * NT + tid);
-        const uint32_t key = keys[slot], v = vals[slot];
-        const bool emit = key != 0u && v >= (uint32_t)p.kmin;
-        uint32_t step = 0;
-        if (emit) {
-            if (p.nw) {
-                unsigned long long m = (unsigned long long)mlo[slot] | (MASK64 ? ((unsigned long long)mhi[slot] << 32) : 0ull);
-                for (int r = 1; r < p.kmin && m; ++r) m &= m - 1;
-                step = m ? (uint32_t)(__ffsll((long long)m) - 1) : 0u;
-            } else step = v > 65535u ? 65535u : v;
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t slot = (uint32_t)(q * NT + tid);
+            const uint32_t key = keys[slot], v = vals[slot];
+            em[q] = key != 0u && v >= (uint32_t)p.kmin;
+            ky[q] = key; st[q] = 0;
+            if (em[q]) {
+                if (p.nw) {
+                    unsigned long long m = (unsigned long long)mlo[slot] | (MASK64 ? ((unsigned long long)mhi[slot] << 32) : 0ull);
+                    for (int r = 1; r < p.kmin && m; ++r) m &= m - 1;
+                    st[q] = m ? (uint32_t)(__ffsll((long long)m) - 1) : 0u;
+                } else st[q] = v > 65535u ? 65535u : v;
+            }
         }
-        gm_emit<GmLdsTable>(b, emit, rs, key, step, 4);
+        const unsigned long long m0 = __ballot(em[0]), m1 = __ballot(em[1]);
+        const uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1);
+        if (n0 + n1 != 0u) {                         // wave-uniform
+            const uint32_t shard = blockIdx.x & (GM_NSHARD - 1);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&b.shard_cnt[shard * GM_SHARD_STRIDE], n0 + n1);
+            base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (em[q]) {
+                    const unsigned long long mq = q ? m1 : m0;
+                    const uint32_t idx = base + (q ? n0 : 0u) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
+                    if (idx < b.cand_region) {
+                        GmCand c;
+                        c.rs = rs; c.b = ky[q]; c.step = (uint16_t)st[q]; c.flags = 4; c.pad = 0; c.score = 0.0f;
+                        b.cands[(size_t)shard * b.cand_region + idx] = c;
+                    }
+                }
+        }
     }
     if (tid < 64) {                                  // b = 0: cumulative per-step counts
         uint32_t run = s_cnt0[tid];
