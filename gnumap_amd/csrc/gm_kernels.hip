@@ -1434,27 +1434,16 @@ __global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParam
         bpv[j] = (uint32_t)lane < nl ? __builtin_elementwise_sub_sat(bpv[j], pos) : 0u;      // :267
     }
     tick(1);
-    // b = 0 (a hit closer to the reference start than the seed's read offset) is the one position that can take several
-    // votes from one seed: counted per step.  It is rare, so it is only looked for when the number of non-zero window
-    // starts (one compare + popcount per slot) falls short of the number of entries.
-    uint32_t nnz = 0;
-#pragma unroll
-    for (int j = 0; j < U; ++j) nnz += (uint32_t)__popcll(__ballot(bpv[j] != 0u));
-    if (nnz != nvalid) {                             // wave-uniform, rare
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const uint32_t nl = meta[j] >> 24, t = (meta[j] >> 16) & 63u;
-            const unsigned long long z = __ballot((uint32_t)lane < nl && bpv[j] == 0u);
-            if (lane == 0 && z != 0ull) atomicAdd(&s_cnt0[t], (uint32_t)__popcll(z));
-        }
-    }
     const bool filter = p.kmin >= 2 && E > 256;
     const uint32_t thr1 = (uint32_t)(p.kmin < 100 ? p.kmin : 100);      // filter bytes saturate (>= 128 -> retry kernel), so cap the test
     uint32_t wcount = 0;                             // wave-uniform fill of this wave's list segment
+    uint32_t nnz = 0;                                // non-zero window starts of this wave (scalar)
+    const int lorg = wave ? GMS_LCAP - 1 : 0, ldir = wave ? -1 : 1;       // the list is two stacks (see below)
     if (filter) {
         // ---- pass 1: one non-returning ds_add per hit into the counting filter
 #pragma unroll
         for (int j = 0; j < U; ++j) {
+            nnz += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(bpv[j] != 0u));
             if (bpv[j] != 0) {
                 // slot = the low 13 bits of the window start as they are (SA hits are spread evenly; positions a multiple of
                 // 8192 apart share a slot, which only sends them on to the second filter): word = b[10:0], byte = b[12:11]
@@ -1462,22 +1451,37 @@ __global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParam
                 atomicAdd(&s_r0[h & 2047u], 1u << ((h >> 8) & 0x18u));
             }
         }
+    } else {
+#pragma unroll
+        for (int j = 0; j < U; ++j) nnz += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(bpv[j] != 0u));
+    }
+    // b = 0 (a hit closer to the reference start than the seed's read offset) is the one position that can take several
+    // votes from one seed: counted per step.  It is rare, so it is only looked for when the number of non-zero window
+    // starts (popcount of the compare pass 1 makes anyway) falls short of the number of entries.
+    if (nnz != nvalid) {                             // wave-uniform, rare
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const uint32_t m = __builtin_amdgcn_readfirstlane(s_desc[j * NW + wave].y);
+            const uint32_t nl = m >> 24, t = (m >> 16) & 63u;
+            const unsigned long long z = __builtin_amdgcn_ballot_w64((uint32_t)lane < nl && bpv[j] == 0u);
+            if (lane == 0 && z != 0ull) atomicAdd(&s_cnt0[t], (uint32_t)__popcll(z));
+        }
+    }
+    if (filter) {
         __syncthreads();
         tick(2);
-        // ---- pass 2a: hits whose slot counted >= 2 -> list (ballot + plain stores)
+        // ---- pass 2a: hits whose slot counted >= kmin -> list (ballot + plain stores)
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             bool pass = false;
             if (bpv[j] != 0) {
-                uint32_t bx = bpv[j];
-                asm volatile("" : "+v"(bx));                 // recompute the hash instead of keeping 2 registers per slot alive
-                const uint32_t h = bx;
+                const uint32_t h = bpv[j];
                 pass = ((s_r0[h & 2047u] >> ((h >> 8) & 0x18u)) & 255u) >= thr1;
             }
-            const unsigned long long m = __ballot(pass);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
             if (pass) {
                 const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, wcount));
-                if (at < (uint32_t)GMS_LCAP) { const uint32_t li = wave ? GMS_LCAP - 1 - at : at; s_lbp[li] = bpv[j]; s_lt[li] = (uint8_t)((meta[j] >> 16) & 63u); }
+                if (at < (uint32_t)GMS_LCAP) { const uint32_t li = (uint32_t)(lorg + ldir * (int)at); s_lbp[li] = bpv[j]; s_lt[li] = (uint8_t)(j * NW + wave); }   // slot id; its seed's step is looked up later, for the few that survive
             }
             wcount += (uint32_t)__popcll(m);
         }
@@ -1485,10 +1489,10 @@ __global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParam
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const bool pass = bpv[j] != 0;
-            const unsigned long long m = __ballot(pass);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
             if (pass) {
                 const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, wcount));
-                if (at < (uint32_t)GMS_LCAP) { const uint32_t li = wave ? GMS_LCAP - 1 - at : at; s_lbp[li] = bpv[j]; s_lt[li] = (uint8_t)((meta[j] >> 16) & 63u); }
+                if (at < (uint32_t)GMS_LCAP) { const uint32_t li = (uint32_t)(lorg + ldir * (int)at); s_lbp[li] = bpv[j]; s_lt[li] = (uint8_t)(j * NW + wave); }
             }
             wcount += (uint32_t)__popcll(m);
         }
@@ -1558,7 +1562,7 @@ __global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParam
                 bool fresh = false;
                 if (bp4[q] != 0u && c4[q] >= thr) {
                     const uint32_t i = i0 + 64u * q + (uint32_t)lane;
-                    const uint32_t bp = bp4[q], t = s_lt[wave ? GMS_LCAP - 1 - i : i];
+                    const uint32_t bp = bp4[q], t = (s_desc[s_lt[wave ? GMS_LCAP - 1 - i : i]].y >> 16) & 63u;
                     uint32_t slot = (bp * 0x9E3779B1u) >> 24;
                     bool found = false;
                     for (int probe = 0; probe < T2; ++probe) {
@@ -1574,7 +1578,7 @@ __global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParam
                         else if (MASK64) atomicOr(&mhi[slot], 1u << (t - 32));
                     }
                 }
-                nfresh += (uint32_t)__popcll(__ballot(fresh));
+                nfresh += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(fresh));
             }
         }
         if (lane == 0 && nfresh) atomicAdd(&s_nkeys, nfresh);
@@ -1614,7 +1618,7 @@ __global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParam
                 } else st[q] = v > 65535u ? 65535u : v;
             }
         }
-        const unsigned long long m0 = __ballot(em[0]), m1 = __ballot(em[1]);
+        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(em[0]), m1 = __builtin_amdgcn_ballot_w64(em[1]);
         const uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1);
         if (n0 + n1 != 0u) {                         // wave-uniform
             const uint32_t shard = blockIdx.x & (GM_NSHARD - 1);
@@ -1639,7 +1643,7 @@ __global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParam
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(run, off); if (lane >= off) run += t; }
         const uint32_t total = __shfl(run, 63);
-        const unsigned long long reached = __ballot(run >= (uint32_t)p.kmin);
+        const unsigned long long reached = __builtin_amdgcn_ballot_w64(run >= (uint32_t)p.kmin);
         const bool emit = tid == 0 && total >= (uint32_t)p.kmin;
         const uint32_t step = p.nw ? (uint32_t)(__ffsll((long long)reached) - 1) : (total > 65535u ? 65535u : total);
         gm_emit<GmLdsTable>(b, emit, rs, 0u, step, 4);

@@ -113,6 +113,7 @@ CONFIGS = {
     "fast_k1": dict(fast=1, mer=14, jump=14, min_seed_hits=1),
     "raw60": dict(align_score=60.0, align_is_fraction=0),
     "a07_q50": dict(align_score=0.7, cutoff=50.0),
+    "m6_j2": dict(mer=6, jump=2),                               # 48 seeds x ~70 hits per strand: > 32 seeds (64-bit step masks), > 40 slots (list kernel)
 }
 
 
@@ -376,10 +377,14 @@ def test_pipelined_sub_batches_equal_single_pass(ix_full, syn_reads, packed, mon
     assert len(first) == len(last) and np.array_equal(first["pos"], last["pos"])
 
 
-@pytest.mark.parametrize("env", [dict(GM_VOTE="block"), dict(GM_VOTE="block", GM_VOTE_KERNEL="steps"), dict(GM_VOTE="block", GM_VOTE_NT="64"),
-                                 dict(GM_VOTE="block", GM_VOTE_NT="256"), dict(GM_VOTE="block", GM_VOTE_TB="10"), dict(GM_VOTE="wave"), dict(GM_VOTE="wave", GM_VOTE_SPARSE="0"),
+@pytest.mark.parametrize("env", [dict(GM_VOTE="block"),                                             # dense seeds: k_vote_slots (the default dense kernel)
+                                 dict(GM_VOTE="block", GM_VOTE_KERNEL="block"), dict(GM_VOTE="block", GM_VOTE_KERNEL="block", GM_VOTE_NT="64"),
+                                 dict(GM_VOTE="block", GM_VOTE_KERNEL="block", GM_VOTE_NT="256"), dict(GM_VOTE="block", GM_VOTE_KERNEL="block", GM_VOTE_TB="10"),
+                                 dict(GM_VOTE="block", GM_VOTE_KERNEL="steps"), dict(GM_VOTE="block", GM_VOTE_KERNEL="pipe"),
+                                 dict(GM_VOTE="block", GM_VOTE_KERNEL="pipe", GM_VOTE_NT="128", GM_VOTE_R="1"),
+                                 dict(GM_VOTE="wave"), dict(GM_VOTE="wave", GM_VOTE_SPARSE="0"),
                                  dict(GM_NW="wave"), dict(GM_KMER_TABLE="0"), dict(GM_KMER_TABLE="6")])
-@pytest.mark.parametrize("cfg", ["default", "no_nw", "k3", "h30"])
+@pytest.mark.parametrize("cfg", ["default", "no_nw", "k3", "h30", "m6_j2"])
 def test_every_kernel_variant_matches_oracle(env, cfg, syn_fa, oracle, oix, syn_reads, packed):
     """the dispatch heuristics pick kernels by seed density; force each variant on the same inputs (fresh process state is
     not needed: the switches are read per launch or cached per variant name)"""

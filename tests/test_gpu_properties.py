@@ -141,3 +141,32 @@ def test_sample_agrees_with_oracle(big, oracle):
             assert np.float32(m["score"]).view(np.uint32) == np.float32(hh["score"]).view(np.uint32)
             assert [(int(q["pos"]), int(q["strand"])) for q in res["positions"][m["pos_begin"]:m["pos_end"]]] == [(int(a), int(b)) for a, b in hh["pos"]]
     batch.destroy()
+
+
+def test_multi_slot_seeds_agree_with_oracle(big, oracle):
+    """-m 9 -j 9 on 20 Mbp: ~76 SA hits per seed, i.e. two 64-lane slots per seed and ~800 hits per read x strand, the regime
+    of BASELINE configs[1] (k_vote_slots: counting filter, second filter, exact table) checked read by read"""
+    n = 3000
+    B, Q, Ln, pos, strand = _exact_reads(big, n)
+    L = 100
+    rng = big["rng"]
+    sub = rng.random((n, L)) < 0.03
+    B[:, :L] = np.where(sub, ACGT[(np.searchsorted(ACGT, B[:, :L]) + rng.integers(1, 4, (n, L))) % 4], B[:, :L])
+    kw = dict(mer=9, jump=9)
+    p = g.Params(**kw); op = oracle.params(**kw)
+    batch = g.Batch(big["ix"], n, B.shape[1])
+    res = batch.map(p, B, Q, Ln)
+    c = batch.counters()
+    assert c["sa_hits"] > 600 * 2 * n and c["vote_retries"] == 0
+    oix = oracle.index_load(big["fa"])
+    mb = res["match_begin"]
+    for i in rng.integers(0, n, 200):
+        seq = B[i, :L].tobytes(); qual = Q[i, :L].tobytes()
+        o = oracle.map_read(oix, op, oracle.pwm(seq, qual), seq)
+        assert res["status"][i] == o["status"] and res["denominator"][i] == o["denominator"] and res["top_score"][i] == o["top_score"]
+        ms = res["matches"][int(mb[i]):int(mb[i + 1])]
+        assert len(ms) == len(o["hits"])
+        for m, hh in zip(ms, o["hits"]):
+            assert np.float32(m["score"]).view(np.uint32) == np.float32(hh["score"]).view(np.uint32)
+            assert [(int(q["pos"]), int(q["strand"])) for q in res["positions"][m["pos_begin"]:m["pos_end"]]] == [(int(a), int(b)) for a, b in hh["pos"]]
+    batch.destroy()
