@@ -219,7 +219,7 @@ def main():
     # the one collective of the path: RCCL all-reduce of the device-resident coverage track (once per run, outside the
     # per-step loop, like the reference's MPI Allreduce at end of run: src/Driver.cpp:1660-1672)
     allreduce_ms = None
-    if world > 1:
+    if world > 1 or os.environ.get("GM_FORCE_DIST") == "1":
         cov = gd.DeviceTrack(ix.coverage_device_ptr(), ix.coverage_bins()).tensor(dev)
         torch.cuda.synchronize(); barrier()
         ta = time.perf_counter()
@@ -274,8 +274,7 @@ def main():
             "pcie_inclusive_reads_per_s": round(pcie_inclusive, 1),
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    gd.shutdown()
 
 
 if __name__ == "__main__":

@@ -14,7 +14,9 @@ def env_rank():
 
 def init(backend, device=None):
     rank, world, _ = env_rank()
-    if world > 1 and not dist.is_initialized():
+    # GM_FORCE_DIST=1: initialise the process group for a single rank too (rehearses the RCCL path on a one-GPU box)
+    if (world > 1 or os.environ.get("GM_FORCE_DIST") == "1") and not dist.is_initialized():
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         if backend == "nccl":
@@ -22,6 +24,11 @@ def init(backend, device=None):
         else:
             dist.init_process_group(backend)
     return rank, world
+
+
+def shutdown():
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def barrier():
@@ -56,10 +63,19 @@ def sum_over_ranks(value, device="cpu"):
 
 
 def allreduce_coverage(track):
-    """in-place SUM all-reduce of a float32 coverage track (a CPU tensor under gloo, the HBM-resident track under nccl)"""
+    """in-place SUM all-reduce of a float32 coverage track (a CPU tensor under gloo, the HBM-resident track under nccl).
+    A device track is a view of memory the library allocated, not the torch allocator: the collective runs on a torch-owned
+    staging tensor (two device-to-device copies of the track, outside the timed region) so that ProcessGroupNCCL only ever
+    sees storage it can record streams on."""
     assert track.dtype == torch.float32
     if dist.is_available() and dist.is_initialized():
-        dist.all_reduce(track, op=dist.ReduceOp.SUM)
+        if track.is_cuda:
+            stage = torch.empty_like(track)
+            stage.copy_(track)
+            dist.all_reduce(stage, op=dist.ReduceOp.SUM)
+            track.copy_(stage)
+        else:
+            dist.all_reduce(track, op=dist.ReduceOp.SUM)
     return track
 
 
