@@ -87,6 +87,7 @@ struct gm_index {
     // parameter tables resident in HBM: S256 (256x4 floats) + lut (512 float2)
     std::vector<float> ptab_host;
     std::map<int, DevBuf> kmer_tabs;        // memoised backward search of the last T characters of a seed, per T
+    std::map<int, DevBuf> kmer_ctabs;       // its compact form (16 B per 8 codes), per T
     std::mutex mu;
     uint64_t hbm_bytes = 0;
 };
@@ -213,7 +214,7 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
     { const char* e = getenv("GM_DBG"); dp.dbg = e ? atoi(e) : 0; }
     // k-mer interval table: the last T = min(mer, 12) characters of every seed are one 8-byte lookup (GM_KMER_TABLE=0
     // keeps the pure occ walk; GM_KMER_TABLE=<T> picks another suffix length)
-    dp.kmer_tab = nullptr; dp.kmer_T = 0;
+    dp.kmer_tab = nullptr; dp.kmer_T = 0; dp.kmer_ctab = nullptr;
     {
         int T = std::min(p->mer, 12);
         if (const char* e = getenv("GM_KMER_TABLE")) T = std::min(std::min(atoi(e), p->mer), 13);
@@ -227,6 +228,17 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
                 ix->hbm_bytes += tb.cap;
             }
             dp.kmer_tab = tb.as<uint2>(); dp.kmer_T = T;
+            static const bool compact = [] { const char* e = getenv("GM_KMER_COMPACT"); return !(e && !strcmp(e, "0")); }();
+            if (compact) {
+                DevBuf& cb = ix->kmer_ctabs[T];
+                if (!cb.p) {
+                    if (cb.ensure(((size_t)1 << (2 * T - 3)) * 16)) return GM_E_NOMEM;
+                    KCHK(gmk_build_kmer_compact(tb.as<uint2>(), cb.as<uint4>(), T, st));
+                    HIPCHK(hipStreamSynchronize(st));
+                    ix->hbm_bytes += cb.cap;
+                }
+                dp.kmer_ctab = cb.as<uint4>();
+            }
         }
     }
     dp.hcap = p->max_kmer_hits; dp.gap = p->gap; dp.align_score = p->align_score; dp.cutoff = p->cutoff;
@@ -323,6 +335,7 @@ extern "C" void gm_index_close(gm_index* ix) {
         ix->d_bwt.release(); ix->d_sa.release(); ix->d_full.release(); ix->d_pac.release(); ix->d_contig.release();
         ix->d_cov.release(); ix->d_ptab.release(); ix->d_planes.release(); ix->d_nuc.release();
         for (auto& kv : ix->kmer_tabs) kv.second.release();
+        for (auto& kv : ix->kmer_ctabs) kv.second.release();
     }
     delete ix;
 }

@@ -36,6 +36,7 @@ struct GmDevParams {
                                     // the DP with rows 'a','c','g','t' (genome windows are lowercase acgt)
     const uint2* kmer_tab;          // SA interval of every kmer_T-mer (suffix of the seed k-mer), or null: {k,l}; empty = {0xFFFFFFFF, depth}
     int kmer_T;
+    const uint4* kmer_ctab;         // compact form of kmer_tab, 16 B per 8 consecutive codes: {first SA rank, 8 x u8 hit counts (2 words), escape flag}; null = not built
     const float2* lut;              // [0..255] Phred+33, [256..511] Phred+64: (p, (1-p)/3) as fp32; p = NaN when negative
 };
 
@@ -104,6 +105,7 @@ extern "C++" {
 int gmk_expand_full_sa(const GmDevIndex& ix, uint32_t* full_sa, void* stream);
 int gmk_build_occ_planes(const GmDevIndex& ix, uint4* planes, uint32_t nblk, void* stream);
 int gmk_build_kmer_table(const GmDevIndex& ix, uint2* tab, int T, void* stream);
+int gmk_build_kmer_compact(const uint2* tab, uint4* ctab, int T, void* stream);
 int gmk_prep(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream);
 int gmk_seed(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream);
 int gmk_scan_entries(const GmDevBatch& b, void* stream);

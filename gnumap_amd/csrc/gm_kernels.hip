@@ -221,17 +221,74 @@ __global__ void __launch_bounds__(256) k_build_kmer_table(GmDevIndex ix, uint2* 
     tab[code] = out;
 }
 
+// Compact form of the k-mer table for the seed kernel: the SA intervals of lexicographically consecutive T-mers are adjacent
+// (apart from the few suffixes shorter than T), so 8 consecutive codes need one start rank and 8 hit counts.  16 bytes per 8
+// codes instead of 64: the 10-mer table shrinks from 8 MB to 2 MB and stays in the L2 of every XCD - the seed kernel's random
+// lookups stop being HBM traffic.  A record is marked "escape" when a count does not fit a byte or its intervals are not
+// adjacent; empty codes (count 0) and escapes are answered from the full table, so results never depend on this form.
+__global__ void __launch_bounds__(256) k_build_kmer_compact(const uint2* tab, uint4* ctab, int T) {
+    const uint32_t rec = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rec >= (1u << (2 * T - 3))) return;
+    uint32_t start = 0, next = 0, w0 = 0, w1 = 0, esc = 0;
+    bool have = false;
+    for (uint32_t i = 0; i < 8; ++i) {
+        const uint2 iv = tab[rec * 8 + i];
+        uint32_t cnt = 0;
+        if (iv.x != 0xFFFFFFFFu) {
+            cnt = iv.y - iv.x + 1;
+            if (!have) { start = iv.x; have = true; }
+            else if (iv.x != next) esc = 1;              // a shorter suffix sorts in between
+            next = iv.y + 1;
+            if (cnt >= 255u) esc = 1;
+        }
+        if (i < 4) w0 |= (cnt & 255u) << (8 * i); else w1 |= (cnt & 255u) << (8 * (i - 4));
+    }
+    ctab[rec] = make_uint4(start, w0, w1, esc);
+}
+
 // ------------------------------------------------------------------------------------------------
 // prep: one thread per read
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_prep(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) k_prep(GmDevIndex ix, GmDevParams p, GmDevBatch b, uint32_t tile_reads) {
+    // the quality -> (p, q) table and the 256-row score table are read once per base: keep them in LDS, not behind 5 loads per base
+    __shared__ float2 s_lut[512];
+    __shared__ float4 s_S[256];
+    for (int q = threadIdx.x; q < 512; q += 256) s_lut[q] = p.lut[q];
+    s_S[threadIdx.x] = reinterpret_cast<const float4*>(p.S256)[threadIdx.x];
+    // a lane walking its own row with 8-byte loads pulls a whole 128-byte line per load and finds it evicted by the next one
+    // (measured: 13 x the useful HBM traffic).  So the 256 reads of a tile are staged into LDS with coalesced 16-byte loads.
+    // tile_reads = reads per tile that fit the LDS budget (256 at 100 bp); 0 = rows too long to stage, lanes read HBM directly
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_tile[];          // bases of a tile, then quals
     unsigned long long bad = 0;
-    if (r < b.n) {
+    const bool staged = tile_reads != 0;
+    const uint32_t TR = staged ? tile_reads : 256u;
+    const uint32_t n_tiles = (b.n + TR - 1u) / TR;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint32_t r0 = tile * TR;
+    const uint32_t nr = b.n - r0 < TR ? b.n - r0 : TR;
+    const size_t bytes = (size_t)nr * b.stride;
+    unsigned char* const s_b = s_tile; unsigned char* const s_q = s_tile + (size_t)TR * b.stride;
+    __syncthreads();                                 // the previous tile (and the tables) are done with
+#pragma unroll
+    for (int which = 0; which < 2 && staged; ++which) {
+        const unsigned char* src = (which ? b.quals : b.bases) + (size_t)r0 * b.stride;
+        unsigned char* dst = which ? s_q : s_b;
+        if ((((size_t)src) & 15) == 0) {
+            for (size_t o = (size_t)threadIdx.x * 16; o < bytes; o += 256 * 16) {
+                if (o + 16 <= bytes) *reinterpret_cast<uint4*>(dst + o) = *reinterpret_cast<const uint4*>(src + o);
+                else for (size_t q = o; q < bytes; ++q) dst[q] = src[q];
+            }
+        } else {
+            for (size_t o = (size_t)threadIdx.x * 8; o < bytes; o += 256 * 8) *reinterpret_cast<uint2*>(dst + o) = *reinterpret_cast<const uint2*>(src + o);
+        }
+    }
+    __syncthreads();
+    const uint32_t r = r0 + threadIdx.x;
+    if (threadIdx.x < TR && r < b.n) {
         uint32_t L = b.len[r];
-        const uint8_t* rb = b.bases + (size_t)r * b.stride;
-        const uint8_t* rq = b.quals + (size_t)r * b.stride;
-        const float2* lut = p.lut + ((r < b.illumina_until) ? 256 : 0);
+        const uint8_t* rb = staged ? s_b + (size_t)threadIdx.x * b.stride : b.bases + (size_t)r * b.stride;
+        const uint8_t* rq = staged ? s_q + (size_t)threadIdx.x * b.stride : b.quals + (size_t)r * b.stride;
+        const float2* lut = s_lut + ((r < b.illumina_until) ? 256 : 0);
         int8_t st = 0;
         float self = 0.0f;
         double mn;
@@ -246,7 +303,8 @@ __global__ void __launch_bounds__(256) k_prep(GmDevIndex ix, GmDevParams p, GmDe
                     uint32_t qc = ((t < 4 ? qw.x : qw.y) >> ((t & 3) * 8)) & 255u;
                     float2 pq = lut[qc];
                     if (pq.x != pq.x) bad = 1;               // negative probability (SeqReader.cpp:1171-1189)
-                    const float* s = p.S256 + ch * 4;
+                    const float4 sv = s_S[ch];
+                    const float s[4] = { sv.x, sv.y, sv.z, sv.w };
                     score = __fadd_rn(score, gm_get_val(gm_nt4(ch), pq.x, pq.y, s));
                 }
             }
@@ -270,6 +328,7 @@ __global__ void __launch_bounds__(256) k_prep(GmDevIndex ix, GmDevParams p, GmDe
         b.hit_count[r] = 0;
         b.hit_cursor[r] = 0;
     }
+    }
     gm_count(b, GMK_BAD_QUAL, bad);
 }
 
@@ -279,7 +338,12 @@ __global__ void __launch_bounds__(256) k_prep(GmDevIndex ix, GmDevParams p, GmDe
 __global__ void __launch_bounds__(256) k_seed(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
     // the 128 reads of this workgroup (2 lanes per read: + and - strand) are staged into LDS with coalesced 16-byte loads
     extern __shared__ __attribute__((aligned(16))) unsigned char s_reads[];
-    const uint32_t r0 = blockIdx.x * 128u;
+    unsigned long long nk = 0, nocc = 0, nblk = 0, ntab = 0, nseed_all = 0, nent_all = 0;
+    // persistent workgroups: a tile is 128 reads; the work counters go to HBM once per wave at the very end (one atomic per
+    // wave per tile on six shared addresses used to cost more than the seed search itself: ~90 M atomics/s per address)
+    const uint32_t n_tiles = (b.n + 127u) / 128u;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint32_t r0 = tile * 128u;
     {
         const uint32_t nr = b.n - r0 < 128u ? b.n - r0 : 128u;
         const size_t bytes = (size_t)nr * b.stride;                       // stride is a multiple of 8; r0 * stride of 16 when stride % 16 == 0
@@ -294,8 +358,8 @@ __global__ void __launch_bounds__(256) k_seed(GmDevIndex ix, GmDevParams p, GmDe
         }
     }
     __syncthreads();
-    uint32_t rs = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long nk = 0, nocc = 0, nblk = 0, nseed = 0, nent = 0, ntab = 0;
+    const uint32_t rs = tile * 256u + threadIdx.x;
+    unsigned long long nseed = 0, nent = 0;
     if (rs < 2 * b.n) {
         uint32_t r = rs >> 1, strand = rs & 1;
         bool on = b.status[r] == 0 && (strand ? p.neg_strand : p.pos_strand);
@@ -322,10 +386,26 @@ __global__ void __launch_bounds__(256) k_seed(GmDevIndex ix, GmDevParams p, GmDe
                         code |= c << (2 * q);
                     }
                     if (ok) {
-                        const uint2 iv = p.kmer_tab[code];
                         ++ntab;
-                        if (iv.x == 0xFFFFFFFFu) { ok = false; t = p.mer - (int)iv.y; }   // the last iv.y characters do not occur
-                        else { k = iv.x; l = iv.y; }
+                        bool answered = false;
+                        if (p.kmer_ctab) {                           // 2 MB, L2 resident: start rank + byte counts of 8 consecutive codes
+                            const uint4 rec = p.kmer_ctab[code >> 3];
+                            const uint32_t sub = code & 7u;
+                            const unsigned long long cw = (unsigned long long)rec.y | ((unsigned long long)rec.z << 32);
+                            const uint32_t cnt = (uint32_t)(cw >> (8 * sub)) & 255u;
+                            if (rec.w == 0u && cnt != 0u) {
+                                const unsigned long long below = sub ? (cw & (~0ull >> (64 - 8 * sub))) : 0ull;
+                                unsigned long long s2 = (below & 0x00FF00FF00FF00FFull) + ((below >> 8) & 0x00FF00FF00FF00FFull);      // 4 x 16-bit sums
+                                const uint32_t pre = (uint32_t)((s2 * 0x0001000100010001ull) >> 48);
+                                k = rec.x + pre; l = k + cnt - 1;
+                                answered = true;
+                            }
+                        }
+                        if (!answered) {
+                            const uint2 iv = p.kmer_tab[code];
+                            if (iv.x == 0xFFFFFFFFu) { ok = false; t = p.mer - (int)iv.y; }   // the last iv.y characters do not occur
+                            else { k = iv.x; l = iv.y; }
+                        }
                     }
                 }
                 for (; ok && t >= 0; --t) {
@@ -354,7 +434,7 @@ __global__ void __launch_bounds__(256) k_seed(GmDevIndex ix, GmDevParams p, GmDe
                 }
                 uint32_t cnt = l - k + 1;
                 if (p.hcap > 0 && cnt > p.hcap) { i += 1; continue; }       // too many hits: slide by one (:213-217)
-                if (nseed < b.max_seeds) { GmSeed sd; sd.k = k; sd.l = l; sd.pos = i; out[nseed] = sd; }
+                if (nseed < b.max_seeds && !(p.dbg & 128)) { GmSeed sd; sd.k = k; sd.l = l; sd.pos = i; out[nseed] = sd; }
                 ++nseed;
                 nent += cnt;
                 i += (uint32_t)p.jump;
@@ -363,12 +443,15 @@ __global__ void __launch_bounds__(256) k_seed(GmDevIndex ix, GmDevParams p, GmDe
         b.n_seeds[rs] = (uint16_t)(nseed < b.max_seeds ? nseed : b.max_seeds);
         b.n_entries[rs] = nent > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nent;
     }
+    nseed_all += nseed; nent_all += nent;
+    __syncthreads();                                 // everyone is done with this tile's reads before the next one is staged
+    }
     gm_count(b, GMK_KMERS, nk);
     gm_count(b, GMK_OCC, nocc);
     gm_count(b, GMK_OCC_BLOCKS, nblk);
     gm_count(b, GMK_TAB_LOOKUPS, ntab);
-    gm_count(b, GMK_SEEDS, nseed);
-    gm_count(b, GMK_SA_HITS, nent);
+    gm_count(b, GMK_SEEDS, nseed_all);
+    gm_count(b, GMK_SA_HITS, nent_all);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2396,15 +2479,25 @@ int gmk_build_kmer_table(const GmDevIndex& ix, uint2* tab, int T, void* stream) 
     return (int)hipGetLastError();
 }
 
+int gmk_build_kmer_compact(const uint2* tab, uint4* ctab, int T, void* stream) {
+    uint32_t n = 1u << (2 * T - 3);
+    hipLaunchKernelGGL(k_build_kmer_compact, dim3(cdiv(n, 256)), dim3(256), 0, S_(stream), tab, ctab, T);
+    return (int)hipGetLastError();
+}
+
 int gmk_prep(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream) {
     if (b.n == 0) return 0;
-    hipLaunchKernelGGL(k_prep, dim3(cdiv(b.n, 256)), dim3(256), 0, S_(stream), ix, p, b);
+    // reads per LDS tile: 48 KB for bases + quals, whole waves; rows too long for at least one wave per tile are read directly
+    uint32_t tr = (uint32_t)(49152 / (2 * (size_t)b.stride));
+    tr = tr >= 256 ? 256 : (tr / 64) * 64;
+    const uint32_t per = tr ? tr : 256;
+    hipLaunchKernelGGL(k_prep, dim3((uint32_t)std::min<uint64_t>(cdiv(b.n, per), 256 * 4)), dim3(256), (size_t)2 * tr * b.stride, S_(stream), ix, p, b, tr);
     return (int)hipGetLastError();
 }
 
 int gmk_seed(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream) {
     if (b.n == 0) return 0;
-    hipLaunchKernelGGL(k_seed, dim3(cdiv(2ull * b.n, 256)), dim3(256), (size_t)128 * b.stride, S_(stream), ix, p, b);
+    hipLaunchKernelGGL(k_seed, dim3((uint32_t)std::min<uint64_t>(cdiv(2ull * b.n, 256), 256 * 12)), dim3(256), (size_t)128 * b.stride, S_(stream), ix, p, b);
     return (int)hipGetLastError();
 }
 
