@@ -113,6 +113,7 @@ CONFIGS = {
     "fast_k1": dict(fast=1, mer=14, jump=14, min_seed_hits=1),
     "raw60": dict(align_score=60.0, align_is_fraction=0),
     "a07_q50": dict(align_score=0.7, cutoff=50.0),
+    "m20_j2": dict(mer=20, jump=2),                             # 40 seeds per strand: 64-bit step masks inside k_vote_slots (<= 40 slots)
     "m6_j2": dict(mer=6, jump=2),                               # 48 seeds x ~70 hits per strand: > 32 seeds (64-bit step masks), > 40 slots (list kernel)
 }
 
@@ -382,9 +383,10 @@ def test_pipelined_sub_batches_equal_single_pass(ix_full, syn_reads, packed, mon
                                  dict(GM_VOTE="block", GM_VOTE_KERNEL="block", GM_VOTE_NT="256"), dict(GM_VOTE="block", GM_VOTE_KERNEL="block", GM_VOTE_TB="10"),
                                  dict(GM_VOTE="block", GM_VOTE_KERNEL="steps"), dict(GM_VOTE="block", GM_VOTE_KERNEL="pipe"),
                                  dict(GM_VOTE="block", GM_VOTE_KERNEL="pipe", GM_VOTE_NT="128", GM_VOTE_R="1"),
+                                 dict(GM_VOTE="block", GM_TEST_SAMPLED="1"),                         # k_vote_slots on LF-walk coordinates (no full SA)
                                  dict(GM_VOTE="wave"), dict(GM_VOTE="wave", GM_VOTE_SPARSE="0"),
-                                 dict(GM_NW="wave"), dict(GM_KMER_TABLE="0"), dict(GM_KMER_TABLE="6")])
-@pytest.mark.parametrize("cfg", ["default", "no_nw", "k3", "h30", "m6_j2"])
+                                 dict(GM_NW="wave"), dict(GM_KMER_TABLE="0"), dict(GM_KMER_TABLE="6"), dict(GM_KMER_COMPACT="0")])
+@pytest.mark.parametrize("cfg", ["default", "no_nw", "k3", "h30", "m6_j2", "m20_j2", "k1"])
 def test_every_kernel_variant_matches_oracle(env, cfg, syn_fa, oracle, oix, syn_reads, packed):
     """the dispatch heuristics pick kernels by seed density; force each variant on the same inputs (fresh process state is
     not needed: the switches are read per launch or cached per variant name)"""
@@ -397,7 +399,8 @@ import gnumap_amd as g
 from conftest import read_fastq
 reads = read_fastq({os.path.join(ROOT, 'tests', 'golden', 'syn.fq')!r})
 B, Q, Ln = g.pack_reads([r[1] for r in reads], [r[2] for r in reads])
-ix = g.Index({syn_fa!r}, flags=g.GM_INDEX_FULL_SA)
+import os
+ix = g.Index({syn_fa!r}, flags=0 if os.environ.get('GM_TEST_SAMPLED') else g.GM_INDEX_FULL_SA)
 p = g.Params(**{CONFIGS[cfg]!r})
 b = g.Batch(ix, len(reads), B.shape[1])
 b.upload(p, B, Q, Ln); b.map_device(p)
