@@ -1528,10 +1528,11 @@ __global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParam
         for (int j = 0; j < U; ++j) {
             nnz += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(bpv[j] != 0u));
             if (bpv[j] != 0) {
-                // slot = the low 13 bits of the window start as they are (SA hits are spread evenly; positions a multiple of
-                // 8192 apart share a slot, which only sends them on to the second filter): word = b[10:0], byte = b[12:11]
+                // slot = the low 13 bits of the window start as they are, used as the BYTE address of its counter (SA hits are
+                // spread evenly; positions a multiple of 8192 apart share a slot, which only sends them on to the second
+                // filter): the add needs the word and a shift, the test in pass 2a is one byte load
                 const uint32_t h = bpv[j];
-                atomicAdd(&s_r0[h & 2047u], 1u << ((h >> 8) & 0x18u));
+                atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(s_r0) + (h & 0x1FFCu)), 1u << ((h & 3u) << 3));
             }
         }
     } else {
@@ -1558,8 +1559,7 @@ __global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParam
         for (int j = 0; j < U; ++j) {
             bool pass = false;
             if (bpv[j] != 0) {
-                const uint32_t h = bpv[j];
-                pass = ((s_r0[h & 2047u] >> ((h >> 8) & 0x18u)) & 255u) >= thr1;
+                pass = (uint32_t)reinterpret_cast<const unsigned char*>(s_r0)[bpv[j] & 8191u] >= thr1;
             }
             const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
             if (pass) {
