@@ -536,7 +536,7 @@ static int map_pipelined(gm_index* ix, const gm_params* p, const GmDevParams& dp
             view[i].gtab_keys = b->sub_gk[s].as<uint32_t>(); view[i].gtab_vals = b->sub_gv[s].as<uint32_t>();
             HIPCHK(hipMemsetAsync(b->sub_gk[s].p, 0xFF, slots * 4, ss));
             HIPCHK(hipMemsetAsync(b->sub_gv[s].p, 0, slots * 4, ss));
-            { KTimer t(b, GM_K_VOTE_RETRY, ss); KCHK(gmk_vote_retry(ix->dev, dp, view[i], 1, small[1], ss)); }
+            { KTimer t(b, GM_K_VOTE_RETRY, ss); KCHK(gmk_vote_retry(ix->dev, dp, view[i], 1, 0, small[1], ss)); }
             HIPCHK(hipMemcpyAsync(shard_host.data(), view[i].shard_cnt, shard_bytes, hipMemcpyDeviceToHost, ss));
             HIPCHK(hipStreamSynchronize(ss));
             tally(total, mx);
@@ -596,14 +596,21 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
     b->mapped = false;
     if (b->n == 0) { b->n_cands = 0; b->n_raw = 0; b->mapped = true; memset(b->counters_host, 0, sizeof b->counters_host); return GM_OK; }
     const int use_full = ix->full_sa ? 1 : 0;
-    // expected SA hits per seed ~ reference length / 4^mer: dense seeds get one workgroup per read x strand in the vote
-    // kernel, sparse ones one wavefront (GM_VOTE=wave|block overrides the heuristic)
+    // which vote kernel: expected SA hits per seed ~ reference length / 4^mer (capped by -h), expected seeds per strand from the
+    // longest read.  0 = sparse (<= 16 hits per read x strand fit a 16-lane group), 1 = k_vote_slots (its hits fit 40 slots of
+    // 64 lanes), 2 = its 64-slot form, 3 = k_vote_block (more: rounds of 2048 hits).  GM_VOTE=wave|block|big|rounds forces 0..3, GM_VOTE_KERNEL the dense form.
     int dense = 0;
     {
         double per_seed = (double)ix->h.seq_len / pow(4.0, (double)std::min(p->mer, 31));
         if (p->max_kmer_hits > 0) per_seed = std::min(per_seed, (double)p->max_kmer_hits);
-        dense = per_seed >= 8.0;
-        if (const char* ev = getenv("GM_VOTE")) dense = !strcmp(ev, "block") ? 1 : !strcmp(ev, "wave") ? 0 : dense;
+        const double L = (double)b->stride;
+        double ns = L > p->mer ? floor((L - p->mer - 1) / std::max(1, p->jump)) + 1 : 1;
+        if (p->nw && p->fast) ns = 1;
+        ns = std::min(ns, (double)b->max_seeds);
+        const double e_exp = ns * (1.0 + per_seed);                                      // the true locus + chance hits
+        const double slots_exp = ns * ceil((per_seed + 3.0 * sqrt(per_seed) + 1.0) / 64.0);
+        dense = e_exp > 14.0 ? (slots_exp <= 38.0 ? 1 : slots_exp <= 60.0 ? 2 : 3) : 0;
+        if (const char* ev = getenv("GM_VOTE")) dense = !strcmp(ev, "block") ? 1 : !strcmp(ev, "big") ? 2 : !strcmp(ev, "rounds") ? 3 : !strcmp(ev, "wave") ? 0 : dense;
     }
     b->counters_on_host = false;
     {   // optional sub-batch pipeline over several streams for large full-SA batches (GM_PIPELINE=<sub-batch size>).  Measured
@@ -661,11 +668,41 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         uint32_t n_retry = small[1];
         if (n_retry && mx <= b->dev.cand_region) {
             size_t slots = (size_t)ctr[GMK_HEAVY_SLOTS];
-            if (b->gtab_keys.ensure(slots * 4) || b->gtab_vals.ensure(slots * 4)) return GM_E_NOMEM;
-            fill_dev_batch(b);
-            HIPCHK(hipMemsetAsync(b->gtab_keys.p, 0xFF, slots * 4, st));
-            HIPCHK(hipMemsetAsync(b->gtab_vals.p, 0, slots * 4, st));
-            { KTimer t(b, GM_K_VOTE_RETRY, st); KCHK(gmk_vote_retry(ix->dev, dp, b->dev, use_full, n_retry, st)); }
+            const size_t budget = (size_t)1 << 28;       // table slots per launch (2 GB of keys + counts)
+            if (slots <= budget) {
+                if (b->gtab_keys.ensure(slots * 4) || b->gtab_vals.ensure(slots * 4)) return GM_E_NOMEM;
+                fill_dev_batch(b);
+                HIPCHK(hipMemsetAsync(b->gtab_keys.p, 0xFF, slots * 4, st));
+                HIPCHK(hipMemsetAsync(b->gtab_vals.p, 0, slots * 4, st));
+                { KTimer t(b, GM_K_VOTE_RETRY, st); KCHK(gmk_vote_retry(ix->dev, dp, b->dev, use_full, 0, n_retry, st)); }
+            } else {
+                // many read x strands at once (a kernel choice that did not fit the data): the tables are handed out again per
+                // launch instead of all at once
+                std::vector<uint32_t> list(n_retry), nent((size_t)2 * b->n);
+                HIPCHK(hipMemcpyAsync(list.data(), b->retry_list.p, (size_t)n_retry * 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipMemcpyAsync(nent.data(), b->n_entries.p, nent.size() * 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                if (b->gtab_keys.ensure(budget * 4) || b->gtab_vals.ensure(budget * 4)) return GM_E_NOMEM;
+                fill_dev_batch(b);
+                std::vector<unsigned long long> off(n_retry);
+                KTimer t(b, GM_K_VOTE_RETRY, st);
+                for (uint32_t j = 0; j < n_retry;) {
+                    const uint32_t j0 = j;
+                    size_t acc = 0;
+                    while (j < n_retry) {
+                        size_t need = 2 * (size_t)nent[list[j]], sz = 1024;
+                        while (sz < need && sz < 0x80000000u) sz <<= 1;
+                        if (sz > budget) { gm_set_error("a read x strand with more SA hits than the retry table budget; use -h"); return GM_E_CAPACITY; }
+                        if (acc + sz > budget) break;
+                        off[j] = acc; acc += sz; ++j;
+                    }
+                    HIPCHK(hipMemcpyAsync(b->retry_off.as<unsigned long long>() + j0, off.data() + j0, (size_t)(j - j0) * 8, hipMemcpyHostToDevice, st));
+                    HIPCHK(hipMemsetAsync(b->gtab_keys.p, 0xFF, acc * 4, st));
+                    HIPCHK(hipMemsetAsync(b->gtab_vals.p, 0, acc * 4, st));
+                    KCHK(gmk_vote_retry(ix->dev, dp, b->dev, use_full, j0, j - j0, st));
+                    HIPCHK(hipStreamSynchronize(st));        // off[] is reused by the next group
+                }
+            }
             rc = read_shards(total, mx);
             if (rc) return rc;
         }

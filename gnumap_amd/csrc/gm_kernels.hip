@@ -1444,15 +1444,19 @@ __global__ void __launch_bounds__(NT, NT == 256 ? (R > 1 ? 6 : 8) : 5) k_vote_pi
 // Read x strands that need more than GMS_SMAX slots go to k_vote_fast_list through b.big_list.
 #define GMS_SMAX 40                      // slots (64 lanes each) a read x strand may take in this kernel
 #define GMS_LCAP 540                     // compacted list entries per workgroup (more -> retry kernel)
-template <bool MASK64, bool FULL>
-__global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
-    constexpr int NT = 128, NW = 2, U = GMS_SMAX / NW, ZK = 512 / NT;
+// BIG = the form for 41..64 slots per read x strand (e.g. 10-mers on a 150 Mbp reference: ~150 hits per seed): 32 slots per
+// wave, a longer list, the second filter takes the whole zeroed region (4096 x 16 bit) and the table its own 4 KB.
+template <bool MASK64, bool FULL, bool BIG>
+__global__ void __launch_bounds__(128, BIG ? 5 : 7) k_vote_slots(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
+    constexpr int SMAX = BIG ? 64 : GMS_SMAX, LCAP = BIG ? 1280 : GMS_LCAP;
+    constexpr int NT = 128, NW = 2, U = SMAX / NW, ZK = 512 / NT;
     static_assert(NW == 2, "the list is two stacks growing towards each other");
     __shared__ uint4 s_r0v[512];                     // 8 KB: counting filter (8192 x 8 bit), then keys | vals | low masks | high masks x 512
-    __shared__ uint32_t s_lbp[GMS_LCAP];
-    __shared__ uint8_t s_lt[GMS_LCAP];
-    __shared__ uint2 s_desc[GMS_SMAX];               // {SA rank (flat entry index if !FULL) of lane 0, read offset | tag << 16 | (lanes - 1) << 24}
+    __shared__ uint32_t s_lbp[LCAP];
+    __shared__ uint8_t s_lt[LCAP];
+    __shared__ uint2 s_desc[SMAX];               // {SA rank (flat entry index if !FULL) of lane 0, read offset | tag << 16 | (lanes - 1) << 24}
     __shared__ uint32_t s_cnt0[64];
+    __shared__ uint32_t s_tab[BIG ? 1024 : 1];        // BIG: the exact table (256 x key | votes | low mask | high mask)
     __shared__ uint32_t s_nslots, s_E, s_nkeys, s_full, s_lcnt[NW];
     uint32_t* const s_r0 = reinterpret_cast<uint32_t*>(s_r0v);
     const uint32_t rs = blockIdx.x;                  // grid = 2n
@@ -1475,7 +1479,7 @@ __global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParam
             if (lane >= off) { ie += te; is += ts; }
         }
         uint32_t E0 = __shfl(ie, 63), S0 = __shfl(is, 63);
-        if (S0 > GMS_SMAX) {                         // wave-uniform: hand over to the list kernel
+        if (S0 > SMAX) {                         // wave-uniform: hand over to the list kernel
             if (lane == 0) { const uint32_t at = atomicAdd(b.n_big, 1u); b.big_list[at] = rs; }
             S0 = 0; E0 = 0;
         } else {
@@ -1485,8 +1489,9 @@ __global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParam
                 s_desc[s0 + j] = make_uint2((FULL ? sd.k : e0) + 64u * j, sd.pos | ((uint32_t)lane << 16) | ((left < 64u ? left : 64u) << 24));
             }
         }
-        if ((uint32_t)lane >= S0 && lane < GMS_SMAX) s_desc[lane] = make_uint2(0u, 0u);      // unused slots: no valid lane
+        if ((uint32_t)lane >= S0 && lane < SMAX) s_desc[lane] = make_uint2(0u, 0u);      // unused slots: no valid lane
         s_cnt0[lane] = 0;
+        if (BIG) for (int q = lane; q < 1024; q += 64) s_tab[q] = 0;
         if (lane == 0) { s_nslots = S0; s_E = E0; s_nkeys = 0; s_full = 0; }
     }
 #pragma unroll
@@ -1521,7 +1526,7 @@ __global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParam
     const uint32_t thr1 = (uint32_t)(p.kmin < 100 ? p.kmin : 100);      // filter bytes saturate (>= 128 -> retry kernel), so cap the test
     uint32_t wcount = 0;                             // wave-uniform fill of this wave's list segment
     uint32_t nnz = 0;                                // non-zero window starts of this wave (scalar)
-    const int lorg = wave ? GMS_LCAP - 1 : 0, ldir = wave ? -1 : 1;       // the list is two stacks (see below)
+    const int lorg = wave ? LCAP - 1 : 0, ldir = wave ? -1 : 1;       // the list is two stacks (see below)
     if (filter) {
         // ---- pass 1: one non-returning ds_add per hit into the counting filter
 #pragma unroll
@@ -1564,7 +1569,7 @@ __global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParam
             const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
             if (pass) {
                 const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, wcount));
-                if (at < (uint32_t)GMS_LCAP) { const uint32_t li = (uint32_t)(lorg + ldir * (int)at); s_lbp[li] = bpv[j]; s_lt[li] = (uint8_t)(j * NW + wave); }   // slot id; its seed's step is looked up later, for the few that survive
+                if (at < (uint32_t)LCAP) { const uint32_t li = (uint32_t)(lorg + ldir * (int)at); s_lbp[li] = bpv[j]; s_lt[li] = (uint8_t)(j * NW + wave); }   // slot id; its seed's step is looked up later, for the few that survive
             }
             wcount += (uint32_t)__popcll(m);
         }
@@ -1575,13 +1580,13 @@ __global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParam
             const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
             if (pass) {
                 const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, wcount));
-                if (at < (uint32_t)GMS_LCAP) { const uint32_t li = (uint32_t)(lorg + ldir * (int)at); s_lbp[li] = bpv[j]; s_lt[li] = (uint8_t)(j * NW + wave); }
+                if (at < (uint32_t)LCAP) { const uint32_t li = (uint32_t)(lorg + ldir * (int)at); s_lbp[li] = bpv[j]; s_lt[li] = (uint8_t)(j * NW + wave); }
             }
             wcount += (uint32_t)__popcll(m);
         }
     }
     // the list is one array used as two stacks: wave 0 grows up from 0, wave 1 down from the top; they only meet when the
-    // two together exceed GMS_LCAP, and then the read x strand goes to the retry kernel anyway
+    // two together exceed LCAP, and then the read x strand goes to the retry kernel anyway
     if (lane == 0) s_lcnt[wave] = wcount;
     __syncthreads();
     tick(3);
@@ -1600,13 +1605,15 @@ __global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParam
     }
     // ---- pass 2b: the list is mostly single positions that shared a filter slot with another one; a linear-probing table
     // loaded with all of them makes every wave step wait for its unluckiest lane (tens of dependent CAS round trips).  So
-    // the list goes through a second counting filter first (other hash, 16-bit counters: at most GMS_LCAP entries, no
+    // the list goes through a second counting filter first (other hash, 16-bit counters: at most LCAP entries, no
     // wrap), and only entries whose second slot also reached kmin enter the exact table, which then stays nearly empty.
     // Both live in the zeroed filter memory: words [0,1024) = 2048 x 16-bit counters, words [1024,2048) = 256 slots of
     // key | votes | low step mask | high step mask (key 0 = empty; b = 0 never gets here).
     constexpr int T2 = 256;
-    uint32_t* const keys = s_r0 + 1024; uint32_t* const vals = keys + T2; uint32_t* const mlo = keys + 2 * T2; uint32_t* const mhi = keys + 3 * T2;
-    const bool lfull = s_lcnt[0] + s_lcnt[1] > (uint32_t)GMS_LCAP;       // block-uniform
+    constexpr uint32_t F2W = BIG ? 2047u : 1023u;     // second filter: words of two 16-bit counters
+    constexpr int F2S = BIG ? 11 : 10;
+    uint32_t* const keys = BIG ? s_tab : s_r0 + 1024; uint32_t* const vals = keys + T2; uint32_t* const mlo = keys + 2 * T2; uint32_t* const mhi = keys + 3 * T2;
+    const bool lfull = s_lcnt[0] + s_lcnt[1] > (uint32_t)LCAP;       // block-uniform
     const uint32_t n_l = lfull ? 0u : s_lcnt[wave];
     const uint32_t thr = (uint32_t)(p.kmin < 1 ? 1 : p.kmin);
     for (uint32_t i0 = 0; i0 < n_l; i0 += 256) {     // four wave steps at a time: their list reads are in flight together
@@ -1614,13 +1621,13 @@ __global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParam
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t i = i0 + 64u * q + (uint32_t)lane;
-            bp4[q] = i < n_l ? s_lbp[wave ? GMS_LCAP - 1 - i : i] : 0u;
+            bp4[q] = i < n_l ? s_lbp[wave ? LCAP - 1 - i : i] : 0u;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (bp4[q] != 0u) {
-                const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> 21;
-                atomicAdd(&s_r0[h2 & 1023u], 1u << ((h2 >> 10) << 4));
+                const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> (BIG ? 20 : 21);
+                atomicAdd(&s_r0[h2 & F2W], 1u << ((h2 >> F2S) << 4));
             }
     }
     __syncthreads();
@@ -1633,19 +1640,19 @@ __global__ void __launch_bounds__(128, 7) k_vote_slots(GmDevIndex ix, GmDevParam
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint32_t i = i0 + 64u * q + (uint32_t)lane;
-                bp4[q] = i < n_l ? s_lbp[wave ? GMS_LCAP - 1 - i : i] : 0u;
+                bp4[q] = i < n_l ? s_lbp[wave ? LCAP - 1 - i : i] : 0u;
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> 21;
-                c4[q] = (s_r0[h2 & 1023u] >> ((h2 >> 10) << 4)) & 0xFFFFu;
+                const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> (BIG ? 20 : 21);
+                c4[q] = (s_r0[h2 & F2W] >> ((h2 >> F2S) << 4)) & 0xFFFFu;
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 bool fresh = false;
                 if (bp4[q] != 0u && c4[q] >= thr) {
                     const uint32_t i = i0 + 64u * q + (uint32_t)lane;
-                    const uint32_t bp = bp4[q], t = (s_desc[s_lt[wave ? GMS_LCAP - 1 - i : i]].y >> 16) & 63u;
+                    const uint32_t bp = bp4[q], t = (s_desc[s_lt[wave ? LCAP - 1 - i : i]].y >> 16) & 63u;
                     uint32_t slot = (bp * 0x9E3779B1u) >> 24;
                     bool found = false;
                     for (int probe = 0; probe < T2; ++probe) {
@@ -1953,9 +1960,9 @@ struct GmGlobalTable {
     __device__ __forceinline__ uint32_t slot0(uint32_t key) const { return (key * 0x85EBCA6Bu) >> (32 - bits); }
 };
 
-__global__ void __launch_bounds__(256) k_vote_retry(GmDevIndex ix, GmDevParams p, GmDevBatch b, int use_full_sa, uint32_t n_retry) {
-    uint32_t j = blockIdx.x;
-    if (j >= n_retry) return;
+__global__ void __launch_bounds__(256) k_vote_retry(GmDevIndex ix, GmDevParams p, GmDevBatch b, int use_full_sa, uint32_t j0, uint32_t n_retry) {
+    if (blockIdx.x >= n_retry) return;
+    uint32_t j = j0 + blockIdx.x;                    // entries [j0, j0 + n_retry) of the retry list
     uint32_t rs = b.retry_list[j];
     uint32_t ns = b.n_seeds[rs];
     uint32_t E = b.n_entries[rs];
@@ -2536,10 +2543,12 @@ int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, in
             return (int)hipGetLastError();
         }
         static const bool pipe_form = [] { const char* e = getenv("GM_VOTE_KERNEL"); return e && !strcmp(e, "pipe"); }();
-        static const bool slots_form = [] { const char* e = getenv("GM_VOTE_KERNEL"); return !e || !strcmp(e, "slots"); }();
+        static const char* const kenv = getenv("GM_VOTE_KERNEL");
+        const bool slots_form = kenv ? !strcmp(kenv, "slots") : dense <= 2;      // dense == 2: the 64-slot form; 3: rounds of the block form
         if (slots_form) {                           // default: wave-uniform seed slots + the list kernel for what it hands over
             const uint32_t lgrid = (uint32_t)std::min<uint64_t>(cdiv(2ull * b.n, 4), 256 * 20);
-#define GM_LAUNCH_VSL(M, F) hipLaunchKernelGGL((k_vote_slots<M, F>), dim3(2 * b.n), dim3(128), 0, S_(stream), ix, p, b)
+#define GM_LAUNCH_VSL(M, F) do { if (dense == 2) hipLaunchKernelGGL((k_vote_slots<M, F, true>), dim3(2 * b.n), dim3(128), 0, S_(stream), ix, p, b); \
+                                 else hipLaunchKernelGGL((k_vote_slots<M, F, false>), dim3(2 * b.n), dim3(128), 0, S_(stream), ix, p, b); } while (0)
             if (m64) { if (use_full_sa) GM_LAUNCH_VSL(true, true); else GM_LAUNCH_VSL(true, false); }
             else { if (use_full_sa) GM_LAUNCH_VSL(false, true); else GM_LAUNCH_VSL(false, false); }
 #undef GM_LAUNCH_VSL
@@ -2590,9 +2599,9 @@ int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, in
     return (int)hipGetLastError();
 }
 
-int gmk_vote_retry(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, uint32_t n_retry, void* stream) {
+int gmk_vote_retry(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, uint32_t j0, uint32_t n_retry, void* stream) {
     if (n_retry == 0) return 0;
-    hipLaunchKernelGGL(k_vote_retry, dim3(n_retry), dim3(256), 0, S_(stream), ix, p, b, use_full_sa, n_retry);
+    hipLaunchKernelGGL(k_vote_retry, dim3(n_retry), dim3(256), 0, S_(stream), ix, p, b, use_full_sa, j0, n_retry);
     return (int)hipGetLastError();
 }
 
