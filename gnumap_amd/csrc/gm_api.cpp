@@ -485,7 +485,7 @@ extern "C" int gm_batch_upload(gm_batch* b, const gm_params* p, const gm_reads* 
 // Large batches in full-SA mode: the batch is cut into sub-batches that go through prep -> seed -> vote -> NW on NS
 // streams, so that the LDS-bound vote kernel of one sub-batch runs beside the seed / NW kernels of its neighbours.
 // Returns 1 when a candidate shard overflowed (the caller then takes the single-pass path, which can grow the list).
-static int map_pipelined(gm_index* ix, const gm_params* p, const GmDevParams& dp, gm_batch* b, hipStream_t st, int dense, uint32_t sub_n) {
+static int map_pipelined(gm_index* ix, const gm_params* p, const GmDevParams& dp, gm_batch* b, hipStream_t st, int dense, int slots_hint, uint32_t sub_n) {
     const uint32_t n = b->n;
     const uint32_t nsb = (n + sub_n - 1) / sub_n;
     for (int i = 0; i < gm_batch::NS; ++i)
@@ -557,7 +557,7 @@ static int map_pipelined(gm_index* ix, const gm_params* p, const GmDevParams& dp
         HIPCHK(hipMemsetAsync(view[i].rs_overflow, 0, 2 * (size_t)view[i].n, ss));
         { KTimer t(b, GM_K_PREP, ss); KCHK(gmk_prep(ix->dev, dp, view[i], ss)); }
         { KTimer t(b, GM_K_SEED, ss); KCHK(gmk_seed(ix->dev, dp, view[i], ss)); }
-        { KTimer t(b, GM_K_VOTE, ss); KCHK(gmk_vote(ix->dev, dp, view[i], 1, dense, ss)); }
+        { KTimer t(b, GM_K_VOTE, ss); KCHK(gmk_vote(ix->dev, dp, view[i], 1, dense, slots_hint, ss)); }
         if (i + 1 >= (uint32_t)gm_batch::NS) { int rc = finish(next_finish++); if (rc) return rc; }
     }
     while (next_finish < nsb && !overflow) { int rc = finish(next_finish++); if (rc) return rc; }
@@ -599,7 +599,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
     // which vote kernel: expected SA hits per seed ~ reference length / 4^mer (capped by -h), expected seeds per strand from the
     // longest read.  0 = sparse (<= 16 hits per read x strand fit a 16-lane group), 1 = k_vote_slots (its hits fit 40 slots of
     // 64 lanes), 2 = its 64-slot form, 3 = k_vote_block (more: rounds of 2048 hits).  GM_VOTE=wave|block|big|rounds forces 0..3, GM_VOTE_KERNEL the dense form.
-    int dense = 0;
+    int dense = 0, slots_hint = 40;                  // slots_hint: expected 64-lane slots per read x strand (picks the k_vote_slots form)
     {
         double per_seed = (double)ix->h.seq_len / pow(4.0, (double)std::min(p->mer, 31));
         if (p->max_kmer_hits > 0) per_seed = std::min(per_seed, (double)p->max_kmer_hits);
@@ -610,6 +610,8 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         const double e_exp = ns * (1.0 + per_seed);                                      // the true locus + chance hits
         const double slots_exp = ns * ceil((per_seed + 3.0 * sqrt(per_seed) + 1.0) / 64.0);
         dense = e_exp > 14.0 ? (slots_exp <= 38.0 ? 1 : slots_exp <= 60.0 ? 2 : 3) : 0;
+        slots_hint = (int)std::min(1000.0, slots_exp);
+        if (const char* ev = getenv("GM_VOTE_SLOTS")) slots_hint = atoi(ev);
         if (const char* ev = getenv("GM_VOTE")) dense = !strcmp(ev, "block") ? 1 : !strcmp(ev, "big") ? 2 : !strcmp(ev, "rounds") ? 3 : !strcmp(ev, "wave") ? 0 : dense;
     }
     b->counters_on_host = false;
@@ -619,7 +621,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         uint32_t sub_n = 0;
         if (const char* ev = getenv("GM_PIPELINE")) sub_n = (uint32_t)atoi(ev);
         if (use_full && sub_n >= 4096 && b->n >= 3 * (uint64_t)sub_n) {
-            int prc = map_pipelined(ix, p, dp, b, st, dense, sub_n);
+            int prc = map_pipelined(ix, p, dp, b, st, dense, slots_hint, sub_n);
             if (prc <= 0) return prc;                    // done, or a real error
         }
     }
@@ -651,7 +653,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         HIPCHK(hipMemsetAsync(b->rs_overflow.p, 0, 2 * (size_t)b->n, st));
         HIPCHK(hipMemsetAsync(b->counters.as<unsigned long long>() + GMK_HEAVY_SLOTS, 0, 8, st));
         HIPCHK(hipMemsetAsync(b->counters.as<unsigned long long>() + GMK_OVERFLOW_RS, 0, 8, st));
-        { KTimer t(b, GM_K_VOTE, st); KCHK(gmk_vote(ix->dev, dp, b->dev, use_full, dense, st)); }
+        { KTimer t(b, GM_K_VOTE, st); KCHK(gmk_vote(ix->dev, dp, b->dev, use_full, dense, slots_hint, st)); }
         uint32_t small[2];
         HIPCHK(hipMemcpyAsync(small, b->small.p, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(ctr, b->counters.p, sizeof ctr, hipMemcpyDeviceToHost, st));

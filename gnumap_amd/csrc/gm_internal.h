@@ -110,7 +110,7 @@ int gmk_prep(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, vo
 int gmk_seed(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream);
 int gmk_scan_entries(const GmDevBatch& b, void* stream);
 int gmk_locate_sampled(const GmDevIndex& ix, const GmDevBatch& b, void* stream);
-int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, int dense, void* stream);
+int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, int dense, int slots_hint, void* stream);
 int gmk_vote_retry(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, uint32_t j0, uint32_t n_retry, void* stream);
 int gmk_nw(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream);
 int gmk_compact(const GmDevBatch& b, void* stream);

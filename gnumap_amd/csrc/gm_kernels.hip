@@ -1444,11 +1444,15 @@ __global__ void __launch_bounds__(NT, NT == 256 ? (R > 1 ? 6 : 8) : 5) k_vote_pi
 // Read x strands that need more than GMS_SMAX slots go to k_vote_fast_list through b.big_list.
 #define GMS_SMAX 40                      // slots (64 lanes each) a read x strand may take in this kernel
 #define GMS_LCAP 540                     // compacted list entries per workgroup (more -> retry kernel)
-// BIG = the form for 41..64 slots per read x strand (e.g. 10-mers on a 150 Mbp reference: ~150 hits per seed): 32 slots per
-// wave, a longer list, the second filter takes the whole zeroed region (4096 x 16 bit) and the table its own 4 KB.
-template <bool MASK64, bool FULL, bool BIG>
-__global__ void __launch_bounds__(128, BIG ? 5 : 7) k_vote_slots(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
-    constexpr int SMAX = BIG ? 64 : GMS_SMAX, LCAP = BIG ? 1280 : GMS_LCAP;
+// SMAX = slots a read x strand may take: 16 / 24 / 40 for few seeds or few hits per seed (every slot of the form is walked,
+// used or not, so the small forms are the fast ones there), 64 = BIG, the form for 41..64 slots (e.g. 10-mers on a 150 Mbp
+// reference: ~150 hits per seed): 32 slots per wave, a longer list, the second filter takes the whole zeroed region
+// (4096 x 16 bit) and the table its own 4 KB.
+template <bool MASK64, bool FULL, int SMAX>
+__global__ void __launch_bounds__(128, SMAX == 64 ? 5 : 7) k_vote_slots(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
+    constexpr bool BIG = SMAX == 64;
+    constexpr int LCAP = BIG ? 1280 : GMS_LCAP;
+    static_assert(SMAX == 16 || SMAX == 24 || SMAX == GMS_SMAX || SMAX == 64, "instantiated forms");
     constexpr int NT = 128, NW = 2, U = SMAX / NW, ZK = 512 / NT;
     static_assert(NW == 2, "the list is two stacks growing towards each other");
     __shared__ uint4 s_r0v[512];                     // 8 KB: counting filter (8192 x 8 bit), then keys | vals | low masks | high masks x 512
@@ -2528,7 +2532,7 @@ int gmk_locate_sampled(const GmDevIndex& ix, const GmDevBatch& b, void* stream) 
     return (int)hipGetLastError();
 }
 
-int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, int dense, void* stream) {
+int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, int dense, int slots_hint, void* stream) {
     if (b.n == 0) return 0;
     // dense seeds (many SA hits per read x strand): one workgroup per read x strand
     if (dense && b.max_seeds <= 64) {
@@ -2546,11 +2550,14 @@ int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, in
         static const char* const kenv = getenv("GM_VOTE_KERNEL");
         const bool slots_form = kenv ? !strcmp(kenv, "slots") : dense <= 2;      // dense == 2: the 64-slot form; 3: rounds of the block form
         if (slots_form) {                           // default: wave-uniform seed slots + the list kernel for what it hands over
+            const int slot_form = dense == 2 ? 64 : slots_hint <= 14 ? 16 : slots_hint <= 22 ? 24 : GMS_SMAX;
             const uint32_t lgrid = (uint32_t)std::min<uint64_t>(cdiv(2ull * b.n, 4), 256 * 20);
-#define GM_LAUNCH_VSL(M, F) do { if (dense == 2) hipLaunchKernelGGL((k_vote_slots<M, F, true>), dim3(2 * b.n), dim3(128), 0, S_(stream), ix, p, b); \
-                                 else hipLaunchKernelGGL((k_vote_slots<M, F, false>), dim3(2 * b.n), dim3(128), 0, S_(stream), ix, p, b); } while (0)
+#define GM_LAUNCH_VSL1(M, F, S) hipLaunchKernelGGL((k_vote_slots<M, F, S>), dim3(2 * b.n), dim3(128), 0, S_(stream), ix, p, b)
+#define GM_LAUNCH_VSL(M, F) do { if (slot_form == 64) GM_LAUNCH_VSL1(M, F, 64); else if (slot_form == 16) GM_LAUNCH_VSL1(M, F, 16); \
+                                 else if (slot_form == 24) GM_LAUNCH_VSL1(M, F, 24); else GM_LAUNCH_VSL1(M, F, GMS_SMAX); } while (0)
             if (m64) { if (use_full_sa) GM_LAUNCH_VSL(true, true); else GM_LAUNCH_VSL(true, false); }
             else { if (use_full_sa) GM_LAUNCH_VSL(false, true); else GM_LAUNCH_VSL(false, false); }
+#undef GM_LAUNCH_VSL1
 #undef GM_LAUNCH_VSL
             if (m64) hipLaunchKernelGGL(k_vote_fast_list<true>, dim3(lgrid), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
             else hipLaunchKernelGGL(k_vote_fast_list<false>, dim3(lgrid), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);

@@ -380,6 +380,7 @@ def test_pipelined_sub_batches_equal_single_pass(ix_full, syn_reads, packed, mon
 
 @pytest.mark.parametrize("env", [dict(GM_VOTE="block"),                                             # dense seeds: k_vote_slots (the default dense kernel)
                                  dict(GM_VOTE="big"), dict(GM_VOTE="rounds"),                      # its 64-slot form; rounds of the block form
+                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="10"), dict(GM_VOTE="block", GM_VOTE_SLOTS="40"),   # 16-slot form (+ list kernel), 40-slot form
                                  dict(GM_VOTE="block", GM_VOTE_KERNEL="block"), dict(GM_VOTE="block", GM_VOTE_KERNEL="block", GM_VOTE_NT="64"),
                                  dict(GM_VOTE="block", GM_VOTE_KERNEL="block", GM_VOTE_NT="256"), dict(GM_VOTE="block", GM_VOTE_KERNEL="block", GM_VOTE_TB="10"),
                                  dict(GM_VOTE="block", GM_VOTE_KERNEL="steps"), dict(GM_VOTE="block", GM_VOTE_KERNEL="pipe"),
