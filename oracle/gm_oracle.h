@@ -7,7 +7,8 @@
  *
  * Parity pin: FM-index query (occ / SA interval / locate), window fetch, FASTQ->PWM, self score,
  * banded NW score and traceback/CIGAR are checked against the UNMODIFIED reference functions
- * compiled into oracle/_ref/libgnumap_ref.so (tests/test_oracle_vs_ref.py) and against the
+ * compiled into oracle/_ref/libgnumap_ref.so (vectors in tests/golden/ref_vectors.npz made by tests/golden/make_fixtures.py,
+ * checked by tests/test_oracle_golden.py; reverse_comp / reverse_CIGAR / fix_CIGAR_for_deletions likewise) and against the
  * known answers of bin_seq::Test (src/bin_seq.cpp:1095-1127).  The driver level (adaptive k-mer
  * walk, voting, unique map, posterior, MAPQ, SAM text: align_seq2_raw.cpp, Driver.cpp:432-753,
  * ScoredSeq.h:293-404) is restated from the source text; those files cannot be compiled here

@@ -9,6 +9,7 @@ Outputs (all small, all DATA — inputs and expected outputs, no reference sourc
                                       occ, SA intervals, locate, windows, PWM, self score, NW score, traceback
 """
 import os, sys, ctypes, json
+import ctypes as C
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -256,6 +257,20 @@ def main():
     vec["tb_aligned_hex"] = np.array([a.hex() for a in tb_aligned], dtype="S700")
     vec["tb_len"] = tb_len
     vec["tb_cigar"] = np.array(tb_cigar, dtype="S256")
+    # output-side helpers of inc/SequenceOperations.h: reverse_comp (:56-96), reverse_CIGAR (:109-123), fix_CIGAR_for_deletions (:32-42)
+    helper_cigars = sorted(set(tb_cigar)) + [b"97M3D", b"3D97M", b"100M", b"5M2D", b"1D", b"12M1I3D", b"10M:5M", b"7"]
+    out = C.create_string_buffer(4096)
+    fixc = []; revc = []
+    for cg in helper_cigars:
+        ref.lib.ref_fix_cigar(cg, out); fixc.append(out.value)
+        ref.lib.ref_reverse_cigar(cg, out); revc.append(out.value)
+    vec["hc_in"] = np.array(helper_cigars, dtype="S256"); vec["hc_fix"] = np.array(fixc, dtype="S256"); vec["hc_rev"] = np.array(revc, dtype="S256")
+    helper_strs = [seqs[i] for i in range(0, n, 7)] + [a for a in tb_aligned[:200]] + [b"acgtnACGTN-xyzRYKM", b"", b"a", b"-"]
+    helper_strs = [x for x in helper_strs if b"\0" not in x]
+    rcs = []
+    for st in helper_strs:
+        ref.lib.ref_reverse_comp(st, out); rcs.append(out.value)
+    vec["rc_in_hex"] = np.array([x.hex() for x in helper_strs], dtype="S4200"); vec["rc_out_hex"] = np.array([x.hex() for x in rcs], dtype="S4200")
     table, gap, maxgap = ref.get_scores()
     vec["S"] = table; vec["gap"] = np.float32(gap); vec["max_gap"] = np.int32(maxgap)
     np.savez_compressed(os.path.join(HERE, "ref_vectors.npz"), **vec)

@@ -123,3 +123,22 @@ def test_cigar_helpers(oracle):
         out = C.create_string_buffer(1024)
         oracle.lib.gmo_reverse_cigar(cig, out)
         assert out.value == rev
+
+
+def test_output_helpers_against_reference_vectors(oracle, golden):
+    """reverse_comp / reverse_CIGAR / fix_CIGAR_for_deletions (inc/SequenceOperations.h:32-123) on every CIGAR the reference's
+    traceback produced for the fixture plus edge cases, and on reads / gapped strings (vectors from oracle/_ref)"""
+    for cg, fx, rv in zip(golden["hc_in"], golden["hc_fix"], golden["hc_rev"]):
+        buf = C.create_string_buffer(bytes(cg), 1024)
+        if len(cg):
+            oracle.lib.gmo_fix_cigar(buf)
+        assert buf.value == bytes(fx), cg
+        out = C.create_string_buffer(1024)
+        oracle.lib.gmo_reverse_cigar(bytes(cg), out)
+        assert out.value == bytes(rv), cg
+    oracle.lib.gmo_revcomp_str.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
+    for hin, hout in zip(golden["rc_in_hex"], golden["rc_out_hex"]):
+        s = bytes.fromhex(hin.decode()); want = bytes.fromhex(hout.decode())
+        out = C.create_string_buffer(len(s) + 8)
+        oracle.lib.gmo_revcomp_str(s, len(s), out)
+        assert out.raw[:len(s)] == want, s
