@@ -1566,14 +1566,17 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : 7) k_vote_slots(GmDevInd
         // ---- pass 2a: hits whose slot counted >= kmin -> list (ballot + plain stores)
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            bool pass = false;
-            if (bpv[j] != 0) {
-                pass = (uint32_t)reinterpret_cast<const unsigned char*>(s_r0)[bpv[j] & 8191u] >= thr1;
-            }
+            // every lane reads its counter byte (lanes without a hit read byte 0 - a broadcast) so that `pass` is the AND of two
+            // compares, not a value merged across a branch; a list index past the end is clamped onto the last entry (the read
+            // x strand goes to the retry kernel then, see lfull) instead of being branched around
+            const uint32_t cnt = reinterpret_cast<const unsigned char*>(s_r0)[bpv[j] & 8191u];
+            const bool pass = (bpv[j] != 0u) & (cnt >= thr1);
             const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
             if (pass) {
-                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, wcount));
-                if (at < (uint32_t)LCAP) { const uint32_t li = (uint32_t)(lorg + ldir * (int)at); s_lbp[li] = bpv[j]; s_lt[li] = (uint8_t)(j * NW + wave); }   // slot id; its seed's step is looked up later, for the few that survive
+                uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, wcount));
+                at = at < (uint32_t)LCAP ? at : (uint32_t)LCAP - 1u;
+                const uint32_t li = (uint32_t)(lorg + ldir * (int)at);
+                s_lbp[li] = bpv[j]; s_lt[li] = (uint8_t)(j * NW + wave);            // slot id; its seed's step is looked up later, for the few that survive
             }
             wcount += (uint32_t)__popcll(m);
         }
@@ -1658,13 +1661,12 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : 7) k_vote_slots(GmDevInd
                     const uint32_t i = i0 + 64u * q + (uint32_t)lane;
                     const uint32_t bp = bp4[q], t = (s_desc[s_lt[wave ? LCAP - 1 - i : i]].y >> 16) & 63u;
                     uint32_t slot = (bp * 0x9E3779B1u) >> 24;
-                    bool found = false;
-                    for (int probe = 0; probe < T2; ++probe) {
-                        const uint32_t old = atomicCAS(&keys[slot], 0u, bp);
-                        if (old == 0u) { fresh = true; found = true; break; }
-                        if (old == bp) { found = true; break; }
-                        slot = (slot + 1) & (T2 - 1);
-                    }
+                    uint32_t old;
+                    int probes = 0;
+                    // one exit test per probe (the table is kept under 3/4 full, so an empty slot always turns up)
+                    while ((old = atomicCAS(&keys[slot], 0u, bp)) != 0u && old != bp && ++probes < T2) slot = (slot + 1) & (T2 - 1);
+                    fresh = old == 0u;
+                    const bool found = old == 0u || old == bp;
                     if (!found) full = true;
                     else {
                         atomicAdd(&vals[slot], 1u);
@@ -1707,7 +1709,7 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : 7) k_vote_slots(GmDevInd
             if (em[q]) {
                 if (p.nw) {
                     unsigned long long m = (unsigned long long)mlo[slot] | (MASK64 ? ((unsigned long long)mhi[slot] << 32) : 0ull);
-                    for (int r = 1; r < p.kmin && m; ++r) m &= m - 1;
+                    for (int r = 1; r < p.kmin; ++r) m &= m - 1;          // uniform trip count; 0 stays 0
                     st[q] = m ? (uint32_t)(__ffsll((long long)m) - 1) : 0u;
                 } else st[q] = v > 65535u ? 65535u : v;
             }
