@@ -1535,14 +1535,15 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : 7) k_vote_slots(GmDevInd
         // ---- pass 1: one non-returning ds_add per hit into the counting filter
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            nnz += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(bpv[j] != 0u));
-            if (bpv[j] != 0) {
-                // slot = the low 13 bits of the window start as they are, used as the BYTE address of its counter (SA hits are
-                // spread evenly; positions a multiple of 8192 apart share a slot, which only sends them on to the second
-                // filter): the add needs the word and a shift, the test in pass 2a is one byte load
-                const uint32_t h = bpv[j];
-                atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(s_r0) + (h & 0x1FFCu)), 1u << ((h & 3u) << 3));
-            }
+            // slot = the low 13 bits of the window start as they are, used as the BYTE address of its counter (SA hits are
+            // spread evenly; positions a multiple of 8192 apart share a slot, which only sends them on to the second filter):
+            // the add needs the word and a shift, the test in pass 2a is one byte load.  No branch around the lanes without a
+            // hit: they add 0 to a word of their own (s_cnt0[lane], which stays what it is).
+            const uint32_t h = bpv[j];
+            const bool nz = h != 0u;
+            nnz += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(nz));
+            uint32_t* const word = nz ? reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(s_r0) + (h & 0x1FFCu)) : &s_cnt0[lane];
+            atomicAdd(word, nz ? 1u << ((h & 3u) << 3) : 0u);
         }
     } else {
 #pragma unroll
