@@ -2173,7 +2173,10 @@ __global__ void __launch_bounds__(256) k_nw(GmDevIndex ix, GmDevParams p, GmDevB
 // Reads stream through two 8-byte words, the 2-bit reference through two 32-bit words; nothing is staged in LDS
 // except the quality LUT.  (k_nw below is the 8-lanes-per-candidate anti-diagonal form; GM_NW=wave selects it.)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_nw_lane(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
+#ifndef GM_NW_OCC
+#define GM_NW_OCC 5       // measured: 4 -> 3.09 ms, 5 -> 2.97, 6 -> 3.03, 8 -> 3.16 (2 M reads)
+#endif
+__global__ void __launch_bounds__(256, GM_NW_OCC) k_nw_lane(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
     __shared__ float2 s_lut[512];
     __shared__ uint32_t s_coff[GM_NW_NCOFF];
     __shared__ uint32_t s_pre[GM_NSHARD + 4];
