@@ -2211,7 +2211,10 @@ __global__ void __launch_bounds__(256, GM_NW_OCC) k_nw_lane(GmDevIndex ix, GmDev
 #pragma unroll
             for (int d = 0; d < 7; ++d) P[d] = d <= 3 ? __fmul_rn(gap, (float)(3 - d)) : GM_NEG_INF;
             // window bases of the current row: W[d] = w[i+delta]; start with row L-1
-            uint32_t W[7];
+            // the base of a band column as two v_perm_b32 selectors (bit 0 and bit 1 of its 2-bit code: take the low or the high
+            // source register whole): picking a cell's value among the row's four is three byte-permutes, no compares
+            uint32_t S1[7], S2[7];
+            auto set_col = [&](int d, uint32_t code) { S1[d] = 0x03020100u + (code & 1u) * 0x04040404u; S2[d] = 0x03020100u + (code >> 1) * 0x04040404u; };
             uint32_t wword_lo = 0, wword_hi = 0; int wbase = -1;          // 16-base words [wbase*16, +16) and the next one
             auto wcode = [&](int j) -> uint32_t {                          // 2-bit code of the reference at window offset j
                 uint32_t g = c.b + (uint32_t)j;
@@ -2221,7 +2224,7 @@ __global__ void __launch_bounds__(256, GM_NW_OCC) k_nw_lane(GmDevIndex ix, GmDev
                 return (word >> ((((g >> 2) & 3u) << 3) + ((~g & 3u) << 1))) & 3u;     // _get_pac src/bntseq.c:225 on a little-endian word
             };
 #pragma unroll
-            for (int d = 0; d < 7; ++d) { int j = Li - 1 + d - 3; W[d] = (j >= 0 && j < Li) ? wcode(j) : 0u; }
+            for (int d = 0; d < 7; ++d) { int j = Li - 1 + d - 3; set_col(d, (j >= 0 && j < Li) ? wcode(j) : 0u); }
             // the read streams through 8-byte words; the NEXT word is requested one chunk ahead so its latency hides under 8 rows
             const int src0 = strand ? 0 : Li - 1, cstep = strand ? 1 : -1, nchunk = (Li + 7) >> 3;
             int chunk = src0 >> 3;
@@ -2253,8 +2256,9 @@ __global__ void __launch_bounds__(256, GM_NW_OCC) k_nw_lane(GmDevIndex ix, GmDev
 #pragma unroll
                 for (int d = 6; d >= 0; --d) {
                     const int j = i + d - 3;
-                    const float lo = (W[d] & 1u) ? v4[1] : v4[0], hi = (W[d] & 1u) ? v4[3] : v4[2];
-                    const float val = (W[d] & 2u) ? hi : lo;
+                    const uint32_t lo = __builtin_amdgcn_perm(__float_as_uint(v4[1]), __float_as_uint(v4[0]), S1[d]);
+                    const uint32_t hi = __builtin_amdgcn_perm(__float_as_uint(v4[3]), __float_as_uint(v4[2]), S1[d]);
+                    const float val = __uint_as_float(__builtin_amdgcn_perm(hi, lo, S2[d]));
                     const float up = d > 0 ? P[d - 1] : ((EDGE && i + 1 == Li) ? gap4 : GM_NEG_INF);        // nm[i+1][j]
                     const float left = d < 6 ? C[d + 1] : ((EDGE && j + 1 == Li) ? gap4 : GM_NEG_INF);       // nm[i][j+1]
                     const float mm = __fadd_rn(P[d], val);
@@ -2270,8 +2274,8 @@ __global__ void __launch_bounds__(256, GM_NW_OCC) k_nw_lane(GmDevIndex ix, GmDev
                 for (int d = 0; d < 7; ++d) P[d] = C[d];
                 // slide the window bases to row i-1
 #pragma unroll
-                for (int d = 6; d >= 1; --d) W[d] = W[d - 1];
-                W[0] = (!EDGE || i - 4 >= 0) ? wcode(i - 4) : 0u;
+                for (int d = 6; d >= 1; --d) { S1[d] = S1[d - 1]; S2[d] = S2[d - 1]; }
+                set_col(0, (!EDGE || i - 4 >= 0) ? wcode(i - 4) : 0u);
             };
             {
                 int i = Li - 1;
