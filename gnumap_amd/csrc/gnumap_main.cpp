@@ -12,6 +12,7 @@
 #include "gnumap_hip.h"
 #include <algorithm>
 #include <atomic>
+#include <charconv>
 #include <condition_variable>
 #include <deque>
 #include <chrono>
@@ -330,7 +331,14 @@ static void format_sam(std::string& out, const gm_index* ix, const gm_params& p,
         for (uint32_t k = 0; k < QL; ++k) w[k] = q[QL - 1 - k];
         w += QL; *w++ = '\t';
     }
-    w += snprintf(w, 120, "XA:f:%g\tXP:f:%g\tX0:i:%d\n", (double)(float)r.a_score * (1.0 / p.adjust), (double)(float)r.post_prob, r.sim_matches);
+    // "XA:f:%g\tXP:f:%g\tX0:i:%d\n": std::to_chars(general, 6) is specified as printf's %g and is ~4x faster than snprintf
+    memcpy(w, "XA:f:", 5); w += 5;
+    w = std::to_chars(w, w + 40, (double)(float)r.a_score * (1.0 / p.adjust), std::chars_format::general, 6).ptr;
+    memcpy(w, "\tXP:f:", 6); w += 6;
+    w = std::to_chars(w, w + 40, (double)(float)r.post_prob, std::chars_format::general, 6).ptr;
+    memcpy(w, "\tX0:i:", 6); w += 6;
+    if (r.sim_matches < 0) { *w++ = '-'; w = put_u64(w, (uint64_t)(-(int64_t)r.sim_matches)); } else w = put_u64(w, (uint64_t)r.sim_matches);
+    *w++ = '\n';
     out.resize((size_t)(w - out.data()));
 }
 
