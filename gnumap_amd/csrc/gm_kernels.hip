@@ -1442,6 +1442,20 @@ __global__ void __launch_bounds__(NT, NT == 256 ? (R > 1 ? 6 : 8) : 5) k_vote_pi
 // ballot + popcount per slot, and every per-slot branch is a scalar branch.  The LDS phases are those of k_vote_pipe:
 // counting filter (non-returning ds_add) -> compacted list -> exact table with key 0 = empty and a list of inserted slots.
 // Read x strands that need more than GMS_SMAX slots go to k_vote_fast_list through b.big_list.
+// inclusive prefix sum over the 64 lanes of a wavefront with DPP adds (no LDS permutes): within rows of 16 lanes by
+// row_shr 1, 2, 3, 4, 8, then the row totals by row_bcast:15 / row_bcast:31 (lanes a move does not reach add 0)
+__device__ __forceinline__ uint32_t gm_wave_scan_incl(uint32_t x) {
+    uint32_t v = x;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);        // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);        // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x113, 0xF, 0xF, true);        // row_shr:3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xE, true);        // row_shr:4, banks 1-3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xC, true);        // row_shr:8, banks 2-3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);        // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);        // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 #define GMS_SMAX 40                      // slots (64 lanes each) a read x strand may take in this kernel
 #define GMS_LCAP 540                     // compacted list entries per workgroup (more -> retry kernel)
 // SMAX = slots a read x strand may take: 16 / 24 / 40 for few seeds or few hits per seed (every slot of the form is walked,
@@ -1476,12 +1490,7 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : 7) k_vote_slots(GmDevInd
         if (p.nw && p.fast && ns > 1) ns = 1;
         const uint32_t cnt = (uint32_t)lane < ns ? sd.l - sd.k + 1 : 0u;
         const uint32_t nsl = (cnt + 63u) >> 6;
-        uint32_t ie = cnt, is = nsl;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t te = __shfl_up(ie, off), ts = __shfl_up(is, off);
-            if (lane >= off) { ie += te; is += ts; }
-        }
+        const uint32_t ie = gm_wave_scan_incl(cnt), is = gm_wave_scan_incl(nsl);
         uint32_t E0 = __shfl(ie, 63), S0 = __shfl(is, 63);
         if (S0 > SMAX) {                         // wave-uniform: hand over to the list kernel
             if (lane == 0) { const uint32_t at = atomicAdd(b.n_big, 1u); b.big_list[at] = rs; }
