@@ -1475,7 +1475,7 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : 7) k_vote_slots(GmDevInd
     __shared__ uint2 s_desc[SMAX];               // {SA rank (flat entry index if !FULL) of lane 0, read offset | tag << 16 | (lanes - 1) << 24}
     __shared__ uint32_t s_cnt0[64];
     __shared__ uint32_t s_tab[BIG ? 1024 : 1];        // BIG: the exact table (256 x key | votes | low mask | high mask)
-    __shared__ uint32_t s_nslots, s_E, s_nkeys, s_full, s_lcnt[NW];
+    __shared__ uint32_t s_nslots, s_E, s_nkeys, s_full, s_any0, s_lcnt[NW];
     uint32_t* const s_r0 = reinterpret_cast<uint32_t*>(s_r0v);
     const uint32_t rs = blockIdx.x;                  // grid = 2n
     const int tid = threadIdx.x, lane = gm_lane();
@@ -1491,7 +1491,7 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : 7) k_vote_slots(GmDevInd
         const uint32_t cnt = (uint32_t)lane < ns ? sd.l - sd.k + 1 : 0u;
         const uint32_t nsl = (cnt + 63u) >> 6;
         const uint32_t ie = gm_wave_scan_incl(cnt), is = gm_wave_scan_incl(nsl);
-        uint32_t E0 = __shfl(ie, 63), S0 = __shfl(is, 63);
+        uint32_t E0 = __builtin_amdgcn_readlane(ie, 63), S0 = __builtin_amdgcn_readlane(is, 63);
         if (S0 > SMAX) {                         // wave-uniform: hand over to the list kernel
             if (lane == 0) { const uint32_t at = atomicAdd(b.n_big, 1u); b.big_list[at] = rs; }
             S0 = 0; E0 = 0;
@@ -1505,7 +1505,7 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : 7) k_vote_slots(GmDevInd
         if ((uint32_t)lane >= S0 && lane < SMAX) s_desc[lane] = make_uint2(0u, 0u);      // unused slots: no valid lane
         s_cnt0[lane] = 0;
         if (BIG) for (int q = lane; q < 1024; q += 64) s_tab[q] = 0;
-        if (lane == 0) { s_nslots = S0; s_E = E0; s_nkeys = 0; s_full = 0; }
+        if (lane == 0) { s_nslots = S0; s_E = E0; s_nkeys = 0; s_full = 0; s_any0 = 0; }
     }
 #pragma unroll
     for (int k = 0; k < ZK; ++k) s_r0v[tid + NT * k] = make_uint4(0u, 0u, 0u, 0u);
@@ -1562,6 +1562,7 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : 7) k_vote_slots(GmDevInd
     // votes from one seed: counted per step.  It is rare, so it is only looked for when the number of non-zero window
     // starts (popcount of the compare pass 1 makes anyway) falls short of the number of entries.
     if (nnz != nvalid) {                             // wave-uniform, rare
+        if (lane == 0) s_any0 = 1;
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const uint32_t m = __builtin_amdgcn_readfirstlane(s_desc[j * NW + wave].y);
@@ -1744,11 +1745,9 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : 7) k_vote_slots(GmDevInd
                 }
         }
     }
-    if (tid < 64) {                                  // b = 0: cumulative per-step counts
-        uint32_t run = s_cnt0[tid];
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(run, off); if (lane >= off) run += t; }
-        const uint32_t total = __shfl(run, 63);
+    if (tid < 64 && s_any0) {                        // b = 0 (only if some wave saw such a vote): cumulative per-step counts
+        const uint32_t run = gm_wave_scan_incl(s_cnt0[tid]);
+        const uint32_t total = __builtin_amdgcn_readlane(run, 63);
         const unsigned long long reached = __builtin_amdgcn_ballot_w64(run >= (uint32_t)p.kmin);
         const bool emit = tid == 0 && total >= (uint32_t)p.kmin;
         const uint32_t step = p.nw ? (uint32_t)(__ffsll((long long)reached) - 1) : (total > 65535u ? 65535u : total);
