@@ -670,7 +670,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         uint32_t n_retry = small[1];
         if (n_retry && mx <= b->dev.cand_region) {
             size_t slots = (size_t)ctr[GMK_HEAVY_SLOTS];
-            const size_t budget = (size_t)1 << 28;       // table slots per launch (2 GB of keys + counts)
+            static const size_t budget = [] { const char* e = getenv("GM_RETRY_BUDGET"); return e ? (size_t)atoll(e) : (size_t)1 << 28; }();   // table slots per launch (2 GB of keys + counts; the switch is for tests)
             if (slots <= budget) {
                 if (b->gtab_keys.ensure(slots * 4) || b->gtab_vals.ensure(slots * 4)) return GM_E_NOMEM;
                 fill_dev_batch(b);

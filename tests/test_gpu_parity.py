@@ -384,6 +384,7 @@ def test_pipelined_sub_batches_equal_single_pass(ix_full, syn_reads, packed, mon
                                  dict(GM_VOTE="block", GM_VOTE_KERNEL="block"), dict(GM_VOTE="block", GM_VOTE_KERNEL="block", GM_VOTE_NT="64"),
                                  dict(GM_VOTE="block", GM_VOTE_KERNEL="block", GM_VOTE_NT="256"), dict(GM_VOTE="block", GM_VOTE_KERNEL="block", GM_VOTE_TB="10"),
                                  dict(GM_VOTE="block", GM_VOTE_KERNEL="steps"), dict(GM_VOTE="block", GM_VOTE_KERNEL="pipe"),
+                                 dict(GM_VOTE="block", GM_VOTE_KERNEL="block", GM_RETRY_BUDGET="16384"),     # retry tables handed out in several launches
                                  dict(GM_VOTE="block", GM_VOTE_KERNEL="pipe", GM_VOTE_NT="128", GM_VOTE_R="1"),
                                  dict(GM_VOTE="block", GM_TEST_SAMPLED="1"),                         # k_vote_slots on LF-walk coordinates (no full SA)
                                  dict(GM_VOTE="wave"), dict(GM_VOTE="wave", GM_VOTE_SPARSE="0"),
