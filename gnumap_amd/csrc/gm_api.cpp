@@ -212,18 +212,35 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
     dp.mer = p->mer; dp.jump = p->jump; dp.kmin = p->min_seed_hits; dp.nw = p->nw; dp.fast = p->fast;
     dp.pos_strand = p->pos_strand; dp.neg_strand = p->neg_strand; dp.align_is_fraction = p->align_is_fraction;
     { const char* e = getenv("GM_DBG"); dp.dbg = e ? atoi(e) : 0; }
-    // k-mer interval table: the last T = min(mer, 12) characters of every seed are one 8-byte lookup (GM_KMER_TABLE=0
-    // keeps the pure occ walk; GM_KMER_TABLE=<T> picks another suffix length)
+    // k-mer interval table: the last T characters of every seed are one lookup (GM_KMER_TABLE=0 keeps the pure occ walk;
+    // GM_KMER_TABLE=<T> picks another suffix length, at most 14)
     dp.kmer_tab = nullptr; dp.kmer_T = 0; dp.kmer_ctab = nullptr;
     {
-        int T = std::min(p->mer, 12);
-        if (const char* e = getenv("GM_KMER_TABLE")) T = std::min(std::min(atoi(e), p->mer), 13);
+        // up to 12 characters by default; 14 (2 GB + 0.5 GB compact) for longer seeds on references where the extra occ steps
+        // are HBM misses anyway (>= 50 Mbp)
+        int T = std::min(p->mer, ix->h.seq_len >= 50000000ull ? 14 : 12);
+        if (const char* e = getenv("GM_KMER_TABLE")) T = std::min(std::min(atoi(e), p->mer), 14);
         if (T >= 4) {
             std::lock_guard<std::mutex> lk(ix->mu);
             DevBuf& tb = ix->kmer_tabs[T];
             if (!tb.p) {
                 if (tb.ensure(((size_t)1 << (2 * T)) * 8)) return GM_E_NOMEM;
-                KCHK(gmk_build_kmer_table(ix->dev, tb.as<uint2>(), T, st));
+                if (T <= 12) {
+                    KCHK(gmk_build_kmer_table(ix->dev, tb.as<uint2>(), T, st));
+                } else {                             // 12 characters directly, then one character (one search step per entry) at a time
+                    DevBuf cur, nxt;
+                    if (cur.ensure(((size_t)1 << 24) * 8)) return GM_E_NOMEM;
+                    int e2 = gmk_build_kmer_table(ix->dev, cur.as<uint2>(), 12, st);
+                    for (int tt = 13; tt <= T && !e2; ++tt) {
+                        uint2* dst = tb.as<uint2>();
+                        if (tt < T) { if (nxt.ensure(((size_t)1 << (2 * tt)) * 8)) { cur.release(); return GM_E_NOMEM; } dst = nxt.as<uint2>(); }
+                        e2 = gmk_extend_kmer_table(ix->dev, cur.as<uint2>(), dst, tt, st);
+                        if (hipStreamSynchronize(st) != hipSuccess) e2 = 1;
+                        if (tt < T) { cur.release(); cur = nxt; nxt = DevBuf(); }
+                    }
+                    cur.release(); nxt.release();
+                    if (e2) { gm_set_error("k-mer table construction failed"); return GM_E_HIP; }
+                }
                 HIPCHK(hipStreamSynchronize(st));
                 ix->hbm_bytes += tb.cap;
             }

@@ -106,6 +106,7 @@ int gmk_expand_full_sa(const GmDevIndex& ix, uint32_t* full_sa, void* stream);
 int gmk_build_occ_planes(const GmDevIndex& ix, uint4* planes, uint32_t nblk, void* stream);
 int gmk_build_kmer_table(const GmDevIndex& ix, uint2* tab, int T, void* stream);
 int gmk_build_kmer_compact(const uint2* tab, uint4* ctab, int T, void* stream);
+int gmk_extend_kmer_table(const GmDevIndex& ix, const uint2* prev, uint2* next, int T, void* stream);
 int gmk_prep(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream);
 int gmk_seed(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream);
 int gmk_scan_entries(const GmDevBatch& b, void* stream);

@@ -221,6 +221,22 @@ __global__ void __launch_bounds__(256) k_build_kmer_table(GmDevIndex ix, uint2* 
     tab[code] = out;
 }
 
+// One more character on the left of every (T-1)-mer of `prev`: the T-mer table from the (T-1)-mer table with ONE backward-search
+// step per entry (the direct build walks all T steps per entry; at T = 14 that is 268 M x 14 steps against 268 M x 1)
+__global__ void __launch_bounds__(256) k_extend_kmer_table(GmDevIndex ix, const uint2* prev, uint2* next, int T) {
+    const uint32_t code = blockIdx.x * blockDim.x + threadIdx.x;
+    if (code >= (1u << (2 * T))) return;
+    const uint32_t c = code >> (2 * (T - 1));                        // the leftmost character is searched last
+    const uint2 pv = prev[code & ((1u << (2 * (T - 1))) - 1u)];
+    uint2 out = pv;                                                  // an empty suffix stays empty, with the depth it died at
+    if (pv.x != 0xFFFFFFFFu) {
+        const uint32_t k = gm_L2(ix, c) + gm_occ_plane(ix, pv.x - 1, c) + 1;
+        const uint32_t l = gm_L2(ix, c) + gm_occ_plane(ix, pv.y, c);
+        if (k > l) { out.x = 0xFFFFFFFFu; out.y = (uint32_t)T; } else { out.x = k; out.y = l; }
+    }
+    next[code] = out;
+}
+
 // Compact form of the k-mer table for the seed kernel: the SA intervals of lexicographically consecutive T-mers are adjacent
 // (apart from the few suffixes shorter than T), so 8 consecutive codes need one start rank and 8 hit counts.  16 bytes per 8
 // codes instead of 64: the 10-mer table shrinks from 8 MB to 2 MB and stays in the L2 of every XCD - the seed kernel's random
@@ -2505,6 +2521,12 @@ int gmk_build_occ_planes(const GmDevIndex& ix, uint4* planes, uint32_t nblk, voi
 int gmk_build_kmer_table(const GmDevIndex& ix, uint2* tab, int T, void* stream) {
     uint32_t n = 1u << (2 * T);
     hipLaunchKernelGGL(k_build_kmer_table, dim3(cdiv(n, 256)), dim3(256), 0, S_(stream), ix, tab, T);
+    return (int)hipGetLastError();
+}
+
+int gmk_extend_kmer_table(const GmDevIndex& ix, const uint2* prev, uint2* next, int T, void* stream) {
+    uint32_t n = 1u << (2 * T);
+    hipLaunchKernelGGL(k_extend_kmer_table, dim3(cdiv(n, 256)), dim3(256), 0, S_(stream), ix, prev, next, T);
     return (int)hipGetLastError();
 }
 
