@@ -560,7 +560,7 @@ static int map_pipelined(gm_index* ix, const gm_params* p, const GmDevParams& dp
         }
         if (mx > region) { overflow = true; return GM_OK; }
         ncand[i] = (uint32_t)total;
-        { KTimer t(b, GM_K_NW, ss); KCHK(gmk_nw(ix->dev, dp, view[i], ss)); }
+        { KTimer t(b, GM_K_NW, ss); KCHK(gmk_nw(ix->dev, dp, view[i], ncand[i], ss)); }
         return GM_OK;
     };
     uint32_t next_finish = 0;
@@ -740,7 +740,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
     if (b->raw_cap < b->n_cands + 16ull) b->raw_cap = b->n_cands + 16ull;
     if (b->raw_hits.ensure(b->raw_cap * sizeof(GmRawHit))) return GM_E_NOMEM;
     fill_dev_batch(b);
-    { KTimer t(b, GM_K_NW, st); KCHK(gmk_nw(ix->dev, dp, b->dev, st)); }
+    { KTimer t(b, GM_K_NW, st); KCHK(gmk_nw(ix->dev, dp, b->dev, b->n_cands, st)); }
     { KTimer t(b, GM_K_COMPACT, st); KCHK(gmk_compact(b->dev, st)); }
     b->mapped = true;
     return GM_OK;
@@ -1291,7 +1291,7 @@ extern "C" int gm_dev_nw_score(gm_index* ix, const gm_params* p, const gm_reads*
         if (n && hipMemcpy(b->cands.p, c.data(), (size_t)n * sizeof(GmCand), hipMemcpyHostToDevice) != hipSuccess) { rc = GM_E_HIP; break; }
         if (hipMemset(b->shards.p, 0, (size_t)GM_NSHARD * GM_SHARD_STRIDE * 4) != hipSuccess) { rc = GM_E_HIP; break; }
         if (hipMemcpy(b->shards.p, &n, 4, hipMemcpyHostToDevice) != hipSuccess) { rc = GM_E_HIP; break; }
-        if (gmk_nw(ix->dev, dp, b->dev, nullptr)) { rc = GM_E_HIP; break; }
+        if (gmk_nw(ix->dev, dp, b->dev, n, nullptr)) { rc = GM_E_HIP; break; }
         if (n && hipMemcpy(c.data(), b->cands.p, (size_t)n * sizeof(GmCand), hipMemcpyDeviceToHost) != hipSuccess) { rc = GM_E_HIP; break; }
     } while (0);
     gm_batch_destroy(b);

@@ -113,7 +113,7 @@ int gmk_scan_entries(const GmDevBatch& b, void* stream);
 int gmk_locate_sampled(const GmDevIndex& ix, const GmDevBatch& b, void* stream);
 int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, int dense, int slots_hint, void* stream);
 int gmk_vote_retry(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, uint32_t j0, uint32_t n_retry, void* stream);
-int gmk_nw(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream);
+int gmk_nw(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint32_t n_cands, void* stream);
 int gmk_compact(const GmDevBatch& b, void* stream);
 int gmk_scan_hits(const GmDevBatch& b, void* stream);
 int gmk_scatter(const GmDevBatch& b, uint32_t grid, void* stream);

@@ -2562,7 +2562,8 @@ int gmk_prep(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, vo
 int gmk_seed(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream) {
     if (b.n == 0) return 0;
     // (measured: a grid of exactly the resident workgroups is slower here, 8.7 against 7.6 ms at 10 M reads)
-    hipLaunchKernelGGL(k_seed, dim3((uint32_t)std::min<uint64_t>(cdiv(2ull * b.n, 256), 256 * 12)), dim3(256), (size_t)128 * b.stride, S_(stream), ix, p, b);
+    static const uint32_t seed_grid = [] { const char* e = getenv("GM_SEED_GRID"); return e ? (uint32_t)atoi(e) : 256u * 12u; }();
+    hipLaunchKernelGGL(k_seed, dim3((uint32_t)std::min<uint64_t>(cdiv(2ull * b.n, 256), seed_grid)), dim3(256), (size_t)128 * b.stride, S_(stream), ix, p, b);
     return (int)hipGetLastError();
 }
 
@@ -2668,11 +2669,15 @@ int gmk_vote_retry(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch&
 
 static inline uint32_t lp_of(uint32_t stride) { return (stride + 7u) & ~7u; }
 
-int gmk_nw(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream) {
+int gmk_nw(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint32_t n_cands, void* stream) {
     if (b.n == 0) return 0;
     static const bool wave_form = [] { const char* e = getenv("GM_NW"); return e && !strcmp(e, "wave"); }();
     if (!wave_form) {
-        hipLaunchKernelGGL(k_nw_lane, dim3(2048), dim3(256), 0, S_(stream), ix, p, b);
+        // ~4 candidates per lane: fewer, larger workgroups leave a long tail (measured at 17 M candidates: 2048 workgroups 6.1 ms,
+        // 16384 5.6 ms), more, smaller ones pay their set-up (LDS tables, shard prefix) too often (2 M candidates: 0.77 against 1.02 ms)
+        static const uint32_t nw_fixed = [] { const char* e = getenv("GM_NW_GRID"); return e ? (uint32_t)atoi(e) : 0u; }();
+        uint32_t nw_grid = nw_fixed ? nw_fixed : std::min<uint32_t>(16384u, std::max<uint32_t>(2048u, n_cands / 1024u));
+        hipLaunchKernelGGL(k_nw_lane, dim3(nw_grid), dim3(256), 0, S_(stream), ix, p, b);
         return (int)hipGetLastError();
     }
     uint32_t Lp = lp_of(b.stride);
