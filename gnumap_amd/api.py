@@ -76,7 +76,7 @@ SAM_DTYPE = np.dtype([("read", "<u4"), ("pos", "<u8"), ("contig", "<u4"), ("chr_
                       ("a_score", "<f4"), ("post_prob", "<f4"), ("sim_matches", "<i4"), ("cigar_off", "<u4")], align=True)
 
 # every symbol include/gnumap_hip.h declares
-EXPORTS = ["gm_last_error", "gm_version", "gm_index_build", "gm_index_open", "gm_index_close", "gm_index_get_info", "gm_index_contig_name",
+EXPORTS = ["gm_last_error", "gm_version", "gm_index_build", "gm_index_build_on", "gm_index_open", "gm_index_close", "gm_index_get_info", "gm_index_contig_name",
            "gm_index_contig_offset", "gm_index_window", "gm_params_default", "gm_params_finalize", "gm_batch_create", "gm_batch_destroy",
            "gm_batch_upload", "gm_map_batch_device", "gm_batch_counters", "gm_batch_set_profiling", "gm_batch_kernel_times", "gm_kernel_name",
            "gm_batch_raw_hits", "gm_map_batch", "gm_output_batch",
@@ -101,6 +101,7 @@ def load_library():
     L.gm_last_error.restype = C.c_char_p
     L.gm_version.restype = C.c_char_p
     L.gm_index_build.argtypes = [C.c_char_p]
+    L.gm_index_build_on.argtypes = [C.c_char_p, C.c_int, C.c_int]
     L.gm_index_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.gm_index_close.argtypes = [C.c_void_p]; L.gm_index_close.restype = None
     L.gm_index_get_info.argtypes = [C.c_void_p, C.POINTER(gm_index_info)]
@@ -153,8 +154,12 @@ def version():
     return lib().gm_version().decode()
 
 
-def index_build(fasta):
-    _chk(lib().gm_index_build(os.fsencode(fasta)))
+GM_BUILD_AUTO, GM_BUILD_HOST, GM_BUILD_DEVICE = 0, 1, 2
+
+
+def index_build(fasta, where=GM_BUILD_AUTO, device=0):
+    """write <fasta>.gnumap.{pac,ann,amb,bwt,sa}; the suffix-array stage runs on the MI355X when there is one (same bytes)"""
+    _chk(lib().gm_index_build_on(os.fsencode(fasta), where, device))
 
 
 class Params:

@@ -267,13 +267,15 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
 // ------------------------------------------------------------------------------------------------
 // index
 // ------------------------------------------------------------------------------------------------
-extern "C" int gm_index_build(const char* fasta_path) {
-    if (!fasta_path) return GM_E_ARG;
+extern "C" int gm_index_build_on(const char* fasta_path, int where, int device_id) {
+    if (!fasta_path || where < GM_BUILD_AUTO || where > GM_BUILD_DEVICE || device_id < 0) return GM_E_ARG;
     std::string err;
-    int rc = gm_host_index_build(fasta_path, err);
+    int rc = gm_host_index_build(fasta_path, where, device_id, err);
     if (rc) gm_set_error(err);
     return rc;
 }
+
+extern "C" int gm_index_build(const char* fasta_path) { return gm_index_build_on(fasta_path, GM_BUILD_AUTO, 0); }
 
 extern "C" int gm_index_open(const char* fasta_path, int device_id, int flags, gm_index** out) {
     if (!fasta_path || !out) return GM_E_ARG;
@@ -281,7 +283,7 @@ extern "C" int gm_index_open(const char* fasta_path, int device_id, int flags, g
     std::string fa = fasta_path, err;
     if (!gm_host_index_files_exist(fa)) {
         if (!(flags & GM_INDEX_BUILD)) { gm_set_error("fail to locate the index files for " + fa); return GM_E_IO; }
-        int rc = gm_host_index_build(fa, err);                       // GenomeBwt::LoadGenome: "Could not find reference genome index! Building now."
+        int rc = gm_host_index_build(fa, GM_BUILD_AUTO, device_id < 0 ? 0 : device_id, err);   // GenomeBwt::LoadGenome: "Could not find reference genome index! Building now."
         if (rc) { gm_set_error(err); return rc; }
     }
     gm_index* ix = new gm_index();

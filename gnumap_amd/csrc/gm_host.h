@@ -19,6 +19,10 @@ struct GmHostIndex {
 
 bool gm_host_index_files_exist(const std::string& fa);
 int gm_host_index_load(const std::string& fa, GmHostIndex& ix, std::string& err);
-int gm_host_index_build(const std::string& fa, std::string& err);
+int gm_host_index_build(const std::string& fa, int where /* GM_BUILD_* */, int device_id, std::string& err);
+// gm_sa_build.hip: suffix array / BWT / SA samples of the forward strand on the device
+bool gm_device_available();
+int gm_device_sa_build(const uint8_t* codes, uint64_t n, int device_id, uint32_t intv, std::vector<uint32_t>& plain, uint64_t& primary,
+                       std::vector<uint64_t>& samples, int* rounds_out, std::string& err);
 
 void gm_set_error(const std::string& s);

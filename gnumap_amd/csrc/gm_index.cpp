@@ -180,38 +180,57 @@ inline int nt4(unsigned char c) {
 struct Hole { uint64_t offset; uint32_t len; char amb; };
 struct Ann { std::string name, anno; uint64_t offset; uint32_t len; uint32_t n_ambs; };
 
+// SA stage on the host: SA-IS, then the BWT with '$' removed (is_bwt src/is.c:208-223, bwt_pac2bwt src/bwtindex.c:60-104) and the
+// rank-sampled SA (bwt_cal_sa src/bwt.c:62-84: sa[isa/intv] = SA[isa]; sa[0] is not stored)
 template <class Int>
-int build_from_codes(const std::string& fa, std::vector<uint8_t>& codes /* n symbols 1..4 + sentinel 0 */, std::string& err) {
+int host_sa_stage(std::vector<uint8_t>& codes /* n symbols 1..4 + sentinel 0 */, uint64_t intv, std::vector<uint32_t>& plain, uint64_t& primary,
+                  std::vector<uint64_t>& samples, std::string& err) {
     const uint64_t n = codes.size() - 1;
     std::vector<Int> SA;
     try { SA.resize(n + 1); } catch (...) { err = "out of memory for the suffix array"; return GM_E_NOMEM; }
     Sais<Int, uint8_t>::run(codes.data(), SA.data(), (Int)(n + 1), (Int)5);
-    // BWT of the forward strand with '$' removed (is_bwt src/is.c:208-223, bwt_pac2bwt src/bwtindex.c:60-104)
+    plain.assign((n + 15) >> 4, 0);
+    primary = 0;
+    uint64_t o = 0;
+    for (uint64_t i = 0; i <= n; ++i) {
+        uint64_t sa = (uint64_t)SA[i];
+        if (sa == 0) { primary = i; continue; }
+        uint32_t c = (uint32_t)codes[sa - 1] - 1;
+        plain[o >> 4] |= c << ((15 - (o & 15)) << 1);
+        ++o;
+    }
+    const uint64_t n_sa = (n + intv) / intv;
+    samples.resize(n_sa - 1);
+    for (uint64_t s = 1; s < n_sa; ++s) samples[s - 1] = (uint64_t)SA[s * intv];
+    return GM_OK;
+}
+
+// .bwt and .sa from the SA stage's products (the same bytes whichever device ran the stage)
+int write_bwt_sa(const std::string& fa, const std::vector<uint8_t>& codes, uint64_t intv, const std::vector<uint32_t>& plain, uint64_t primary,
+                 const std::vector<uint64_t>& samples, std::string& err) {
+    const uint64_t n = codes.size() - 1;
     uint64_t L2[5] = { 0, 0, 0, 0, 0 };
     for (uint64_t i = 0; i < n; ++i) L2[codes[i]]++;                  // codes are 1..4 -> L2[1..4]
     for (int i = 2; i <= 4; ++i) L2[i] += L2[i - 1];
-    uint64_t primary = 0;
     const uint64_t n_words = (n + 15) >> 4;
-    std::vector<uint32_t> plain(n_words, 0);
-    {
-        uint64_t o = 0;
-        for (uint64_t i = 0; i <= n; ++i) {
-            uint64_t sa = (uint64_t)SA[i];
-            if (sa == 0) { primary = i; continue; }
-            uint32_t c = (uint32_t)codes[sa - 1] - 1;
-            plain[o >> 4] |= c << ((15 - (o & 15)) << 1);
-            ++o;
-        }
-    }
     // interleave the occurrence counts every 128 bases (bwt_bwtupdate_core src/bwtindex.c:128-150)
     const uint64_t n_occ = (n + 127) / 128 + 1;
     std::vector<uint32_t> bwt(n_words + n_occ * 8, 0);
     {
         uint64_t c[4] = { 0, 0, 0, 0 }, k = 0;
-        for (uint64_t i = 0; i < n; ++i) {
-            if (i % 128 == 0) { memcpy(&bwt[k], c, 32); k += 8; }
-            if (i % 16 == 0) bwt[k++] = plain[i >> 4];
-            ++c[(plain[i >> 4] >> ((~i & 15) << 1)) & 3];
+        const uint64_t full = n >> 4;                                  // words with 16 real symbols
+        for (uint64_t w = 0; w < n_words; ++w) {
+            if ((w & 7) == 0) { memcpy(&bwt[k], c, 32); k += 8; }
+            const uint32_t x = plain[w];
+            bwt[k++] = x;
+            if (w < full) {                                            // 2-bit symbol histogram of one word
+                const uint32_t lo = x & 0x55555555u, hi = (x >> 1) & 0x55555555u;
+                const uint32_t c3 = (uint32_t)__builtin_popcount(hi & lo), c2 = (uint32_t)__builtin_popcount(hi & ~lo),
+                               c1 = (uint32_t)__builtin_popcount(lo & ~hi);
+                c[3] += c3; c[2] += c2; c[1] += c1; c[0] += 16 - c1 - c2 - c3;
+            } else {
+                for (uint64_t i = w << 4; i < n; ++i) ++c[(x >> ((~i & 15) << 1)) & 3];
+            }
         }
         memcpy(&bwt[k], c, 32);
         k += 8;
@@ -221,19 +240,17 @@ int build_from_codes(const std::string& fa, std::vector<uint8_t>& codes /* n sym
     if (!f) { err = "cannot write " + fa + ".gnumap.bwt"; return GM_E_IO; }
     fwrite(&primary, 8, 1, f); fwrite(&L2[1], 8, 4, f); fwrite(bwt.data(), 4, bwt.size(), f);
     fclose(f);
-    // rank-sampled SA, interval 32 (bwt_cal_sa src/bwt.c:62-84: sa[isa/32] = SA[isa]; sa[0] is not stored)
-    const uint64_t intv = 32, n_sa = (n + intv) / intv;
     f = fopen((fa + ".gnumap.sa").c_str(), "wb");
     if (!f) { err = "cannot write " + fa + ".gnumap.sa"; return GM_E_IO; }
     fwrite(&primary, 8, 1, f); fwrite(&L2[1], 8, 4, f); fwrite(&intv, 8, 1, f); fwrite(&n, 8, 1, f);
-    for (uint64_t s = 1; s < n_sa; ++s) { uint64_t v = (uint64_t)SA[s * intv]; fwrite(&v, 8, 1, f); }
+    if (!samples.empty()) fwrite(samples.data(), 8, samples.size(), f);
     fclose(f);
     return GM_OK;
 }
 
 }  // namespace
 
-int gm_host_index_build(const std::string& fa, std::string& err) {
+int gm_host_index_build(const std::string& fa, int where, int device_id, std::string& err) {
     gzFile fp = gzopen(fa.c_str(), "r");
     if (!fp) { err = "cannot open " + fa; return GM_E_IO; }
     // FASTA -> 2-bit codes (+1), annotations and holes: bns_fasta2bntseq/add1 src/bntseq.c:227-328 with for_only = 1
@@ -322,6 +339,23 @@ int gm_host_index_build(const std::string& fa, std::string& err) {
         fclose(f);
     }
     codes.push_back(0);                                                     // the '$' sentinel
-    if (l_pac + 1 < (1ull << 31)) return build_from_codes<int32_t>(fa, codes, err);
-    return build_from_codes<int64_t>(fa, codes, err);
+    // SA stage: on the MI355X when there is one (gm_sa_build.hip), else SA-IS on the host; GM_INDEX_BUILD=host|device overrides "auto"
+    if (where == GM_BUILD_AUTO) {
+        const char* e = getenv("GM_INDEX_BUILD");
+        if (e && !strcmp(e, "host")) where = GM_BUILD_HOST;
+        else if (e && !strcmp(e, "device")) where = GM_BUILD_DEVICE;
+        else where = gm_device_available() && l_pac >= 4096 ? GM_BUILD_DEVICE : GM_BUILD_HOST;
+    }
+    const uint64_t intv = 32;
+    std::vector<uint32_t> plain;
+    std::vector<uint64_t> samples;
+    uint64_t primary = 0;
+    int rc;
+    if (where == GM_BUILD_DEVICE) {
+        if (!gm_device_available()) { err = "no usable HIP device for the device index build"; return GM_E_NO_DEVICE; }
+        rc = gm_device_sa_build(codes.data(), l_pac, device_id, (uint32_t)intv, plain, primary, samples, nullptr, err);
+    } else if (l_pac + 1 < (1ull << 31)) rc = host_sa_stage<int32_t>(codes, intv, plain, primary, samples, err);
+    else rc = host_sa_stage<int64_t>(codes, intv, plain, primary, samples, err);
+    if (rc) return rc;
+    return write_bwt_sa(fa, codes, intv, plain, primary, samples, err);
 }

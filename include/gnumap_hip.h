@@ -159,7 +159,11 @@ const char* gm_last_error(void);
 const char* gm_version(void);
 
 /* ---- index ---- */
-int gm_index_build(const char* fasta_path);                      /* writes <fa>.gnumap.{pac,ann,amb,bwt,sa} */
+int gm_index_build(const char* fasta_path);                      /* writes <fa>.gnumap.{pac,ann,amb,bwt,sa}; = gm_index_build_on(fa, GM_BUILD_AUTO, 0) */
+/* where the suffix-array stage of the build runs (is_sa/is_bwt src/is.c:53-223): the files are byte-identical either way */
+enum { GM_BUILD_AUTO = 0 /* device if there is one, else host; env GM_INDEX_BUILD=host|device */, GM_BUILD_HOST = 1 /* SA-IS */,
+       GM_BUILD_DEVICE = 2 /* prefix doubling in HBM, gm_sa_build.hip */ };
+int gm_index_build_on(const char* fasta_path, int where, int device_id);
 int gm_index_open(const char* fasta_path, int device_id, int flags, gm_index** out);
 void gm_index_close(gm_index*);
 int gm_index_get_info(const gm_index*, gm_index_info* out);

@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Scale check of the hot path on a large synthetic reference (up to human scale, > 2^31 positions): build the index with
+gm_index_build, load it into HBM, map reads drawn from the whole coordinate range (half of them from the last 5 % of the
+reference, where 32-bit signed arithmetic would wrap), compare a random sample read by read with the oracle (test
+infrastructure, like the tests), check that exact reads recover their origin, and report the rate.
+
+    python3 tools/scale_check.py --mbp 2200 --reads 1000000 --mer 10 --max-kmer-hits 150
+
+Prints one JSON line.  --build-only stops after the index build (no GPU needed)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+ACGT = np.frombuffer(b"ACGT", np.uint8)
+COMP = np.zeros(256, np.uint8)
+for a_, c_ in zip(b"ACGT", b"TGCA"):
+    COMP[a_] = c_
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def write_genome(fa, G, n_contigs, seed):
+    """i.i.d. ACGT in 100-column FASTA, generated contig by contig in 64 Mbp pieces (bounded memory); returns contig offsets"""
+    rng = np.random.default_rng(seed)
+    sizes = [G // n_contigs // 100 * 100] * n_contigs
+    sizes[-1] += G - sum(sizes)
+    offs = [0]
+    with open(fa, "wb") as f:
+        for c, n in enumerate(sizes):
+            f.write(b">chr%d\n" % (c + 1))
+            done = 0
+            while done < n:
+                m = min(64_000_000, n - done)
+                seq = ACGT[rng.integers(0, 4, m, dtype=np.uint8)]
+                rows = m // 100
+                blk = np.empty((rows, 101), np.uint8)
+                blk[:, :100] = seq[:rows * 100].reshape(rows, 100)
+                blk[:, 100] = 10
+                f.write(blk.tobytes())
+                if m % 100:
+                    f.write(seq[rows * 100:].tobytes() + b"\n")
+                done += m
+            offs.append(offs[-1] + n)
+    return offs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mbp", type=float, default=2200.0)
+    ap.add_argument("--contigs", type=int, default=24)
+    ap.add_argument("--reads", type=int, default=1_000_000)
+    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--mer", type=int, default=10)
+    ap.add_argument("--max-kmer-hits", type=int, default=0)
+    ap.add_argument("--sample", type=int, default=64, help="reads compared with the oracle")
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--workdir", default="/tmp/gnumap_scale")
+    ap.add_argument("--build-only", action="store_true")
+    a = ap.parse_args()
+
+    if not a.build_only:
+        import torch              # before libgnumap_hip: torch brings its own HIP runtime
+    import gnumap_amd as g
+    G = int(a.mbp * 1e6)
+    L = a.read_len
+    os.makedirs(a.workdir, exist_ok=True)
+    fa = os.path.join(a.workdir, f"g{a.mbp:g}.fa")
+    t = time.time()
+    offs = write_genome(fa, G, a.contigs, 11)
+    t_gen = time.time() - t
+    log(f"[scale] {G} bp FASTA written in {t_gen:.0f} s")
+    t = time.time()
+    g.index_build(fa)
+    t_build = time.time() - t
+    log(f"[scale] index built in {t_build:.0f} s")
+    out = dict(genome_bp=G, contigs=a.contigs, fasta_write_s=round(t_gen, 1), index_build_s=round(t_build, 1))
+    if a.build_only:
+        print(json.dumps(out)); return
+
+    t = time.time()
+    ix = g.Index(fa, flags=g.GM_INDEX_FULL_SA)
+    torch.cuda.synchronize()
+    out.update(index_load_s=round(time.time() - t, 1), index_hbm_gb=round(ix.info.hbm_bytes / 1e9, 2), l_pac=int(ix.info.l_pac))
+    log(f"[scale] index in HBM: {out['index_hbm_gb']} GB, loaded in {out['index_load_s']} s")
+
+    # reads: exact substrings with 1 % substitutions; half of them from the last 5 % of the coordinate range
+    pac = np.memmap(fa + ".gnumap.pac", np.uint8, "r")
+    rng = np.random.default_rng(5)
+    n = a.reads
+    lo_tail = int(G * 0.95)
+    pos = np.where(rng.random(n) < 0.5, rng.integers(lo_tail, G - L, n), rng.integers(0, G - L, n)).astype(np.int64)
+    # keep every read inside one contig
+    oa = np.asarray(offs)
+    ci = np.searchsorted(oa, pos, side="right") - 1
+    pos = np.minimum(pos, oa[ci + 1] - L)
+    idx = pos[:, None] + np.arange(L)[None, :]
+    codes = (pac[idx >> 2] >> ((~idx & 3) << 1).astype(np.uint8)) & 3
+    Bx = ACGT[codes]
+    strand = rng.integers(0, 2, n).astype(np.uint8)
+    Bx = np.where(strand[:, None] == 1, COMP[Bx[:, ::-1]], Bx)
+    exact = Bx.copy()
+    sub = rng.random((n, L)) < 0.01
+    Bx = np.where(sub, ACGT[(np.searchsorted(ACGT, Bx) + rng.integers(1, 4, (n, L))) % 4], Bx)
+    stride = (L + 7) // 8 * 8
+    B = np.zeros((n, stride), np.uint8); Q = np.zeros((n, stride), np.uint8)
+    B[:, :L] = Bx
+    Q[:, :L] = (33 + rng.integers(20, 41, (n, L))).astype(np.uint8)
+    Ln = np.full(n, L, np.uint16)
+
+    kw = dict(mer=a.mer, max_kmer_hits=a.max_kmer_hits)
+    p = g.Params(**kw)
+    batch = g.Batch(ix, n, stride)
+    res = batch.map(p, B, Q, Ln)                       # full host result (hit lists) for the checks
+    c = batch.counters()
+    mb = res["match_begin"]
+    # property: a read whose substitutions left it exact must have its origin among the reported positions
+    is_exact = (Bx == exact).all(1)
+    found = 0; checked = 0
+    for i in np.flatnonzero(is_exact)[:2000]:
+        checked += 1
+        ok = False
+        for m in res["matches"][int(mb[i]):int(mb[i + 1])]:
+            for q in res["positions"][m["pos_begin"]:m["pos_end"]]:
+                if int(q["pos"]) == int(pos[i]) and int(q["strand"]) == int(strand[i]):
+                    ok = True
+        found += ok
+    out.update(exact_reads_checked=checked, exact_reads_origin_found=found, mapped=int((res["status"] == 0).sum()) if "status" in res else None,
+               max_reported_pos=int(res["positions"]["pos"].max()) if len(res["positions"]) else 0)
+
+    # oracle sample
+    from reflib import OracleLib
+    orc = OracleLib()
+    t = time.time()
+    oix = orc.index_load(fa)
+    op = orc.params(**kw)
+    bad = 0
+    t_or = time.time()
+    pick = rng.integers(0, n, a.sample)
+    for i in pick:
+        seq = B[i, :L].tobytes(); qual = Q[i, :L].tobytes()
+        o = orc.map_read(oix, op, orc.pwm(seq, qual), seq)
+        ms = res["matches"][int(mb[i]):int(mb[i + 1])]
+        same = res["status"][i] == o["status"] and res["denominator"][i] == o["denominator"] and res["top_score"][i] == o["top_score"] and len(ms) == len(o["hits"])
+        if same:
+            for m, hh in zip(ms, o["hits"]):
+                same &= np.float32(m["score"]).view(np.uint32) == np.float32(hh["score"]).view(np.uint32)
+                same &= [(int(q["pos"]), int(q["strand"])) for q in res["positions"][m["pos_begin"]:m["pos_end"]]] == [(int(x), int(y)) for x, y in hh["pos"]]
+        bad += not same
+    out.update(oracle_sample=int(a.sample), oracle_mismatches=int(bad), oracle_reads_per_s=round(a.sample / max(1e-9, time.time() - t_or), 1),
+               oracle_tail_reads=int((pos[pick] >= (1 << 31)).sum()))
+
+    # rate with the reads resident in HBM
+    batch.upload(p, B, Q, Ln)
+    batch.map_device(p)
+    torch.cuda.synchronize()
+    batch.kernel_times(); batch.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        batch.map_device(p)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    out.update(reads=n, mer=p.mer, max_kmer_hits=p.max_kmer_hits, ms_per_step=round(dt * 1e3, 2), reads_per_s=round(n / dt, 1),
+               kernels_ms={k: round(ms / max(1, cnt) * (cnt / a.steps), 3) for k, (ms, cnt) in batch.kernel_times().items() if cnt},
+               sa_hits_per_read=round(c["sa_hits"] / n, 1), candidates_per_read=round(c["candidates"] / n, 2), vote_retries=c.get("vote_retries"))
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
