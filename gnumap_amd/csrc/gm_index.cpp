@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 
 // ------------------------------------------------------------------------------------------------
@@ -210,8 +211,6 @@ int write_bwt_sa(const std::string& fa, const std::vector<uint8_t>& codes, uint6
                  const std::vector<uint64_t>& samples, std::string& err) {
     const uint64_t n = codes.size() - 1;
     uint64_t L2[5] = { 0, 0, 0, 0, 0 };
-    for (uint64_t i = 0; i < n; ++i) L2[codes[i]]++;                  // codes are 1..4 -> L2[1..4]
-    for (int i = 2; i <= 4; ++i) L2[i] += L2[i - 1];
     const uint64_t n_words = (n + 15) >> 4;
     // interleave the occurrence counts every 128 bases (bwt_bwtupdate_core src/bwtindex.c:128-150)
     const uint64_t n_occ = (n + 127) / 128 + 1;
@@ -235,6 +234,8 @@ int write_bwt_sa(const std::string& fa, const std::vector<uint8_t>& codes, uint6
         memcpy(&bwt[k], c, 32);
         k += 8;
         if (k != bwt.size()) { err = "inconsistent bwt_size"; return GM_E_IO; }
+        for (int i = 1; i <= 4; ++i) L2[i] = L2[i - 1] + c[i - 1];     // the BWT is a permutation of the text: its totals are the text's
+        if (L2[4] != n) { err = "inconsistent symbol counts"; return GM_E_IO; }
     }
     FILE* f = fopen((fa + ".gnumap.bwt").c_str(), "wb");
     if (!f) { err = "cannot write " + fa + ".gnumap.bwt"; return GM_E_IO; }
@@ -251,6 +252,13 @@ int write_bwt_sa(const std::string& fa, const std::vector<uint8_t>& codes, uint6
 }  // namespace
 
 int gm_host_index_build(const std::string& fa, int where, int device_id, std::string& err) {
+    const bool timing = getenv("GM_TIMING") && atoi(getenv("GM_TIMING"));            // GM_TIMING=1: stage times on stderr
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        auto t = std::chrono::steady_clock::now();
+        if (timing) fprintf(stderr, "[gm_timing] index build: %s %.2f s\n", what, std::chrono::duration<double>(t - t_last).count());
+        t_last = t;
+    };
     gzFile fp = gzopen(fa.c_str(), "r");
     if (!fp) { err = "cannot open " + fa; return GM_E_IO; }
     // FASTA -> 2-bit codes (+1), annotations and holes: bns_fasta2bntseq/add1 src/bntseq.c:227-328 with for_only = 1
@@ -259,51 +267,64 @@ int gm_host_index_build(const std::string& fa, int where, int device_id, std::st
     std::vector<Hole> holes;
     Rand48 rng(11);
     {
-        std::string line;
-        std::vector<char> buf(1 << 16);
+        // byte-stream state machine over large gzread blocks: a '>' at the start of a line opens a header line (name = up to the
+        // first white space, comment = the rest: kseq), every other byte after the first header except '\n' / '\r' is a base (kseq keeps
+        // blanks inside a sequence line, so they become ambiguity holes like any non-ACGT byte)
+        static const struct Lut { uint8_t v[256]; Lut() { for (int c = 0; c < 256; ++c) v[c] = c == '\r' ? 5 : (uint8_t)nt4((unsigned char)c); } } lut;
+        std::vector<unsigned char> buf(8u << 20);
+        std::string header;
+        bool in_header = false, line_start = true, in_seq = false;
         int lasts = 0;
-        bool in_seq = false;
-        auto take_line = [&](const std::string& ln) {
-            if (!ln.empty() && ln[0] == '>') {
-                Ann a;
-                size_t e = 1;
-                while (e < ln.size() && !isspace((unsigned char)ln[e])) ++e;
-                a.name = ln.substr(1, e - 1);
-                size_t c = e;
-                if (c < ln.size()) ++c;                                   // kseq: the comment is what follows the first separator
-                a.anno = c < ln.size() ? ln.substr(c) : std::string();
-                if (a.anno.empty()) a.anno = "(null)";                    // bntseq.c:238
-                a.offset = codes.size(); a.len = 0; a.n_ambs = 0;
-                anns.push_back(a);
-                lasts = 0;
-                in_seq = true;
-                return;
-            }
-            if (!in_seq) return;
-            Ann& a = anns.back();
-            for (char ch : ln) {
-                if (isspace((unsigned char)ch)) continue;
-                int c = nt4((unsigned char)ch);
+        auto take_header = [&](std::string& ln) {
+            if (!ln.empty() && ln.back() == '\r') ln.pop_back();
+            Ann a;
+            size_t e = 0;
+            while (e < ln.size() && !isspace((unsigned char)ln[e])) ++e;
+            a.name = ln.substr(0, e);
+            size_t c = e;
+            if (c < ln.size()) ++c;                                       // kseq: the comment is what follows the first separator
+            a.anno = c < ln.size() ? ln.substr(c) : std::string();
+            if (a.anno.empty()) a.anno = "(null)";                        // bntseq.c:238
+            a.offset = codes.size(); a.len = 0; a.n_ambs = 0;
+            anns.push_back(a);
+            lasts = 0;
+            in_seq = true;
+            ln.clear();
+        };
+        int got;
+        while ((got = gzread(fp, buf.data(), (unsigned)buf.size())) > 0) {
+            const size_t base = codes.size();
+            codes.resize(base + (size_t)got);                             // at most one code per input byte
+            uint8_t* out = codes.data() + base;
+            for (int i = 0; i < got; ++i) {
+                const unsigned char ch = buf[i];
+                if (in_header) {
+                    if (ch == '\n') { codes.resize((size_t)(out - codes.data())); take_header(header); in_header = false; line_start = true;
+                                      const size_t at = codes.size(); codes.resize(at + (size_t)(got - i)); out = codes.data() + at; }
+                    else header.push_back((char)ch);
+                    continue;
+                }
+                if (ch == '\n') { line_start = true; continue; }
+                if (line_start && ch == '>') { in_header = true; line_start = false; continue; }
+                line_start = false;
+                if (!in_seq) continue;
+                int c = lut.v[ch];
+                if (c == 5) continue;                                     // '\r' of a CRLF line end
                 if (c >= 4) {
+                    Ann& a = anns.back();
+                    const uint64_t at = (uint64_t)(out - codes.data());
                     if (lasts == ch) ++holes.back().len;                  // contiguous run of the same ambiguity code
-                    else { Hole h; h.offset = a.offset + a.len; h.len = 1; h.amb = ch; holes.push_back(h); ++a.n_ambs; }
+                    else { Hole h; h.offset = at; h.len = 1; h.amb = (char)ch; holes.push_back(h); ++a.n_ambs; }
                     c = (int)(rng.next() & 3);
                 }
                 lasts = ch;
-                codes.push_back((uint8_t)(c + 1));
-                ++a.len;
+                *out++ = (uint8_t)(c + 1);
             }
-        };
-        while (gzgets(fp, buf.data(), (int)buf.size())) {
-            line += buf.data();
-            if (!line.empty() && line.back() == '\n') {
-                line.pop_back();
-                if (!line.empty() && line.back() == '\r') line.pop_back();
-                take_line(line);
-                line.clear();
-            }
+            codes.resize((size_t)(out - codes.data()));
         }
-        if (!line.empty()) take_line(line);
+        if (in_header) take_header(header);
+        // contig lengths from the offsets
+        for (size_t k = 0; k < anns.size(); ++k) anns[k].len = (uint32_t)((k + 1 < anns.size() ? anns[k + 1].offset : codes.size()) - anns[k].offset);
     }
     gzclose(fp);
     const uint64_t l_pac = codes.size();
@@ -311,7 +332,12 @@ int gm_host_index_build(const std::string& fa, int where, int device_id, std::st
     // .pac
     {
         std::vector<uint8_t> pac((l_pac >> 2) + 1, 0);
-        for (uint64_t l = 0; l < l_pac; ++l) pac[l >> 2] |= (uint8_t)((codes[l] - 1) << ((~l & 3) << 1));
+        const uint64_t quads = l_pac >> 2;
+        for (uint64_t q = 0; q < quads; ++q) {
+            const uint8_t* c4 = &codes[q << 2];
+            pac[q] = (uint8_t)(((c4[0] - 1) << 6) | ((c4[1] - 1) << 4) | ((c4[2] - 1) << 2) | (c4[3] - 1));
+        }
+        for (uint64_t l = quads << 2; l < l_pac; ++l) pac[l >> 2] |= (uint8_t)((codes[l] - 1) << ((~l & 3) << 1));
         FILE* f = fopen((fa + ".gnumap.pac").c_str(), "wb");
         if (!f) { err = "cannot write " + fa + ".gnumap.pac"; return GM_E_IO; }
         fwrite(pac.data(), 1, (l_pac >> 2) + ((l_pac & 3) == 0 ? 0 : 1), f);
@@ -339,6 +365,7 @@ int gm_host_index_build(const std::string& fa, int where, int device_id, std::st
         fclose(f);
     }
     codes.push_back(0);                                                     // the '$' sentinel
+    lap("FASTA -> codes, .pac/.ann/.amb");
     // SA stage: on the MI355X when there is one (gm_sa_build.hip), else SA-IS on the host; GM_INDEX_BUILD=host|device overrides "auto"
     if (where == GM_BUILD_AUTO) {
         const char* e = getenv("GM_INDEX_BUILD");
@@ -357,5 +384,8 @@ int gm_host_index_build(const std::string& fa, int where, int device_id, std::st
     } else if (l_pac + 1 < (1ull << 31)) rc = host_sa_stage<int32_t>(codes, intv, plain, primary, samples, err);
     else rc = host_sa_stage<int64_t>(codes, intv, plain, primary, samples, err);
     if (rc) return rc;
-    return write_bwt_sa(fa, codes, intv, plain, primary, samples, err);
+    lap(where == GM_BUILD_DEVICE ? "suffix array + BWT + samples (device)" : "suffix array + BWT + samples (host SA-IS)");
+    rc = write_bwt_sa(fa, codes, intv, plain, primary, samples, err);
+    lap("occ interleave, .bwt/.sa");
+    return rc;
 }

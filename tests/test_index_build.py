@@ -60,6 +60,21 @@ def test_build_matches_fresh_reference_build(tmp_path, seed, spec):
     _same(mine, ref)
 
 
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref (reference build) not available")
+@pytest.mark.parametrize("text", [
+    b">one desc here\r\nACGTNNACGT\r\nacgtrryACG\r\n>two\r\nTTTTGGGGCCCCAAAA\r\n",          # CRLF
+    b">x\nACGTACGTAC\nGGG",                                                                 # no final newline
+    b"junk before\n>a  two spaces\n\nACGT\n\n  AC GT\n>b\tq\nNNNNACGTNNNN\n>c\n>d\nA\n",       # blanks inside a line, empty contig
+    b">a\nAC>GT\nACGT\n",                                                                   # '>' inside a sequence line
+])
+def test_fasta_parser_edge_cases_match_reference_build(tmp_path, text):
+    mine = str(tmp_path / "mine.fa"); ref = str(tmp_path / "ref.fa")
+    open(mine, "wb").write(text); open(ref, "wb").write(text)
+    g.index_build(mine)
+    assert RefLib().index_build(ref) == 0
+    _same(mine, ref)
+
+
 def test_open_missing_index_fails_loudly(tmp_path):
     fa = str(tmp_path / "none.fa")
     open(fa, "w").write(">x\nACGT\n")
