@@ -380,7 +380,9 @@ int gm_host_index_build(const std::string& fa, int where, int device_id, std::st
     int rc;
     if (where == GM_BUILD_DEVICE) {
         if (!gm_device_available()) { err = "no usable HIP device for the device index build"; return GM_E_NO_DEVICE; }
-        rc = gm_device_sa_build(codes.data(), l_pac, device_id, (uint32_t)intv, plain, primary, samples, nullptr, err);
+        int rounds = 0;
+        rc = gm_device_sa_build(codes.data(), l_pac, device_id, (uint32_t)intv, plain, primary, samples, &rounds, err);
+        if (timing) fprintf(stderr, "[gm_timing] index build: %d doubling rounds after the 21-symbol sort\n", rounds);
     } else if (l_pac + 1 < (1ull << 31)) rc = host_sa_stage<int32_t>(codes, intv, plain, primary, samples, err);
     else rc = host_sa_stage<int64_t>(codes, intv, plain, primary, samples, err);
     if (rc) return rc;
