@@ -76,7 +76,7 @@ def write_genome(fa, G, n_contigs, seed, repeats=False):
     return offs
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--mbp", type=float, default=2200.0)
     ap.add_argument("--contigs", type=int, default=24)
@@ -90,10 +90,9 @@ def main():
     ap.add_argument("--build-only", action="store_true")
     ap.add_argument("--repeats", action="store_true", help="overlay SINE-/LINE-/satellite-like repeat families (28 %% of the genome)")
     ap.add_argument("--no-nw", action="store_true")
-    a = ap.parse_args()
+    ap.add_argument("--keep", action="store_true", help="keep the FASTA and the index files in --workdir")
+    a = ap.parse_args(argv)
 
-    if not a.build_only:
-        import torch              # before libgnumap_hip: torch brings its own HIP runtime
     import gnumap_amd as g
     G = int(a.mbp * 1e6)
     L = a.read_len
@@ -109,11 +108,10 @@ def main():
     log(f"[scale] index built in {t_build:.0f} s")
     out = dict(genome_bp=G, contigs=a.contigs, repeats=bool(a.repeats), fasta_write_s=round(t_gen, 1), index_build_s=round(t_build, 1))
     if a.build_only:
-        print(json.dumps(out)); return
+        print(json.dumps(out)); return out
 
     t = time.time()
-    ix = g.Index(fa, flags=g.GM_INDEX_FULL_SA)
-    torch.cuda.synchronize()
+    ix = g.Index(fa, flags=g.GM_INDEX_FULL_SA)            # returns with the index resident (gm_index_open synchronises)
     out.update(index_load_s=round(time.time() - t, 1), index_hbm_gb=round(ix.info.hbm_bytes / 1e9, 2), l_pac=int(ix.info.l_pac))
     log(f"[scale] index in HBM: {out['index_hbm_gb']} GB, loaded in {out['index_load_s']} s")
 
@@ -187,17 +185,23 @@ def main():
     # rate with the reads resident in HBM
     batch.upload(p, B, Q, Ln)
     batch.map_device(p)
-    torch.cuda.synchronize()
+    batch.counters()                                   # reads the device counters back: waits for the launch stream
     batch.kernel_times(); batch.set_profiling(True)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         batch.map_device(p)
-    torch.cuda.synchronize()
+    batch.counters()
     dt = (time.perf_counter() - t0) / a.steps
     out.update(reads=n, mer=p.mer, max_kmer_hits=p.max_kmer_hits, ms_per_step=round(dt * 1e3, 2), reads_per_s=round(n / dt, 1),
                kernels_ms={k: round(ms / max(1, cnt) * (cnt / a.steps), 3) for k, (ms, cnt) in batch.kernel_times().items() if cnt},
                sa_hits_per_read=round(c["sa_hits"] / n, 1), candidates_per_read=round(c["candidates"] / n, 2), vote_retries=c.get("vote_retries"))
     print(json.dumps(out), flush=True)
+    batch.destroy(); ix.close()
+    if not a.keep:
+        for ext in ("", ".gnumap.pac", ".gnumap.ann", ".gnumap.amb", ".gnumap.bwt", ".gnumap.sa"):
+            if os.path.exists(fa + ext):
+                os.remove(fa + ext)
+    return out
 
 
 if __name__ == "__main__":
