@@ -213,13 +213,15 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
     dp.pos_strand = p->pos_strand; dp.neg_strand = p->neg_strand; dp.align_is_fraction = p->align_is_fraction;
     { const char* e = getenv("GM_DBG"); dp.dbg = e ? atoi(e) : 0; }
     // k-mer interval table: the last T characters of every seed are one lookup (GM_KMER_TABLE=0 keeps the pure occ walk;
-    // GM_KMER_TABLE=<T> picks another suffix length, at most 14)
+    // GM_KMER_TABLE=<T> picks another suffix length, at most 16)
     dp.kmer_tab = nullptr; dp.kmer_T = 0; dp.kmer_ctab = nullptr;
     {
-        // up to 12 characters by default; 14 (2 GB + 0.5 GB compact) for longer seeds on references where the extra occ steps
-        // are HBM misses anyway (>= 50 Mbp)
-        int T = std::min(p->mer, ix->h.seq_len >= 50000000ull ? 14 : 12);
-        if (const char* e = getenv("GM_KMER_TABLE")) T = std::min(std::min(atoi(e), p->mer), 14);
+        // up to 12 characters by default; more for longer seeds on references where the extra occ steps are HBM misses anyway
+        // (>= 50 Mbp): 14 characters = 2 GB + 0.5 GB compact,
+        // 15 / 16 characters (8.6 + 2.1 GB / 34 + 8.6 GB: what 288 GB of HBM is for) when the seeds are that long: a 16-mer is then
+        // ONE random 16-byte probe instead of a probe + two search steps
+        int T = std::min(p->mer, ix->h.seq_len >= 50000000ull ? 16 : 12);
+        if (const char* e = getenv("GM_KMER_TABLE")) T = std::min(std::min(atoi(e), p->mer), 16);
         if (T >= 4) {
             std::lock_guard<std::mutex> lk(ix->mu);
             DevBuf& tb = ix->kmer_tabs[T];

@@ -204,37 +204,38 @@ __global__ void __launch_bounds__(256) k_build_occ_planes(GmDevIndex ix, uint4* 
 // code = sum over characters, leftmost character in the highest bits.  Empty: {0xFFFFFFFF, d} with d = number of
 // characters (from the right end) after which the backward search died.
 __global__ void __launch_bounds__(256) k_build_kmer_table(GmDevIndex ix, uint2* tab, int T) {
-    uint32_t code = blockIdx.x * blockDim.x + threadIdx.x;
-    if (code >= (1u << (2 * T))) return;
-    uint32_t k = 0, l = ix.seq_len;
-    uint2 out;
-    out.x = 0; out.y = 0;
-    bool ok = true;
-    for (int t = 0; t < T; ++t) {                    // t-th character from the right end
-        uint32_t c = (code >> (2 * t)) & 3u;
-        uint32_t ok_ = gm_occ_plane(ix, k - 1, c), ol_ = gm_occ_plane(ix, l, c);
-        k = gm_L2(ix, c) + ok_ + 1;
-        l = gm_L2(ix, c) + ol_;
-        if (k > l) { ok = false; out.x = 0xFFFFFFFFu; out.y = (uint32_t)t + 1; break; }
+    // grid-stride over the codes: T = 16 has 2^32 of them, more work-items than one launch dimension takes
+    for (uint64_t code = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; code < (1ull << (2 * T)); code += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t k = 0, l = ix.seq_len;
+        uint2 out;
+        out.x = 0; out.y = 0;
+        bool ok = true;
+        for (int t = 0; t < T; ++t) {                    // t-th character from the right end
+            uint32_t c = (uint32_t)(code >> (2 * t)) & 3u;
+            uint32_t ok_ = gm_occ_plane(ix, k - 1, c), ol_ = gm_occ_plane(ix, l, c);
+            k = gm_L2(ix, c) + ok_ + 1;
+            l = gm_L2(ix, c) + ol_;
+            if (k > l) { ok = false; out.x = 0xFFFFFFFFu; out.y = (uint32_t)t + 1; break; }
+        }
+        if (ok) { out.x = k; out.y = l; }
+        tab[code] = out;
     }
-    if (ok) { out.x = k; out.y = l; }
-    tab[code] = out;
 }
 
 // One more character on the left of every (T-1)-mer of `prev`: the T-mer table from the (T-1)-mer table with ONE backward-search
 // step per entry (the direct build walks all T steps per entry; at T = 14 that is 268 M x 14 steps against 268 M x 1)
 __global__ void __launch_bounds__(256) k_extend_kmer_table(GmDevIndex ix, const uint2* prev, uint2* next, int T) {
-    const uint32_t code = blockIdx.x * blockDim.x + threadIdx.x;
-    if (code >= (1u << (2 * T))) return;
-    const uint32_t c = code >> (2 * (T - 1));                        // the leftmost character is searched last
-    const uint2 pv = prev[code & ((1u << (2 * (T - 1))) - 1u)];
-    uint2 out = pv;                                                  // an empty suffix stays empty, with the depth it died at
-    if (pv.x != 0xFFFFFFFFu) {
-        const uint32_t k = gm_L2(ix, c) + gm_occ_plane(ix, pv.x - 1, c) + 1;
-        const uint32_t l = gm_L2(ix, c) + gm_occ_plane(ix, pv.y, c);
-        if (k > l) { out.x = 0xFFFFFFFFu; out.y = (uint32_t)T; } else { out.x = k; out.y = l; }
+    for (uint64_t code = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; code < (1ull << (2 * T)); code += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t c = (uint32_t)(code >> (2 * (T - 1)));            // the leftmost character is searched last
+        const uint2 pv = prev[code & ((1ull << (2 * (T - 1))) - 1ull)];
+        uint2 out = pv;                                                  // an empty suffix stays empty, with the depth it died at
+        if (pv.x != 0xFFFFFFFFu) {
+            const uint32_t k = gm_L2(ix, c) + gm_occ_plane(ix, pv.x - 1, c) + 1;
+            const uint32_t l = gm_L2(ix, c) + gm_occ_plane(ix, pv.y, c);
+            if (k > l) { out.x = 0xFFFFFFFFu; out.y = (uint32_t)T; } else { out.x = k; out.y = l; }
+        }
+        next[code] = out;
     }
-    next[code] = out;
 }
 
 // Compact form of the k-mer table for the seed kernel: the SA intervals of lexicographically consecutive T-mers are adjacent
@@ -243,23 +244,23 @@ __global__ void __launch_bounds__(256) k_extend_kmer_table(GmDevIndex ix, const 
 // lookups stop being HBM traffic.  A record is marked "escape" when a count does not fit a byte or its intervals are not
 // adjacent; empty codes (count 0) and escapes are answered from the full table, so results never depend on this form.
 __global__ void __launch_bounds__(256) k_build_kmer_compact(const uint2* tab, uint4* ctab, int T) {
-    const uint32_t rec = blockIdx.x * blockDim.x + threadIdx.x;
-    if (rec >= (1u << (2 * T - 3))) return;
-    uint32_t start = 0, next = 0, w0 = 0, w1 = 0, esc = 0;
-    bool have = false;
-    for (uint32_t i = 0; i < 8; ++i) {
-        const uint2 iv = tab[rec * 8 + i];
-        uint32_t cnt = 0;
-        if (iv.x != 0xFFFFFFFFu) {
-            cnt = iv.y - iv.x + 1;
-            if (!have) { start = iv.x; have = true; }
-            else if (iv.x != next) esc = 1;              // a shorter suffix sorts in between
-            next = iv.y + 1;
-            if (cnt >= 255u) esc = 1;
+    for (uint64_t rec = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; rec < (1ull << (2 * T - 3)); rec += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t start = 0, next = 0, w0 = 0, w1 = 0, esc = 0;
+        bool have = false;
+        for (uint32_t i = 0; i < 8; ++i) {
+            const uint2 iv = tab[rec * 8 + i];
+            uint32_t cnt = 0;
+            if (iv.x != 0xFFFFFFFFu) {
+                cnt = iv.y - iv.x + 1;
+                if (!have) { start = iv.x; have = true; }
+                else if (iv.x != next) esc = 1;              // a shorter suffix sorts in between
+                next = iv.y + 1;
+                if (cnt >= 255u) esc = 1;
+            }
+            if (i < 4) w0 |= (cnt & 255u) << (8 * i); else w1 |= (cnt & 255u) << (8 * (i - 4));
         }
-        if (i < 4) w0 |= (cnt & 255u) << (8 * i); else w1 |= (cnt & 255u) << (8 * (i - 4));
+        ctab[rec] = make_uint4(start, w0, w1, esc);
     }
-    ctab[rec] = make_uint4(start, w0, w1, esc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2531,20 +2532,20 @@ int gmk_build_occ_planes(const GmDevIndex& ix, uint4* planes, uint32_t nblk, voi
 }
 
 int gmk_build_kmer_table(const GmDevIndex& ix, uint2* tab, int T, void* stream) {
-    uint32_t n = 1u << (2 * T);
-    hipLaunchKernelGGL(k_build_kmer_table, dim3(cdiv(n, 256)), dim3(256), 0, S_(stream), ix, tab, T);
+    const uint64_t n = 1ull << (2 * T);
+    hipLaunchKernelGGL(k_build_kmer_table, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 1u << 22)), dim3(256), 0, S_(stream), ix, tab, T);
     return (int)hipGetLastError();
 }
 
 int gmk_extend_kmer_table(const GmDevIndex& ix, const uint2* prev, uint2* next, int T, void* stream) {
-    uint32_t n = 1u << (2 * T);
-    hipLaunchKernelGGL(k_extend_kmer_table, dim3(cdiv(n, 256)), dim3(256), 0, S_(stream), ix, prev, next, T);
+    const uint64_t n = 1ull << (2 * T);
+    hipLaunchKernelGGL(k_extend_kmer_table, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 1u << 22)), dim3(256), 0, S_(stream), ix, prev, next, T);
     return (int)hipGetLastError();
 }
 
 int gmk_build_kmer_compact(const uint2* tab, uint4* ctab, int T, void* stream) {
-    uint32_t n = 1u << (2 * T - 3);
-    hipLaunchKernelGGL(k_build_kmer_compact, dim3(cdiv(n, 256)), dim3(256), 0, S_(stream), tab, ctab, T);
+    const uint64_t n = 1ull << (2 * T - 3);
+    hipLaunchKernelGGL(k_build_kmer_compact, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 1u << 22)), dim3(256), 0, S_(stream), tab, ctab, T);
     return (int)hipGetLastError();
 }
 
