@@ -241,21 +241,25 @@ __global__ void __launch_bounds__(256) k_extend_kmer_table(GmDevIndex ix, const 
 // Compact form of the k-mer table for the seed kernel: the SA intervals of lexicographically consecutive T-mers are adjacent
 // (apart from the few suffixes shorter than T), so 8 consecutive codes need one start rank and 8 hit counts.  16 bytes per 8
 // codes instead of 64: the 10-mer table shrinks from 8 MB to 2 MB and stays in the L2 of every XCD - the seed kernel's random
-// lookups stop being HBM traffic.  A record is marked "escape" when a count does not fit a byte or its intervals are not
-// adjacent; empty codes (count 0) and escapes are answered from the full table, so results never depend on this form.
+// lookups stop being HBM traffic.  A count byte of 224..239 marks an empty code and carries the depth at which its backward
+// search died (what the seed walk needs to slide on), so the k-mers of the wrong strand - most of the probes with long seeds -
+// cost ONE 128-byte line, not two.  A record is marked "escape" when a count does not fit (>= 224) or its intervals are not
+// adjacent; escapes are answered from the full table, so results never depend on this form.
 __global__ void __launch_bounds__(256) k_build_kmer_compact(const uint2* tab, uint4* ctab, int T) {
     for (uint64_t rec = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; rec < (1ull << (2 * T - 3)); rec += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t start = 0, next = 0, w0 = 0, w1 = 0, esc = 0;
         bool have = false;
         for (uint32_t i = 0; i < 8; ++i) {
             const uint2 iv = tab[rec * 8 + i];
-            uint32_t cnt = 0;
+            uint32_t cnt;
             if (iv.x != 0xFFFFFFFFu) {
                 cnt = iv.y - iv.x + 1;
                 if (!have) { start = iv.x; have = true; }
                 else if (iv.x != next) esc = 1;              // a shorter suffix sorts in between
                 next = iv.y + 1;
-                if (cnt >= 255u) esc = 1;
+                if (cnt >= 224u) esc = 1;
+            } else {
+                cnt = 223u + iv.y;                           // empty: 224..239 = the search died after iv.y (1..16) characters
             }
             if (i < 4) w0 |= (cnt & 255u) << (8 * i); else w1 |= (cnt & 255u) << (8 * (i - 4));
         }
@@ -410,8 +414,14 @@ __global__ void __launch_bounds__(256) k_seed(GmDevIndex ix, GmDevParams p, GmDe
                             const uint32_t sub = code & 7u;
                             const unsigned long long cw = (unsigned long long)rec.y | ((unsigned long long)rec.z << 32);
                             const uint32_t cnt = (uint32_t)(cw >> (8 * sub)) & 255u;
-                            if (rec.w == 0u && cnt != 0u) {
-                                const unsigned long long below = sub ? (cw & (~0ull >> (64 - 8 * sub))) : 0ull;
+                            if (rec.w == 0u && cnt >= 224u) {        // empty, and the record says after how many characters: no second probe
+                                ok = false; t = p.mer - (int)(cnt - 223u);
+                                answered = true;
+                            } else if (rec.w == 0u) {
+                                unsigned long long below = sub ? (cw & (~0ull >> (64 - 8 * sub))) : 0ull;
+                                // bytes >= 224 are empty codes, not counts: a byte's bit 7 survives iff its bits 7, 6 and 5 are all set
+                                const unsigned long long emp = below & (below << 1) & (below << 2) & 0x8080808080808080ull;
+                                below &= ~((emp >> 7) * 0xFFull);
                                 unsigned long long s2 = (below & 0x00FF00FF00FF00FFull) + ((below >> 8) & 0x00FF00FF00FF00FFull);      // 4 x 16-bit sums
                                 const uint32_t pre = (uint32_t)((s2 * 0x0001000100010001ull) >> 48);
                                 k = rec.x + pre; l = k + cnt - 1;
