@@ -1490,9 +1490,9 @@ __device__ __forceinline__ uint32_t gm_wave_scan_incl(uint32_t x) {
 // reference: ~150 hits per seed): 32 slots per wave, a longer list, the second filter takes the whole zeroed region
 // (4096 x 16 bit) and the table its own 4 KB.
 template <bool MASK64, bool FULL, int SMAX>
-__global__ void __launch_bounds__(128, SMAX == 64 ? 5 : 7) k_vote_slots(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
+__global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vote_slots(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
     constexpr bool BIG = SMAX == 64;
-    constexpr int LCAP = BIG ? 1280 : GMS_LCAP;
+    constexpr int LCAP = BIG ? 1280 : SMAX == 16 ? 320 : GMS_LCAP;      // 16-slot form: 10.0 KB of LDS, 16 workgroups per CU
     static_assert(SMAX == 16 || SMAX == 24 || SMAX == GMS_SMAX || SMAX == 64, "instantiated forms");
     constexpr int NT = 128, NW = 2, U = SMAX / NW, ZK = 512 / NT;
     static_assert(NW == 2, "the list is two stacks growing towards each other");
