@@ -29,7 +29,20 @@ for c in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_
 done
 echo "[collect] vote phase clocks"
 GM_DBG=64 $B --reads 1000000 --cpu-seconds 0 > /dev/null 2> "$OUT/phase.log"
+if [ "${MATRIX:-1}" = "1" ]; then
+    echo "[collect] bench matrix over the BASELINE configurations (10 M reads per step, CPU oracle 5 s each)"
+    : > "$OUT/matrix.jsonl"
+    for args in "--mer 10 --no-nw" "--mer 12" "--mer 14" "--mer 16 --jump 8" "--mer 20 --jump 10" "--genome-mbp 20 --contigs 3" \
+                "--genome-mbp 156 --contigs 1" "--genome-mbp 156 --contigs 1 --mer 16 --jump 8" \
+                "--genome-mbp 3100 --contigs 24 --mer 14" "--genome-mbp 3100 --contigs 24 --mer 14 --no-nw" \
+                "--genome-mbp 3100 --contigs 24 --mer 20 --jump 10 --max-kmer-hits 150" \
+                "--genome-mbp 3100 --contigs 24 --mer 20 --jump 10 --max-kmer-hits 150 --no-nw"; do
+        echo "[collect]   bench.py $args"
+        $B $args --cpu-seconds 5 >> "$OUT/matrix.jsonl" 2>> "$OUT/matrix.log"
+    done
+fi
 cd "$ROOT"
+[ -s "$OUT/matrix.jsonl" ] && cp "$OUT/matrix.jsonl" profiles/${TAG}_bench_matrix_10M.jsonl
 python3 tools/summarize_prof.py "$OUT"/stats/*/*_kernel_stats.csv profiles/${TAG}_kernel_stats_10M.csv "$OUT/bench_traced.json"
 python3 tools/pmc_summary.py "$OUT/pmc" 1000000 $KEY profiles/${TAG}_pmc_1M.txt profiles/pmc_latest.json
 python3 tools/pmc_sq.py "$OUT/sq" k_ > profiles/${TAG}_sq_counters_1M.txt
