@@ -224,6 +224,14 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
         if (const char* e = getenv("GM_KMER_TABLE")) T = std::min(std::min(atoi(e), p->mer), 16);
         if (T >= 4) {
             std::lock_guard<std::mutex> lk(ix->mu);
+            // the 15- / 16-character tables are bought with free HBM: step down while table + previous level + compact form (+ 8 GB
+            // for the batches) do not fit what is free right now
+            while (T > 14 && !ix->kmer_tabs.count(T)) {
+                size_t fr = 0, tot = 0;
+                const size_t need = (((size_t)1 << (2 * T)) + ((size_t)1 << (2 * T - 2))) * 8 + ((size_t)1 << (2 * T - 3)) * 16 + ((size_t)8 << 30);
+                if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr >= need) break;
+                --T;
+            }
             DevBuf& tb = ix->kmer_tabs[T];
             if (!tb.p) {
                 if (tb.ensure(((size_t)1 << (2 * T)) * 8)) return GM_E_NOMEM;
