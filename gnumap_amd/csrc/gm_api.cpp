@@ -640,6 +640,9 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         const double slots_exp = ns * ceil((per_seed + 3.0 * sqrt(per_seed) + 1.0) / 64.0);
         dense = e_exp > 14.0 ? (slots_exp <= 38.0 ? 1 : slots_exp <= 60.0 ? 2 : 3) : 0;
         slots_hint = (int)std::min(1000.0, slots_exp);
+        // few hits in many short runs (long seeds on a large reference): one wave per read x strand, 16-rank groups (k_vote_tiny)
+        const double groups_exp = ns * ceil((per_seed + 3.0 * sqrt(per_seed) + 1.0) / 16.0);
+        if (dense == 1 && p->min_seed_hits >= 2 && e_exp + 4.0 * sqrt(e_exp) <= 230.0 && groups_exp <= 28.0) slots_hint = 0;
         if (const char* ev = getenv("GM_VOTE_SLOTS")) slots_hint = atoi(ev);
         if (const char* ev = getenv("GM_VOTE")) dense = !strcmp(ev, "block") ? 1 : !strcmp(ev, "big") ? 2 : !strcmp(ev, "rounds") ? 3 : !strcmp(ev, "wave") ? 0 : dense;
     }

@@ -1784,6 +1784,181 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
     if (prof) atomicAdd(&b.counters[GMK_DBG8], 1ull);
 }
 
+// ---- k_vote_tiny: one WAVEFRONT per read x strand, for at most 256 SA hits in at most 32 groups of 16 ranks ----------------
+// Long seeds on a large reference (-m 14 on 3.1 Gbp: 13 seeds x ~12 hits) leave k_vote_slots latency-bound: a workgroup's life is
+// three dependent HBM round trips (seeds, SA ranks, candidate reservation) and 10 KB of LDS allow 16 of them per CU.  Here a read x
+// strand is one wave and ~5.8 KB of LDS (27 per CU), a descriptor covers 16 consecutive ranks of one seed (a 64-lane step holds
+// four seeds' hits: ~75 % of the lanes carry a hit instead of ~20 %), there is no first counting filter (every hit goes to the
+// list), and the list goes through the second filter (1024 x 16 bit) into a 128-slot exact table as in k_vote_slots.
+// More hits or groups than that -> b.big_list -> k_vote_fast_list; a table that fills up -> the retry kernel.
+#define GMT_Q 32                         // 16-rank groups per read x strand
+#define GMT_LCAP 256                     // hits per read x strand
+template <bool MASK64, bool FULL>
+__global__ void __launch_bounds__(64, 8) k_vote_tiny(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
+    constexpr int U = GMT_Q / 4, T2 = 128;
+    __shared__ uint4 s_r0v[256];                      // 4 KB: words [0,512) = 1024 x 16-bit counters, [512,1024) = 128 x key | votes | low mask | high mask
+    __shared__ uint32_t s_lbp[GMT_LCAP];
+    __shared__ uint8_t s_lt[GMT_LCAP];
+    __shared__ uint2 s_desc[GMT_Q];                   // {SA rank (flat entry index if !FULL) of the group's first hit, read offset | tag << 16 | hits << 24}
+    __shared__ uint32_t s_cnt0[64];
+    uint32_t* const s_r0 = reinterpret_cast<uint32_t*>(s_r0v);
+    const uint32_t rs = blockIdx.x;                   // grid = 2n
+    const int lane = threadIdx.x;
+    GmSeed sd; sd.k = 0; sd.l = 0; sd.pos = 0;
+    if ((uint32_t)lane < b.max_seeds) sd = b.seeds[(size_t)rs * b.max_seeds + lane];
+    uint32_t ns = b.n_seeds[rs];
+    if (p.nw && p.fast && ns > 1) ns = 1;
+    const uint32_t cnt = (uint32_t)lane < ns ? sd.l - sd.k + 1 : 0u;
+    const uint32_t nq = (cnt + 15u) >> 4;
+    const uint32_t ie = gm_wave_scan_incl(cnt), iq = gm_wave_scan_incl(nq);
+    const uint32_t E = __builtin_amdgcn_readlane(ie, 63), Q = __builtin_amdgcn_readlane(iq, 63);
+    if (Q == 0) return;                               // wave-uniform: nothing to vote on
+    if (Q > GMT_Q || E > GMT_LCAP) {                  // wave-uniform: hand over to the list kernel
+        if (lane == 0) { const uint32_t at = atomicAdd(b.n_big, 1u); b.big_list[at] = rs; }
+        return;
+    }
+    if (lane < GMT_Q) s_desc[lane] = make_uint2(0u, 0u);
+    s_cnt0[lane] = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_r0v[lane + 64 * k] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    {
+        const uint32_t q0 = iq - nq, e0 = ie - cnt;
+        for (uint32_t j = 0; j < nq; ++j) {
+            const uint32_t left = cnt - 16u * j;
+            s_desc[q0 + j] = make_uint2((FULL ? sd.k : e0) + 16u * j, sd.pos | ((uint32_t)lane << 16) | ((left < 16u ? left : 16u) << 24));
+        }
+    }
+    __syncthreads();
+    const uint32_t* const src = FULL ? ix.full_sa : b.coords + b.entry_off[rs];
+    // ---- loads: step j holds groups 4j .. 4j+3, lane -> group 4j + lane / 16, rank = first rank + lane % 16
+    uint32_t bpv[U], tg[U];
+    unsigned long long zero_votes = 0;               // (step, lane) pairs that hold a b = 0 vote: rare
+    const uint32_t sub = (uint32_t)lane & 15u;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const uint2 d = s_desc[4 * j + (lane >> 4)];
+        const bool valid = sub < (d.y >> 24);
+        tg[j] = (d.y >> 16) & 63u;
+        uint32_t v = 0;
+        if (valid) v = src[d.x + sub];
+        bpv[j] = valid ? __builtin_elementwise_sub_sat(v, d.y & 0xFFFFu) : 0xFFFFFFFFu;      // :267; 0xFFFFFFFF = no hit (never a window start)
+    }
+    // ---- every hit goes to the list; b = 0 votes are counted per step tag
+    uint32_t wcount = 0;
+    bool any0 = false;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const bool hit = bpv[j] != 0xFFFFFFFFu;
+        const bool z = hit && bpv[j] == 0u;
+        if (z) atomicAdd(&s_cnt0[tg[j]], 1u);
+        any0 |= z;
+        const bool pass = hit && !z;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+        if (pass) {
+            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, wcount));      // < E <= GMT_LCAP
+            s_lbp[at] = bpv[j]; s_lt[at] = (uint8_t)tg[j];
+        }
+        wcount += (uint32_t)__popcll(m);
+    }
+    const bool wave_any0 = __builtin_amdgcn_ballot_w64(any0) != 0ull;
+    __syncthreads();
+    uint32_t* const keys = s_r0 + 512; uint32_t* const vals = keys + T2; uint32_t* const mlo = keys + 2 * T2; uint32_t* const mhi = keys + 3 * T2;
+    const uint32_t n_l = wcount;
+    const uint32_t thr = (uint32_t)(p.kmin < 1 ? 1 : p.kmin);
+    uint32_t bp4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t i = 64u * q + (uint32_t)lane;
+        bp4[q] = i < n_l ? s_lbp[i] : 0u;
+        if (bp4[q] != 0u) {
+            const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> 22;
+            atomicAdd(&s_r0[h2 & 511u], 1u << ((h2 >> 9) << 4));
+        }
+    }
+    __syncthreads();
+    bool full = false;
+    uint32_t nkeys = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> 22;
+        const uint32_t c = (s_r0[h2 & 511u] >> ((h2 >> 9) << 4)) & 0xFFFFu;
+        bool fresh = false;
+        if (bp4[q] != 0u && c >= thr) {
+            const uint32_t bp = bp4[q], t = s_lt[64u * q + (uint32_t)lane];
+            uint32_t slot = (bp * 0x9E3779B1u) >> 25;
+            uint32_t old;
+            int probes = 0;
+            while ((old = atomicCAS(&keys[slot], 0u, bp)) != 0u && old != bp && ++probes < T2) slot = (slot + 1) & (T2 - 1);
+            fresh = old == 0u;
+            if (!(old == 0u || old == bp)) full = true;
+            else {
+                atomicAdd(&vals[slot], 1u);
+                if (t < 32) atomicOr(&mlo[slot], 1u << t);
+                else if (MASK64) atomicOr(&mhi[slot], 1u << (t - 32));
+            }
+        }
+        nkeys += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(fresh));
+    }
+    __syncthreads();
+    if (__builtin_amdgcn_ballot_w64(full) != 0ull || nkeys > (uint32_t)(T2 * 3 / 4)) {     // hand this read x strand to the global-table kernel
+        if (lane == 0) {
+            b.rs_overflow[rs] = 1;
+            const uint32_t j = atomicAdd(b.n_retry, 1u);
+            const uint32_t need = 2 * E; uint32_t sz = 1024; while (sz < need && sz < 0x80000000u) sz <<= 1;
+            const unsigned long long off = atomicAdd(&b.counters[GMK_HEAVY_SLOTS], (unsigned long long)sz);
+            b.retry_list[j] = rs;
+            b.retry_off[j] = off;
+            atomicAdd(&b.counters[GMK_OVERFLOW_RS], 1ull);
+        }
+        return;
+    }
+    {   // ---- emit: two table slots per lane, one candidate reservation per wave (as in k_vote_slots)
+        bool em[2]; uint32_t ky[2], st[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t slot = (uint32_t)(q * 64 + lane);
+            const uint32_t key = keys[slot], v = vals[slot];
+            em[q] = key != 0u && v >= (uint32_t)p.kmin;
+            ky[q] = key; st[q] = 0;
+            if (em[q]) {
+                if (p.nw) {
+                    unsigned long long m = (unsigned long long)mlo[slot] | (MASK64 ? ((unsigned long long)mhi[slot] << 32) : 0ull);
+                    for (int r = 1; r < p.kmin; ++r) m &= m - 1;
+                    st[q] = m ? (uint32_t)(__ffsll((long long)m) - 1) : 0u;
+                } else st[q] = v > 65535u ? 65535u : v;
+            }
+        }
+        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(em[0]), m1 = __builtin_amdgcn_ballot_w64(em[1]);
+        const uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1);
+        if (n0 + n1 != 0u) {                         // wave-uniform
+            const uint32_t shard = blockIdx.x & (GM_NSHARD - 1);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&b.shard_cnt[shard * GM_SHARD_STRIDE], n0 + n1);
+            base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (em[q]) {
+                    const unsigned long long mq = q ? m1 : m0;
+                    const uint32_t idx = base + (q ? n0 : 0u) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
+                    if (idx < b.cand_region) {
+                        GmCand c;
+                        c.rs = rs; c.b = ky[q]; c.step = (uint16_t)st[q]; c.flags = 4; c.pad = 0; c.score = 0.0f;
+                        b.cands[(size_t)shard * b.cand_region + idx] = c;
+                    }
+                }
+        }
+    }
+    if (wave_any0) {                                  // b = 0: cumulative per-step counts
+        const uint32_t run = gm_wave_scan_incl(s_cnt0[lane]);
+        const uint32_t total = __builtin_amdgcn_readlane(run, 63);
+        const unsigned long long reached = __builtin_amdgcn_ballot_w64(run >= (uint32_t)p.kmin);
+        const bool emit = lane == 0 && total >= (uint32_t)p.kmin;
+        const uint32_t step = p.nw ? (uint32_t)(__ffsll((long long)reached) - 1) : (total > 65535u ? 65535u : total);
+        gm_emit<GmLdsTable>(b, emit, rs, 0u, step, 4);
+    }
+}
+
 // ---- vote kernel v4 (dense seeds): seed-uniform load steps, tag filter with plain LDS stores ----------------------
 // The workgroup walks "steps": step s covers NT consecutive SA ranks of ONE seed, so the seed (its step index, SA base and
 // read offset) is wave-uniform and no per-hit table lookups are needed.  All steps' loads are issued back to back.
@@ -2616,10 +2791,11 @@ int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, in
         static const char* const kenv = getenv("GM_VOTE_KERNEL");
         const bool slots_form = kenv ? !strcmp(kenv, "slots") : dense <= 2;      // dense == 2: the 64-slot form; 3: rounds of the block form
         if (slots_form) {                           // default: wave-uniform seed slots + the list kernel for what it hands over
-            const int slot_form = dense == 2 ? 64 : slots_hint <= 14 ? 16 : slots_hint <= 22 ? 24 : GMS_SMAX;
+            const int slot_form = dense == 2 ? 64 : slots_hint == 0 ? 0 : slots_hint <= 14 ? 16 : slots_hint <= 22 ? 24 : GMS_SMAX;      // 0 = k_vote_tiny
             const uint32_t lgrid = (uint32_t)std::min<uint64_t>(cdiv(2ull * b.n, 4), 256 * 20);
 #define GM_LAUNCH_VSL1(M, F, S) hipLaunchKernelGGL((k_vote_slots<M, F, S>), dim3(2 * b.n), dim3(128), 0, S_(stream), ix, p, b)
-#define GM_LAUNCH_VSL(M, F) do { if (slot_form == 64) GM_LAUNCH_VSL1(M, F, 64); else if (slot_form == 16) GM_LAUNCH_VSL1(M, F, 16); \
+#define GM_LAUNCH_VSL(M, F) do { if (slot_form == 0) hipLaunchKernelGGL((k_vote_tiny<M, F>), dim3(2 * b.n), dim3(64), 0, S_(stream), ix, p, b); \
+                                 else if (slot_form == 64) GM_LAUNCH_VSL1(M, F, 64); else if (slot_form == 16) GM_LAUNCH_VSL1(M, F, 16); \
                                  else if (slot_form == 24) GM_LAUNCH_VSL1(M, F, 24); else GM_LAUNCH_VSL1(M, F, GMS_SMAX); } while (0)
             if (m64) { if (use_full_sa) GM_LAUNCH_VSL(true, true); else GM_LAUNCH_VSL(true, false); }
             else { if (use_full_sa) GM_LAUNCH_VSL(false, true); else GM_LAUNCH_VSL(false, false); }

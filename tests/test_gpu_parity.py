@@ -378,9 +378,13 @@ def test_pipelined_sub_batches_equal_single_pass(ix_full, syn_reads, packed, mon
     assert len(first) == len(last) and np.array_equal(first["pos"], last["pos"])
 
 
+_VARIANT_BASELINE = {}
+
+
 @pytest.mark.parametrize("env", [dict(GM_VOTE="block"),                                             # dense seeds: k_vote_slots (the default dense kernel)
                                  dict(GM_VOTE="big"), dict(GM_VOTE="rounds"),                      # its 64-slot form; rounds of the block form
                                  dict(GM_VOTE="block", GM_VOTE_SLOTS="10"), dict(GM_VOTE="block", GM_VOTE_SLOTS="40"),   # 16-slot form (+ list kernel), 40-slot form
+                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="0"), dict(GM_VOTE="block", GM_VOTE_SLOTS="0", GM_TEST_SAMPLED="1"),   # k_vote_tiny (+ list kernel, retry kernel)
                                  dict(GM_VOTE="block", GM_VOTE_KERNEL="block"), dict(GM_VOTE="block", GM_VOTE_KERNEL="block", GM_VOTE_NT="64"),
                                  dict(GM_VOTE="block", GM_VOTE_KERNEL="block", GM_VOTE_NT="256"), dict(GM_VOTE="block", GM_VOTE_KERNEL="block", GM_VOTE_TB="10"),
                                  dict(GM_VOTE="block", GM_VOTE_KERNEL="steps"), dict(GM_VOTE="block", GM_VOTE_KERNEL="pipe"),
@@ -412,10 +416,12 @@ b.upload(p, B, Q, Ln); b.map_device(p)
 hits, status, self_score, top = b.raw_hits()
 print(json.dumps(dict(hits=hits.tobytes().hex(), status=status.tobytes().hex(), top=top.tobytes().hex())))
 """
-    outs = []
-    for e in ({}, env):
+    def run(e):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **e), timeout=300)
         assert r.returncode == 0, r.stderr[-1500:]
-        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    if cfg not in _VARIANT_BASELINE:                 # the default dispatch on this configuration: computed once per configuration
+        _VARIANT_BASELINE[cfg] = run({})
+    outs = [_VARIANT_BASELINE[cfg], run(env)]
     assert outs[0] == outs[1]
     assert len(outs[0]["hits"]) > 16 * 2 * 100
