@@ -1787,16 +1787,16 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
 // ---- k_vote_tiny: one WAVEFRONT per read x strand, for at most 256 SA hits in at most 32 groups of 16 ranks ----------------
 // Long seeds on a large reference (-m 14 on 3.1 Gbp: 13 seeds x ~12 hits) leave k_vote_slots latency-bound: a workgroup's life is
 // three dependent HBM round trips (seeds, SA ranks, candidate reservation) and 10 KB of LDS allow 16 of them per CU.  Here a read x
-// strand is one wave and ~5.8 KB of LDS (27 per CU), a descriptor covers 16 consecutive ranks of one seed (a 64-lane step holds
+// strand is one wave and 4.9 KB of LDS (32 per CU: every wave slot of the CU), a descriptor covers 16 consecutive ranks of one seed (a 64-lane step holds
 // four seeds' hits: ~75 % of the lanes carry a hit instead of ~20 %), there is no first counting filter (every hit goes to the
-// list), and the list goes through the second filter (1024 x 16 bit) into a 128-slot exact table as in k_vote_slots.
+// list), and the list goes through the second filter (512 x 16 bit) into a 128-slot exact table as in k_vote_slots.
 // More hits or groups than that -> b.big_list -> k_vote_fast_list; a table that fills up -> the retry kernel.
 #define GMT_Q 32                         // 16-rank groups per read x strand
 #define GMT_LCAP 256                     // hits per read x strand
 template <bool MASK64, bool FULL>
 __global__ void __launch_bounds__(64, 8) k_vote_tiny(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
     constexpr int U = GMT_Q / 4, T2 = 128;
-    __shared__ uint4 s_r0v[256];                      // 4 KB: words [0,512) = 1024 x 16-bit counters, [512,1024) = 128 x key | votes | low mask | high mask
+    __shared__ uint4 s_r0v[192];                      // 3 KB: words [0,256) = 512 x 16-bit counters, [256,768) = 128 x key | votes | low mask | high mask
     __shared__ uint32_t s_lbp[GMT_LCAP];
     __shared__ uint8_t s_lt[GMT_LCAP];
     __shared__ uint2 s_desc[GMT_Q];                   // {SA rank (flat entry index if !FULL) of the group's first hit, read offset | tag << 16 | hits << 24}
@@ -1820,7 +1820,7 @@ __global__ void __launch_bounds__(64, 8) k_vote_tiny(GmDevIndex ix, GmDevParams 
     if (lane < GMT_Q) s_desc[lane] = make_uint2(0u, 0u);
     s_cnt0[lane] = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) s_r0v[lane + 64 * k] = make_uint4(0u, 0u, 0u, 0u);
+    for (int k = 0; k < 3; ++k) s_r0v[lane + 64 * k] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     {
         const uint32_t q0 = iq - nq, e0 = ie - cnt;
@@ -1863,7 +1863,7 @@ __global__ void __launch_bounds__(64, 8) k_vote_tiny(GmDevIndex ix, GmDevParams 
     }
     const bool wave_any0 = __builtin_amdgcn_ballot_w64(any0) != 0ull;
     __syncthreads();
-    uint32_t* const keys = s_r0 + 512; uint32_t* const vals = keys + T2; uint32_t* const mlo = keys + 2 * T2; uint32_t* const mhi = keys + 3 * T2;
+    uint32_t* const keys = s_r0 + 256; uint32_t* const vals = keys + T2; uint32_t* const mlo = keys + 2 * T2; uint32_t* const mhi = keys + 3 * T2;
     const uint32_t n_l = wcount;
     const uint32_t thr = (uint32_t)(p.kmin < 1 ? 1 : p.kmin);
     uint32_t bp4[4];
@@ -1872,8 +1872,8 @@ __global__ void __launch_bounds__(64, 8) k_vote_tiny(GmDevIndex ix, GmDevParams 
         const uint32_t i = 64u * q + (uint32_t)lane;
         bp4[q] = i < n_l ? s_lbp[i] : 0u;
         if (bp4[q] != 0u) {
-            const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> 22;
-            atomicAdd(&s_r0[h2 & 511u], 1u << ((h2 >> 9) << 4));
+            const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> 23;
+            atomicAdd(&s_r0[h2 & 255u], 1u << ((h2 >> 8) << 4));
         }
     }
     __syncthreads();
@@ -1881,8 +1881,8 @@ __global__ void __launch_bounds__(64, 8) k_vote_tiny(GmDevIndex ix, GmDevParams 
     uint32_t nkeys = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> 22;
-        const uint32_t c = (s_r0[h2 & 511u] >> ((h2 >> 9) << 4)) & 0xFFFFu;
+        const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> 23;
+        const uint32_t c = (s_r0[h2 & 255u] >> ((h2 >> 8) << 4)) & 0xFFFFu;
         bool fresh = false;
         if (bp4[q] != 0u && c >= thr) {
             const uint32_t bp = bp4[q], t = s_lt[64u * q + (uint32_t)lane];
