@@ -643,6 +643,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         // few hits in many short runs (long seeds on a large reference): one wave per read x strand, 16-rank groups (k_vote_tiny)
         const double groups_exp = ns * ceil((per_seed + 3.0 * sqrt(per_seed) + 1.0) / 16.0);
         if (dense == 1 && p->min_seed_hits >= 2 && e_exp + 4.0 * sqrt(e_exp) <= 230.0 && groups_exp <= 28.0) slots_hint = 0;
+        else if (dense == 1 && p->min_seed_hits >= 2 && e_exp + 4.0 * sqrt(e_exp) <= 350.0 && groups_exp <= 56.0) slots_hint = -1;      // k_vote_tiny2
         if (const char* ev = getenv("GM_VOTE_SLOTS")) slots_hint = atoi(ev);
         if (const char* ev = getenv("GM_VOTE")) dense = !strcmp(ev, "block") ? 1 : !strcmp(ev, "big") ? 2 : !strcmp(ev, "rounds") ? 3 : !strcmp(ev, "wave") ? 0 : dense;
     }

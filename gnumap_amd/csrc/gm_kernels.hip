@@ -1959,6 +1959,162 @@ __global__ void __launch_bounds__(64, 8) k_vote_tiny(GmDevIndex ix, GmDevParams 
     }
 }
 
+// ---- k_vote_tiny2: the same one-wave form for up to 384 hits in up to 64 groups (150-bp reads on a human-size reference: 20
+// seeds x ~12 hits; 10-mers on 20 Mbp).  No list at all: the hits stay in registers (16 steps), go through the 1024 x 16-bit
+// filter and, where their slot reached -k, straight into a 256-slot exact table.  6.8 KB of LDS: 23 read x strands per CU.
+#define GMT2_Q 64
+#define GMT2_E 384
+template <bool MASK64, bool FULL>
+__global__ void __launch_bounds__(64, 6) k_vote_tiny2(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
+    constexpr int U = GMT2_Q / 4, T2 = 256;
+    __shared__ uint4 s_r0v[384];                      // 6 KB: words [0,512) = 1024 x 16-bit counters, [512,1536) = 256 x key | votes | low mask | high mask
+    __shared__ uint2 s_desc[GMT2_Q];
+    __shared__ uint32_t s_cnt0[64];
+    uint32_t* const s_r0 = reinterpret_cast<uint32_t*>(s_r0v);
+    const uint32_t rs = blockIdx.x;                   // grid = 2n
+    const int lane = threadIdx.x;
+    GmSeed sd; sd.k = 0; sd.l = 0; sd.pos = 0;
+    if ((uint32_t)lane < b.max_seeds) sd = b.seeds[(size_t)rs * b.max_seeds + lane];
+    uint32_t ns = b.n_seeds[rs];
+    if (p.nw && p.fast && ns > 1) ns = 1;
+    const uint32_t cnt = (uint32_t)lane < ns ? sd.l - sd.k + 1 : 0u;
+    const uint32_t nq = (cnt + 15u) >> 4;
+    const uint32_t ie = gm_wave_scan_incl(cnt), iq = gm_wave_scan_incl(nq);
+    const uint32_t E = __builtin_amdgcn_readlane(ie, 63), Q = __builtin_amdgcn_readlane(iq, 63);
+    if (Q == 0) return;                               // wave-uniform: nothing to vote on
+    if (Q > GMT2_Q || E > GMT2_E) {                   // wave-uniform: hand over to the list kernel
+        if (lane == 0) { const uint32_t at = atomicAdd(b.n_big, 1u); b.big_list[at] = rs; }
+        return;
+    }
+    s_desc[lane] = make_uint2(0u, 0u);
+    s_cnt0[lane] = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s_r0v[lane + 64 * k] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    {
+        const uint32_t q0 = iq - nq, e0 = ie - cnt;
+        for (uint32_t j = 0; j < nq; ++j) {
+            const uint32_t left = cnt - 16u * j;
+            s_desc[q0 + j] = make_uint2((FULL ? sd.k : e0) + 16u * j, sd.pos | ((uint32_t)lane << 16) | ((left < 16u ? left : 16u) << 24));
+        }
+    }
+    __syncthreads();
+    const uint32_t* const src = FULL ? ix.full_sa : b.coords + b.entry_off[rs];
+    uint32_t bpv[U], tg[U];
+    const uint32_t sub = (uint32_t)lane & 15u;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const uint2 d = s_desc[4 * j + (lane >> 4)];
+        const bool valid = sub < (d.y >> 24);
+        tg[j] = (d.y >> 16) & 63u;
+        uint32_t v = 0;
+        if (valid) v = src[d.x + sub];
+        bpv[j] = valid ? __builtin_elementwise_sub_sat(v, d.y & 0xFFFFu) : 0xFFFFFFFFu;      // :267; 0xFFFFFFFF = no hit
+    }
+    // ---- pass A: b = 0 votes per step tag; every other hit counts in the filter.  Afterwards bpv = 0 means "nothing here".
+    bool any0 = false;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const bool hit = bpv[j] != 0xFFFFFFFFu;
+        const bool z = hit && bpv[j] == 0u;
+        if (z) atomicAdd(&s_cnt0[tg[j]], 1u);
+        any0 |= z;
+        if (!hit) bpv[j] = 0u;
+        if (bpv[j] != 0u) {
+            const uint32_t h2 = (bpv[j] * 0x85EBCA6Bu) >> 22;
+            atomicAdd(&s_r0[h2 & 511u], 1u << ((h2 >> 9) << 4));
+        }
+    }
+    const bool wave_any0 = __builtin_amdgcn_ballot_w64(any0) != 0ull;
+    __syncthreads();
+    // ---- pass B: hits whose filter slot reached -k enter the exact table
+    uint32_t* const keys = s_r0 + 512; uint32_t* const vals = keys + T2; uint32_t* const mlo = keys + 2 * T2; uint32_t* const mhi = keys + 3 * T2;
+    const uint32_t thr = (uint32_t)(p.kmin < 1 ? 1 : p.kmin);
+    bool full = false;
+    uint32_t nkeys = 0;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const uint32_t bp = bpv[j];
+        const uint32_t h2 = (bp * 0x85EBCA6Bu) >> 22;
+        const uint32_t c = (s_r0[h2 & 511u] >> ((h2 >> 9) << 4)) & 0xFFFFu;
+        bool fresh = false;
+        if (bp != 0u && c >= thr) {
+            const uint32_t t = tg[j];
+            uint32_t slot = (bp * 0x9E3779B1u) >> 24;
+            uint32_t old;
+            int probes = 0;
+            while ((old = atomicCAS(&keys[slot], 0u, bp)) != 0u && old != bp && ++probes < T2) slot = (slot + 1) & (T2 - 1);
+            fresh = old == 0u;
+            if (!(old == 0u || old == bp)) full = true;
+            else {
+                atomicAdd(&vals[slot], 1u);
+                if (t < 32) atomicOr(&mlo[slot], 1u << t);
+                else if (MASK64) atomicOr(&mhi[slot], 1u << (t - 32));
+            }
+        }
+        nkeys += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(fresh));
+    }
+    __syncthreads();
+    if (__builtin_amdgcn_ballot_w64(full) != 0ull || nkeys > (uint32_t)(T2 * 3 / 4)) {     // hand this read x strand to the global-table kernel
+        if (lane == 0) {
+            b.rs_overflow[rs] = 1;
+            const uint32_t j = atomicAdd(b.n_retry, 1u);
+            const uint32_t need = 2 * E; uint32_t sz = 1024; while (sz < need && sz < 0x80000000u) sz <<= 1;
+            const unsigned long long off = atomicAdd(&b.counters[GMK_HEAVY_SLOTS], (unsigned long long)sz);
+            b.retry_list[j] = rs;
+            b.retry_off[j] = off;
+            atomicAdd(&b.counters[GMK_OVERFLOW_RS], 1ull);
+        }
+        return;
+    }
+    {   // ---- emit: four table slots per lane, one candidate reservation per wave
+        bool em[4]; uint32_t ky[4], st[4], nb[4];
+        unsigned long long mk[4];
+        uint32_t total = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t slot = (uint32_t)(q * 64 + lane);
+            const uint32_t key = keys[slot], v = vals[slot];
+            em[q] = key != 0u && v >= (uint32_t)p.kmin;
+            ky[q] = key; st[q] = 0;
+            if (em[q]) {
+                if (p.nw) {
+                    unsigned long long m = (unsigned long long)mlo[slot] | (MASK64 ? ((unsigned long long)mhi[slot] << 32) : 0ull);
+                    for (int r = 1; r < p.kmin; ++r) m &= m - 1;
+                    st[q] = m ? (uint32_t)(__ffsll((long long)m) - 1) : 0u;
+                } else st[q] = v > 65535u ? 65535u : v;
+            }
+            mk[q] = __builtin_amdgcn_ballot_w64(em[q]);
+            nb[q] = total;
+            total += (uint32_t)__popcll(mk[q]);
+        }
+        if (total != 0u) {                           // wave-uniform
+            const uint32_t shard = blockIdx.x & (GM_NSHARD - 1);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&b.shard_cnt[shard * GM_SHARD_STRIDE], total);
+            base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (em[q]) {
+                    const uint32_t idx = base + nb[q] + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk[q] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk[q], 0u));
+                    if (idx < b.cand_region) {
+                        GmCand c;
+                        c.rs = rs; c.b = ky[q]; c.step = (uint16_t)st[q]; c.flags = 4; c.pad = 0; c.score = 0.0f;
+                        b.cands[(size_t)shard * b.cand_region + idx] = c;
+                    }
+                }
+        }
+    }
+    if (wave_any0) {                                  // b = 0: cumulative per-step counts
+        const uint32_t run = gm_wave_scan_incl(s_cnt0[lane]);
+        const uint32_t total = __builtin_amdgcn_readlane(run, 63);
+        const unsigned long long reached = __builtin_amdgcn_ballot_w64(run >= (uint32_t)p.kmin);
+        const bool emit = lane == 0 && total >= (uint32_t)p.kmin;
+        const uint32_t step = p.nw ? (uint32_t)(__ffsll((long long)reached) - 1) : (total > 65535u ? 65535u : total);
+        gm_emit<GmLdsTable>(b, emit, rs, 0u, step, 4);
+    }
+}
+
 // ---- vote kernel v4 (dense seeds): seed-uniform load steps, tag filter with plain LDS stores ----------------------
 // The workgroup walks "steps": step s covers NT consecutive SA ranks of ONE seed, so the seed (its step index, SA base and
 // read offset) is wave-uniform and no per-hit table lookups are needed.  All steps' loads are issued back to back.
@@ -2791,10 +2947,11 @@ int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, in
         static const char* const kenv = getenv("GM_VOTE_KERNEL");
         const bool slots_form = kenv ? !strcmp(kenv, "slots") : dense <= 2;      // dense == 2: the 64-slot form; 3: rounds of the block form
         if (slots_form) {                           // default: wave-uniform seed slots + the list kernel for what it hands over
-            const int slot_form = dense == 2 ? 64 : slots_hint == 0 ? 0 : slots_hint <= 14 ? 16 : slots_hint <= 22 ? 24 : GMS_SMAX;      // 0 = k_vote_tiny
+            const int slot_form = dense == 2 ? 64 : slots_hint == 0 ? 0 : slots_hint < 0 ? -1 : slots_hint <= 14 ? 16 : slots_hint <= 22 ? 24 : GMS_SMAX;      // 0 = k_vote_tiny, -1 = k_vote_tiny2
             const uint32_t lgrid = (uint32_t)std::min<uint64_t>(cdiv(2ull * b.n, 4), 256 * 20);
 #define GM_LAUNCH_VSL1(M, F, S) hipLaunchKernelGGL((k_vote_slots<M, F, S>), dim3(2 * b.n), dim3(128), 0, S_(stream), ix, p, b)
 #define GM_LAUNCH_VSL(M, F) do { if (slot_form == 0) hipLaunchKernelGGL((k_vote_tiny<M, F>), dim3(2 * b.n), dim3(64), 0, S_(stream), ix, p, b); \
+                                 else if (slot_form == -1) hipLaunchKernelGGL((k_vote_tiny2<M, F>), dim3(2 * b.n), dim3(64), 0, S_(stream), ix, p, b); \
                                  else if (slot_form == 64) GM_LAUNCH_VSL1(M, F, 64); else if (slot_form == 16) GM_LAUNCH_VSL1(M, F, 16); \
                                  else if (slot_form == 24) GM_LAUNCH_VSL1(M, F, 24); else GM_LAUNCH_VSL1(M, F, GMS_SMAX); } while (0)
             if (m64) { if (use_full_sa) GM_LAUNCH_VSL(true, true); else GM_LAUNCH_VSL(true, false); }

@@ -394,7 +394,8 @@ _VARIANT_BASELINE = {}
                                  dict(GM_VOTE="wave"), dict(GM_VOTE="wave", GM_VOTE_SPARSE="0"),
                                  dict(GM_NW="wave"), dict(GM_KMER_TABLE="0"), dict(GM_KMER_TABLE="6"), dict(GM_KMER_COMPACT="0"),
                                  dict(GM_KMER_TABLE="13"), dict(GM_KMER_TABLE="14"),           # tables extended one character at a time (m20_j2, k1)
-                                 dict(GM_KMER_TABLE="15"), dict(GM_KMER_TABLE="16")])          # 2^30 / 2^32 codes (64-bit code arithmetic), 43 GB of HBM at 16
+                                 dict(GM_KMER_TABLE="15"), dict(GM_KMER_TABLE="16"),           # 2^30 / 2^32 codes (64-bit code arithmetic), 43 GB of HBM at 16
+                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="-1"), dict(GM_VOTE="block", GM_VOTE_SLOTS="-1", GM_TEST_SAMPLED="1")])   # k_vote_tiny2
 @pytest.mark.parametrize("cfg", ["default", "no_nw", "k3", "h30", "m6_j2", "m20_j2", "k1"])
 def test_every_kernel_variant_matches_oracle(env, cfg, syn_fa, oracle, oix, syn_reads, packed):
     """the dispatch heuristics pick kernels by seed density; force each variant on the same inputs (fresh process state is
