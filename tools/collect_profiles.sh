@@ -9,23 +9,24 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-KEY=g100m_c6_s42_L100_m10_full
+KEY=${KEY:-g100m_c6_s42_L100_m10_full}       # workload key of profiles/pmc_latest.json (bench.py matches it)
+# BENCH_ARGS="--genome-mbp 3100 --contigs 24 --mer 14" KEY=g3100m_c24_s42_L100_m14_full MATRIX=0 LATEST=0 tools/collect_profiles.sh r01c_human
 cd /tmp                                            # rocprofv3 scratch files go to the cwd
-B="python3 $ROOT/bench.py"
+B="python3 $ROOT/bench.py ${BENCH_ARGS:-}"
 echo "[collect] plain bench"
 $B > "$OUT/bench.json" 2> "$OUT/bench.log"
 echo "[collect] kernel trace + stats"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --cpu-seconds 0 > "$OUT/bench_traced.json" 2> "$OUT/stats.log"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" ${BENCH_ARGS:-} --cpu-seconds 0 > "$OUT/bench_traced.json" 2> "$OUT/stats.log"
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" TCC_EA0_RDREQ_sum; do
     d="$OUT/pmc/$(echo $c | tr ' ' '_')"
     echo "[collect] pmc $c"
-    rocprofv3 --output-format csv --pmc $c -d "$d" -- python3 "$ROOT/bench.py" --reads 1000000 --steps 2 --cpu-seconds 0 > /dev/null 2> "$OUT/pmc.log"
+    rocprofv3 --output-format csv --pmc $c -d "$d" -- python3 "$ROOT/bench.py" ${BENCH_ARGS:-} --reads 1000000 --steps 2 --cpu-seconds 0 > /dev/null 2> "$OUT/pmc.log"
 done
 for c in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD" \
          "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS"; do
     d="$OUT/sq/$(echo $c | cut -d' ' -f1)"
     echo "[collect] pmc $c"
-    rocprofv3 --output-format csv --pmc $c -d "$d" -- python3 "$ROOT/bench.py" --reads 1000000 --steps 2 --cpu-seconds 0 > /dev/null 2> "$OUT/sq.log" || echo "[collect] SQ pass failed (see sq.log)"
+    rocprofv3 --output-format csv --pmc $c -d "$d" -- python3 "$ROOT/bench.py" ${BENCH_ARGS:-} --reads 1000000 --steps 2 --cpu-seconds 0 > /dev/null 2> "$OUT/sq.log" || echo "[collect] SQ pass failed (see sq.log)"
 done
 echo "[collect] vote phase clocks"
 GM_DBG=64 $B --reads 1000000 --cpu-seconds 0 > /dev/null 2> "$OUT/phase.log"
@@ -44,7 +45,8 @@ fi
 cd "$ROOT"
 [ -s "$OUT/matrix.jsonl" ] && cp "$OUT/matrix.jsonl" profiles/${TAG}_bench_matrix_10M.jsonl
 python3 tools/summarize_prof.py "$OUT"/stats/*/*_kernel_stats.csv profiles/${TAG}_kernel_stats_10M.csv "$OUT/bench_traced.json"
-python3 tools/pmc_summary.py "$OUT/pmc" 1000000 $KEY profiles/${TAG}_pmc_1M.txt profiles/pmc_latest.json
+if [ "${LATEST:-1}" = "1" ]; then PJ=profiles/pmc_latest.json; else PJ="$OUT/pmc_other.json"; fi
+python3 tools/pmc_summary.py "$OUT/pmc" 1000000 $KEY profiles/${TAG}_pmc_1M.txt $PJ
 python3 tools/pmc_sq.py "$OUT/sq" k_ > profiles/${TAG}_sq_counters_1M.txt
 grep "gm_dbg" "$OUT/phase.log" > profiles/${TAG}_vote_phase_clocks_1M.txt || true
 tail -1 "$OUT/bench.json" > profiles/${TAG}_bench_full_10M.json
