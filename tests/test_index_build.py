@@ -80,3 +80,18 @@ def test_open_missing_index_fails_loudly(tmp_path):
     open(fa, "w").write(">x\nACGT\n")
     with pytest.raises(g.GnumapError, match="fail to locate the index files"):
         g.Index(fa, flags=g.GM_INDEX_HOST_ONLY)
+
+
+def test_build_on_argument_and_device_errors(tmp_path):
+    """gm_index_build_on: a bad `where` is an argument error; asking for the device build without a GPU fails loudly (no
+    silent host fallback); GM_BUILD_HOST works without one"""
+    import torch
+    fa = str(tmp_path / "x.fa")
+    open(fa, "w").write(">x\n" + "ACGTTGCAAGGCTTAACCGGTTAA" * 20 + "\n")
+    with pytest.raises(g.GnumapError):
+        g.index_build(fa, where=7)
+    if not torch.cuda.is_available():
+        with pytest.raises(g.GnumapError, match="no usable HIP device"):
+            g.index_build(fa, where=g.GM_BUILD_DEVICE)
+    g.index_build(fa, where=g.GM_BUILD_HOST)
+    assert os.path.getsize(fa + ".gnumap.bwt") > 0
