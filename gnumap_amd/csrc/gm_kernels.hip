@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(256) k_prep(GmDevIndex ix, GmDevParams p, GmDe
 // ------------------------------------------------------------------------------------------------
 // seed: one lane per read x strand walks the read exactly like align_sequence does
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_seed(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
+__global__ void __launch_bounds__(256, 8) k_seed(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
     // the 128 reads of this workgroup (2 lanes per read: + and - strand) are staged into LDS with coalesced 16-byte loads
     extern __shared__ __attribute__((aligned(16))) unsigned char s_reads[];
     unsigned long long nk = 0, nocc = 0, nblk = 0, ntab = 0, nseed_all = 0, nent_all = 0;
