@@ -58,7 +58,7 @@ static void usage(int rc, const char* msg) {
             "  -k, --num_seed=INT           Minimum number of seed matches per location (default: 2)\n"
             "  -h, --max_kmer=INT           Kmers occuring more often than this are skipped (default: no limit)\n"
             "  -T, --max_match=INT          Maximum number of matches per read (default: 1000)\n"
-            "  -u, --unique                 Only match sequences to one position\n"
+            "  -u X                         Only match sequences to one position (like the reference, -u swallows the next word)\n"
             "  -G, --gap_penalty=DOUBLE     Gap penalty (default: -4)\n"
             "  -c, --num_proc=INT           accepted for compatibility (the GPU path ignores it)\n"
             "  -b, --bs_seq / --b2 / -d, --a_to_g   bisulfite / A-to-G scoring\n"
@@ -115,7 +115,9 @@ static void parse_args(int argc, char** argv, Options& o) {
         }
         if (strlen(a) > 2) { fprintf(stderr, "Irregular Parameter in: %s\n", a); exit(1); }
         char c = a[1];
-        bool flag = strchr("prubd0", c) != nullptr;
+        // -u takes no value but the reference's parser consumes the next argv all the same (src/Driver.cpp:2768-2770 lacks the
+        // count--): a command line written for the reference has a filler word there, so the same is done here
+        bool flag = strchr("prbd0", c) != nullptr;
         const char* v = nullptr;
         if (!flag) { if (i + 1 >= argc) usage(1, "missing value"); v = argv[++i]; }
         switch (c) {
@@ -168,6 +170,7 @@ struct Block {
     // results of the two batch calls
     std::vector<gm_sam_rec> recs; std::vector<char> pool; uint64_t n_recs = 0;
     int gpu = 0;
+    int illumina = 0;                       // --illumina still in force when this block starts (the fallback is sticky, SeqReader.cpp:1171-1180)
     std::vector<std::string> text;          // SAM text, one piece per formatter thread
     bool failed = false;
 };
@@ -357,6 +360,7 @@ static double secs_since(std::chrono::steady_clock::time_point t0) { return std:
 
 static int process_block(Worker& w, const Options& o, Block& b) {
     const uint32_t n = b.n;
+    gm_params bp = o.p; bp.illumina = b.illumina;
     auto c0 = std::chrono::steady_clock::now();
     pack_block(b, 4);
     gm_reads reads; reads.n = n; reads.stride = b.stride; reads.bases = b.bases.data(); reads.quals = b.qbuf.data(); reads.len = b.len.data();
@@ -370,7 +374,7 @@ static int process_block(Worker& w, const Options& o, Block& b) {
         hits.denominator = w.den.data(); hits.match_begin = w.mbegin.data();
         hits.matches = w.matches.data(); hits.matches_cap = w.matches.size();
         hits.positions = w.positions.data(); hits.positions_cap = w.positions.size();
-        int rc = gm_map_batch(w.ix, &o.p, w.batch, &reads, &hits, nullptr);
+        int rc = gm_map_batch(w.ix, &bp, w.batch, &reads, &hits, nullptr);
         if (rc == GM_E_CAPACITY) { w.matches.resize(hits.matches_cap + 64); w.positions.resize(hits.positions_cap + 64); continue; }
         if (rc != GM_OK) { fprintf(stderr, "ERROR: gm_map_batch: %s\n", gm_last_error()); return rc; }
         break;
@@ -381,7 +385,7 @@ static int process_block(Worker& w, const Options& o, Block& b) {
     gm_sam_out so;
     for (;;) {
         so.recs = b.recs.data(); so.recs_cap = b.recs.size(); so.cigar_pool = b.pool.data(); so.cigar_cap = b.pool.size();
-        int rc = gm_output_batch(w.ix, &o.p, w.batch, &reads, &hits, &so, nullptr);
+        int rc = gm_output_batch(w.ix, &bp, w.batch, &reads, &hits, &so, nullptr);
         if (rc == GM_E_CAPACITY) { b.recs.resize(so.recs_cap + 64); b.pool.resize(so.cigar_cap + 64); continue; }
         if (rc != GM_OK) { fprintf(stderr, "ERROR: gm_output_batch: %s\n", gm_last_error()); return rc; }
         break;
@@ -451,6 +455,7 @@ int main(int argc, char** argv) {
 
     std::thread scanner([&] {
         uint64_t idx = 0;
+        int ill_state = o.p.illumina;
         Block* b;
         while (!failed && free_q.pop(b)) {
             auto s0 = std::chrono::steady_clock::now();
@@ -458,6 +463,10 @@ int main(int argc, char** argv) {
             t_scan += secs_since(s0);
             if (!more) { free_q.push(b); break; }
             b->index = idx++; b->failed = false;
+            b->illumina = ill_state;
+            if (ill_state)                              // gILLUMINA is cleared for the rest of the run by the first quality below '@'
+                for (uint32_t i = 0; i < b->n && ill_state; ++i)
+                    for (uint32_t t = 0; t < b->len[i]; ++t) if ((unsigned char)b->qual[i][t] < 64) { ill_state = 0; break; }
             map_q.push(b);
         }
         map_q.close();

@@ -792,7 +792,7 @@ int gmo_format_sam(const gmo_index* ix, const gmo_params* p, const gmo_sam* s, c
 /* ============================================================================================
  * Whole run (parallel_thread_run Driver.cpp:2303-2407; PrintFinalSGR GenomeBwt.cpp:1212-1273)
  * ==========================================================================================*/
-typedef struct { char* name; char* seq; char* qual; int L; } fq_rec;
+typedef struct { char* name; char* seq; char* qual; int L; int ill; } fq_rec;
 typedef struct { char* sam; size_t sam_len; gmo_deposit* deps; int n_deps; int matched; gmo_counters ctr; } read_out;
 
 typedef struct {
@@ -810,7 +810,7 @@ static void map_one(work_t* w, uint64_t i) {
     memset(ro, 0, sizeof *ro);
     int L = fr->L;
     float* pwm = (float*)malloc(sizeof(float) * 4 * (size_t)(L > 0 ? L : 1));
-    int ill = w->illumina;
+    int ill = fr->ill;
     if (gmo_pwm_from_fastq(fr->seq, fr->qual, L, &ill, pwm) != 0) { free(pwm); return; }
     gmo_result r;
     gmo_map_read(w->ix, w->p, pwm, fr->seq, L, &r);
@@ -872,6 +872,15 @@ int gmo_run(const gmo_index* ix, const gmo_params* p, const char* fastq, const c
         n++;
     }
     fclose(f);
+    /* --illumina falls back to Phred+33 at the first negative quality and STAYS there for every later read of the run
+     * (gILLUMINA is a global cleared at SeqReader.cpp:1174; reads are parsed in file order under read_lock) */
+    {
+        int ill = p->illumina;
+        for (uint64_t i = 0; i < n; ++i) {
+            if (ill) for (const char* q = recs[i].qual; *q && q < recs[i].qual + recs[i].L; ++q) if ((int)*q - 64 < 0) { ill = 0; break; }
+            recs[i].ill = ill;
+        }
+    }
     work_t w; memset(&w, 0, sizeof w);
     w.ix = ix; w.p = p; w.recs = recs; w.n = n; w.illumina = p->illumina;
     w.outs = (read_out*)calloc(n ? n : 1, sizeof(read_out));

@@ -22,7 +22,7 @@ def pytest_configure(config):
 @pytest.fixture(scope="session", autouse=True)
 def _build_checkers():
     """Build the test-only checkers (oracle restatement; reference harness where /root/reference exists)."""
-    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle", "ref"], check=True,
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle", "ref", "refbin"], check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     # the product itself (hipcc cross-compiles gfx950 without a GPU); a failure here must be loud
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "gnumap_amd")], check=True, stdout=subprocess.DEVNULL)

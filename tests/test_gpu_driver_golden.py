@@ -1,0 +1,64 @@
+"""The product (gnumap binary -> C ABI -> HIP kernels) against the outputs of the UNMODIFIED reference program
+(tests/golden/ref_runs/, made by tests/golden/make_driver_fixtures.py from oracle/_ref/gnumap_ref): the SAME argv as the
+reference was run with, SAM text byte-identical including record order; .sgr / .gmp equal up to the order of fp32 atomic adds."""
+import gzip
+import json
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+RUNS = os.path.join(GOLDEN, "ref_runs")
+MANIFEST = json.load(open(os.path.join(RUNS, "manifest.json")))
+EXE = os.path.join(ROOT, "gnumap_amd", "bin", "gnumap")
+
+
+def ref_text(mode, ext):
+    return gzip.open(os.path.join(RUNS, f"{mode}.{ext}.gz"), "rt").read()
+
+
+def track(text, ncol):
+    d = {}
+    for line in text.splitlines():
+        f = line.split("\t")
+        assert len(f) == ncol, line
+        d[(f[0], int(f[1]))] = [float(x) for x in f[2:]]
+    return d
+
+
+def compare_tracks(mine, ref, ncol):
+    a, b = track(mine, ncol), track(ref, ncol)
+    assert len(b) > 100 or not b
+    # a bin whose fp32-atomic sum is a rounding error away from the 0.001 print threshold may differ in presence only
+    for k in set(a) ^ set(b):
+        assert (a.get(k) or b.get(k))[0] < 2e-3, k
+    for k in set(a) & set(b):
+        for x, y in zip(a[k], b[k]):
+            assert abs(x - y) <= 1e-4 * max(1.0, abs(y)) + 2e-5, (k, x, y)
+
+
+@pytest.mark.parametrize("extra", [[], ["--locate=sampled"], ["--batch=64", "--workers=2"]], ids=["full_sa", "sampled_sa", "batch64"])
+@pytest.mark.parametrize("mode", sorted(MANIFEST))
+def test_cli_equals_reference_program(mode, extra, tmp_path):
+    m = MANIFEST[mode]
+    if extra and mode not in ("default", "no_nw", "bs_all", "T2", "u", "illumina", "k1_all", "m16_h150_all"):
+        pytest.skip("index / batching variants run on a subset of the modes")
+    out = str(tmp_path / "mine")
+    r = subprocess.run([EXE, "-g", os.path.join(GOLDEN, "syn.fa"), "-o", out, "-a", "0.9"] + m["argv"] + extra + [os.path.join(GOLDEN, m["fastq"])],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    sam = "".join(l for l in open(out + ".sam") if not l.startswith("@PG"))
+    ref = ref_text(mode, "sam")
+    if sam != ref:
+        a, b = sam.splitlines(), ref.splitlines()
+        first = next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), min(len(a), len(b)))
+        pytest.fail(f"{mode}: {len(a)} vs {len(b)} lines, first difference at line {first}:\n  mine {a[first] if first < len(a) else None}\n  ref  {b[first] if first < len(b) else None}")
+    if "sgr" in m["tracks"]:
+        assert not os.path.exists(out + ".gmp")
+        compare_tracks(open(out + ".sgr").read(), ref_text(mode, "sgr"), 3)
+    else:
+        assert not os.path.exists(out + ".sgr")
+        compare_tracks(open(out + ".gmp").read(), ref_text(mode, "gmp"), 8)
