@@ -5,14 +5,16 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this; the product
  * (gnumap_amd/, include/) never links, imports or executes anything under oracle/.
  *
- * Parity pin: FM-index query (occ / SA interval / locate), window fetch, FASTQ->PWM, self score,
- * banded NW score and traceback/CIGAR are checked against the UNMODIFIED reference functions
- * compiled into oracle/_ref/libgnumap_ref.so (vectors in tests/golden/ref_vectors.npz made by tests/golden/make_fixtures.py,
- * checked by tests/test_oracle_golden.py; reverse_comp / reverse_CIGAR / fix_CIGAR_for_deletions likewise) and against the
- * known answers of bin_seq::Test (src/bin_seq.cpp:1095-1127).  The driver level (adaptive k-mer
- * walk, voting, unique map, posterior, MAPQ, SAM text: align_seq2_raw.cpp, Driver.cpp:432-753,
- * ScoredSeq.h:293-404) is restated from the source text; those files cannot be compiled here
- * (inc/Genome.h:45 needs GSL) so that level is "parity unpinned" — see DESIGN.md.
+ * Parity pin (both levels pinned to the UNMODIFIED reference compiled by oracle/Makefile):
+ *  - function level: FM-index query (occ / SA interval / locate), window fetch, FASTQ->PWM, self score, banded NW score and
+ *    traceback/CIGAR, reverse_comp / reverse_CIGAR / fix_CIGAR_for_deletions against oracle/_ref/libgnumap_ref.so (vectors in
+ *    tests/golden/ref_vectors.npz made by tests/golden/make_fixtures.py, checked by tests/test_oracle_golden.py) and the
+ *    known answers of bin_seq::Test (src/bin_seq.cpp:1095-1127);
+ *  - driver level (adaptive k-mer walk, voting, accept test, unique map, denominator, winner, MAPQ, SAM text, .sgr, .gmp:
+ *    inc/align_seq2_raw.cpp:22-328, src/Driver.cpp:432-753,2146-2217, inc/ScoredSeq.h:293-404, src/*ScoredSeq.cpp,
+ *    src/GenomeBwt.cpp:483-490,1092-1273): gmo_run writes byte-identical SAM (record order included), .sgr and .gmp to the
+ *    reference PROGRAM oracle/_ref/gnumap_ref (src/Driver.cpp etc. compiled in place) in the 30 modes of
+ *    tests/golden/ref_runs/manifest.json (made by tests/golden/make_driver_fixtures.py, checked by tests/test_driver_golden.py).
  */
 #ifndef GM_ORACLE_H
 #define GM_ORACLE_H
