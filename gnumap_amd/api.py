@@ -79,7 +79,7 @@ SAM_DTYPE = np.dtype([("read", "<u4"), ("pos", "<u8"), ("contig", "<u4"), ("chr_
 EXPORTS = ["gm_last_error", "gm_version", "gm_index_build", "gm_index_build_on", "gm_index_open", "gm_index_close", "gm_index_get_info", "gm_index_contig_name",
            "gm_index_contig_offset", "gm_index_window", "gm_params_default", "gm_params_finalize", "gm_batch_create", "gm_batch_destroy",
            "gm_batch_upload", "gm_map_batch_device", "gm_batch_counters", "gm_batch_set_profiling", "gm_batch_kernel_times", "gm_kernel_name",
-           "gm_batch_raw_hits", "gm_map_batch", "gm_output_batch",
+           "gm_batch_raw_hits", "gm_host_alloc", "gm_host_free", "gm_map_batch", "gm_output_batch",
            "gm_dev_sa_interval", "gm_dev_locate", "gm_dev_nw_score", "gm_dev_traceback", "gm_coverage_reset", "gm_coverage_bins",
            "gm_coverage_device_ptr", "gm_coverage_add", "gm_coverage_download", "gm_coverage_allreduce", "gm_coverage_write_sgr", "gm_coverage_enable_nuc", "gm_coverage_nuc_device_ptr",
            "gm_coverage_download_nuc", "gm_coverage_write_gmp"]
@@ -119,6 +119,8 @@ def load_library():
     L.gm_batch_kernel_times.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.gm_kernel_name.argtypes = [C.c_int]; L.gm_kernel_name.restype = C.c_char_p
     L.gm_batch_raw_hits.argtypes = [C.c_void_p, C.c_void_p, u64, C.POINTER(u64), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gm_host_alloc.argtypes = [C.c_size_t]; L.gm_host_alloc.restype = C.c_void_p
+    L.gm_host_free.argtypes = [C.c_void_p]; L.gm_host_free.restype = None
     L.gm_map_batch.argtypes = [C.c_void_p, C.POINTER(gm_params), C.c_void_p, C.POINTER(gm_reads), C.POINTER(gm_hits), C.c_void_p]
     L.gm_output_batch.argtypes = [C.c_void_p, C.POINTER(gm_params), C.c_void_p, C.POINTER(gm_reads), C.POINTER(gm_hits), C.POINTER(gm_sam_out), C.c_void_p]
     L.gm_dev_sa_interval.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]

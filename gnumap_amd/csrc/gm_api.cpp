@@ -98,8 +98,11 @@ struct gm_batch {
     uint32_t n = 0, stride = 0, max_seeds = 0, illumina_until = 0;
     DevBuf bases, quals, len, status, self_score, min_score, top_score, seeds, n_seeds, n_entries, entry_off, coords,
         rs_overflow, retry_list, retry_off, gtab_keys, gtab_vals, cands, hit_count, hit_begin, hit_cursor, raw_hits, counters, small, shards, big_list,
-        tb_items, tb_ops, tb_len, dep_pos, dep_span, dep_w, dep_codes, dep_coff;
-    PinBuf h_ops, h_ops_len, h_raw;
+        tb_items, tb_ops, tb_len, dep_pos, dep_span, dep_w, dep_codes, dep_coff,
+        // grouping (process_hits' unique map) and output stage, gm_output.hip
+        g_sorted, g_ord, g_lead, g_krank, g_khash, g_nmatch, g_mbegin, g_multi, g_matches, g_positions, scan_tmp,
+        o_small, o_posmatch, o_post, o_mapq, o_emit, o_reccnt, o_cigcnt, o_recoff, o_cigoff, o_recs, o_pool, o_codes;
+    PinBuf h_raw, h_top, h_hbegin, h_ord, h_post, h_mapq, h_emit;
     uint32_t cand_cap = 0;
     uint64_t raw_cap = 0;
     uint32_t n_cands = 0;
@@ -434,8 +437,13 @@ extern "C" void gm_batch_destroy(gm_batch* b) {
     DevBuf* all[] = { &b->bases, &b->quals, &b->len, &b->status, &b->self_score, &b->min_score, &b->top_score, &b->seeds, &b->n_seeds,
                       &b->n_entries, &b->entry_off, &b->coords, &b->rs_overflow, &b->retry_list, &b->retry_off, &b->gtab_keys, &b->gtab_vals,
                       &b->cands, &b->hit_count, &b->hit_begin, &b->hit_cursor, &b->raw_hits, &b->counters, &b->small, &b->shards, &b->big_list, &b->tb_items, &b->tb_ops,
-                      &b->tb_len, &b->dep_pos, &b->dep_span, &b->dep_w, &b->dep_codes, &b->dep_coff };
+                      &b->tb_len, &b->dep_pos, &b->dep_span, &b->dep_w, &b->dep_codes, &b->dep_coff,
+                      &b->g_sorted, &b->g_ord, &b->g_lead, &b->g_krank, &b->g_khash, &b->g_nmatch, &b->g_mbegin, &b->g_multi, &b->g_matches, &b->g_positions,
+                      &b->scan_tmp, &b->o_small, &b->o_posmatch, &b->o_post, &b->o_mapq, &b->o_emit, &b->o_reccnt, &b->o_cigcnt, &b->o_recoff, &b->o_cigoff,
+                      &b->o_recs, &b->o_pool, &b->o_codes };
     for (DevBuf* d : all) d->release();
+    PinBuf* pins[] = { &b->h_raw, &b->h_top, &b->h_hbegin, &b->h_ord, &b->h_post, &b->h_mapq, &b->h_emit };
+    for (PinBuf* d : pins) d->release();
     for (int i = 0; i < gm_batch::NS; ++i) { if (b->sub_streams[i]) (void)hipStreamDestroy(b->sub_streams[i]); b->sub_gk[i].release(); b->sub_gv[i].release(); }
     if (b->sub_ready) (void)hipEventDestroy(b->sub_ready);
     b->sub_counters.release(); b->sub_small.release(); b->sub_shards.release();
@@ -854,15 +862,9 @@ extern "C" int gm_batch_raw_hits(gm_batch* b, gm_raw_hit* out, uint64_t cap, uin
     return GM_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// gm_map_batch: kernels + the reference's unique-map bookkeeping (process_hits :102-165, set_top_matches :506-610)
-// ------------------------------------------------------------------------------------------------
-static inline char comp_base(char c) {      // reverse_comp SequenceOperations.h:56-96 on a lowercase acgt window
-    switch (c) { case 'a': return 't'; case 't': return 'a'; case 'c': return 'g'; case 'g': return 'c'; default: return 'n'; }
-}
-
-// host-side bookkeeping of a batch is independent per read: cut the reads into contiguous chunks, one host thread each
-// (GM_HOST_THREADS, default min(16, cores)); results are concatenated in read order, so the output does not depend on it
+// host-side bookkeeping that is independent per item: cut into contiguous chunks, one host thread each (GM_HOST_THREADS; used by
+// the track writers.  The two batch calls below run their fp64 pass on the CALLING thread only: a driver gets its parallelism from
+// calling them from several threads with different batches)
 static unsigned host_threads() {
     static const unsigned n = [] {
         const char* e = getenv("GM_HOST_THREADS");
@@ -883,11 +885,6 @@ template <class F> static unsigned parallel_chunks(uint32_t n, uint32_t grain, u
     return T;
 }
 
-struct HostMatch {
-    float score; uint64_t first_pos; uint8_t first_strand;
-    std::set<std::pair<uint64_t, int>> positions;
-};
-
 struct PhaseClock {                         // GM_TIMING=1: host-side phase times of the two batch calls on stderr
     bool on; const char* what; std::chrono::steady_clock::time_point t0; std::string line;
     explicit PhaseClock(const char* w) : on(getenv("GM_TIMING") && atoi(getenv("GM_TIMING"))), what(w), t0(std::chrono::steady_clock::now()) {}
@@ -900,6 +897,31 @@ struct PhaseClock {                         // GM_TIMING=1: host-side phase time
     ~PhaseClock() { if (on) fprintf(stderr, "[gm_timing] %s:%s\n", what, line.c_str()); }
 };
 
+extern "C" void* gm_host_alloc(size_t bytes) {
+    void* q = nullptr;
+    if (hipHostMalloc(&q, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { gm_set_error("hipHostMalloc failed"); return nullptr; }
+    return q;
+}
+extern "C" void gm_host_free(void* q) { if (q) (void)hipHostFree(q); }
+
+static_assert(sizeof(gm_match) == sizeof(GmDevMatch) && offsetof(gm_match, first_pos) == offsetof(GmDevMatch, first_pos) &&
+              offsetof(gm_match, first_strand) == offsetof(GmDevMatch, first_strand) && offsetof(gm_match, pos_begin) == offsetof(GmDevMatch, pos_begin) &&
+              offsetof(gm_match, pos_end) == offsetof(GmDevMatch, pos_end), "gm_match layout");
+static_assert(sizeof(gm_pos) == sizeof(GmDevPos) && offsetof(gm_pos, strand) == offsetof(GmDevPos, strand), "gm_pos layout");
+static_assert(sizeof(gm_sam_rec) == sizeof(GmDevSamRec) && offsetof(gm_sam_rec, pos) == offsetof(GmDevSamRec, pos) &&
+              offsetof(gm_sam_rec, contig) == offsetof(GmDevSamRec, contig) && offsetof(gm_sam_rec, chr_pos) == offsetof(GmDevSamRec, chr_pos) &&
+              offsetof(gm_sam_rec, strand) == offsetof(GmDevSamRec, strand) && offsetof(gm_sam_rec, mapq) == offsetof(GmDevSamRec, mapq) &&
+              offsetof(gm_sam_rec, a_score) == offsetof(GmDevSamRec, a_score) && offsetof(gm_sam_rec, post_prob) == offsetof(GmDevSamRec, post_prob) &&
+              offsetof(gm_sam_rec, sim_matches) == offsetof(GmDevSamRec, sim_matches) && offsetof(gm_sam_rec, cigar_off) == offsetof(GmDevSamRec, cigar_off),
+              "gm_sam_rec layout");
+
+// ------------------------------------------------------------------------------------------------
+// gm_map_batch = the block loop over set_top_matches (src/Driver.cpp:2344-2356).
+// Device: prep -> seed -> locate+vote -> NW -> compaction (gm_map_batch_device), then process_hits' unique map as kernels
+// (gm_output.hip: processing order, key grouping on the 2-bit reference, std::map order, -T / -u exits) writing gm_match /
+// gm_pos records in HBM.  Host: ONE flat fp64 pass, denominator += exp(score) in the reference's order (glibc exp, the
+// order-dependent part that has to stay bit-identical to the CPU program).
+// ------------------------------------------------------------------------------------------------
 extern "C" int gm_map_batch(gm_index* ix, const gm_params* p, gm_batch* b, const gm_reads* reads, gm_hits* out, void* stream) {
     if (!ix || !p || !b || !reads || !out) return GM_E_ARG;
     PhaseClock pc("gm_map_batch");
@@ -908,136 +930,80 @@ extern "C" int gm_map_batch(gm_index* ix, const gm_params* p, gm_batch* b, const
     pc.lap("upload");
     rc = gm_map_batch_device(ix, p, b, stream);
     if (rc) return rc;
-    pc.lap("device");
-    RawDownload r;
-    rc = download_raw(b, r, S_(stream), !p->nw);
-    if (rc) return rc;
-    pc.lap("download+sort");
+    hipStream_t st = S_(stream);
     const uint32_t n = b->n;
     out->n = n;
-    struct Chunk { std::vector<gm_match> matches; std::vector<gm_pos> positions; uint32_t lo = 0, hi = 0; };
-    const unsigned want = host_threads();
-    std::vector<Chunk> chunks(want);
-    std::vector<uint32_t> mcount(n, 0);
-    const unsigned T = parallel_chunks(n, 4096, want, [&](unsigned ci, uint32_t lo, uint32_t hi) {
-      Chunk& ch = chunks[ci]; ch.lo = lo; ch.hi = hi;
-      std::vector<gm_match>& matches = ch.matches; std::vector<gm_pos>& positions = ch.positions;
-      std::string w, key;
-      for (uint32_t i = lo; i < hi; ++i) {
-        const size_t m0 = matches.size();
-        out->status[i] = r.status[i];
-        out->self_score[i] = r.self_score[i];
-        out->denominator[i] = 0;
-        out->top_score[i] = r.status[i] == GM_READ_TOO_SHORT ? -2.0 : r.status[i] == GM_READ_TOO_POOR ? -3.0 : 0.0;
-        if (r.status[i] != 0) continue;
-        const uint32_t L = b->len_host[i];
-        if (r.begin[i + 1] - r.begin[i] == 1 && !(p->nw && 1 > p->max_matches)) {
-            // one accepted hit: the unique map has one key whatever the window string is
-            const GmRawHit& h = r.hits[r.begin[i]];
-            out->denominator[i] = 0.0 + exp((double)h.score);
-            out->top_score[i] = (double)r.top[i];
-            gm_match m;
-            m.read = i; m.score = h.score; m.first_pos = h.pos; m.first_strand = h.strand;
-            m.pos_begin = (uint32_t)positions.size();
-            gm_pos q; q.pos = h.pos; q.strand = h.strand; positions.push_back(q);
-            m.pos_end = (uint32_t)positions.size();
-            matches.push_back(m);
-            mcount[i] = 1;
-            continue;
-        }
-        std::map<std::string, HostMatch> uniq;
-        double den = 0.0;
-        bool too_many = false;
-        w.resize(L); key.resize(L);
-        int cur_strand = -1; bool strand_stopped = false;
-        for (uint64_t hidx = r.begin[i]; hidx < r.begin[i + 1] && !too_many; ++hidx) {
-            const GmRawHit& h = r.hits[hidx];
-            if ((int)h.strand != cur_strand) { cur_strand = h.strand; strand_stopped = false; }
-            if (strand_stopped) continue;
-            if (!host_window(ix->h, h.pos, L, &w[0])) continue;       // cannot happen: the kernel checked it
-            if (h.strand == GM_NEG_STRAND) { for (uint32_t t = 0; t < L; ++t) key[t] = comp_base(w[L - 1 - t]); }
-            else key = w;
-            auto it = uniq.find(key);
-            if (it == uniq.end()) {
-                HostMatch m; m.score = h.score; m.first_pos = h.pos; m.first_strand = h.strand;
-                m.positions.insert({ h.pos, (int)h.strand });
-                uniq.emplace(key, std::move(m));
-                den += exp((double)h.score);
-            } else {
-                if (p->unique_only) {
-                    if (p->nw) too_many = true;                       // align_sequence returns false -> READ_TOO_MANY
-                    else strand_stopped = true;                       // --no_nw ignores the return value (:317-325)
-                    continue;
-                }
-                if (it->second.positions.insert({ h.pos, (int)h.strand }).second) den += exp((double)h.score);
-            }
-        }
-        if (p->nw && uniq.size() > p->max_matches) too_many = true;   // :299-306 (the map only grows, so the last check decides)
-        if (too_many) { out->status[i] = GM_READ_TOO_MANY; out->top_score[i] = 999999.0; continue; }
-        if (uniq.empty()) { out->status[i] = GM_READ_NONE; continue; }
-        out->denominator[i] = den;
-        out->top_score[i] = (double)r.top[i];
-        for (auto& kv : uniq) {
-            gm_match m;
-            m.read = i; m.score = kv.second.score; m.first_pos = kv.second.first_pos; m.first_strand = kv.second.first_strand;
-            m.pos_begin = (uint32_t)positions.size();
-            for (auto& ps : kv.second.positions) { gm_pos q; q.pos = ps.first; q.strand = (uint8_t)ps.second; positions.push_back(q); }
-            m.pos_end = (uint32_t)positions.size();
-            matches.push_back(m);
-        }
-        mcount[i] = (uint32_t)(matches.size() - m0);
-      }
-    });
-    pc.lap("unique-map");
-    uint64_t need_m = 0, need_p = 0;
-    for (unsigned c = 0; c < T; ++c) { need_m += chunks[c].matches.size(); need_p += chunks[c].positions.size(); }
-    bool fits = need_m <= out->matches_cap && need_p <= out->positions_cap;
-    if (!fits) { out->matches_cap = need_m; out->positions_cap = need_p; gm_set_error("output buffers too small"); return GM_E_CAPACITY; }
-    if (need_p > 0xFFFFFFFFull) { gm_set_error("more than 2^32 positions in one batch"); return GM_E_CAPACITY; }
-    uint64_t acc = 0;
-    for (uint32_t i = 0; i < n; ++i) { out->match_begin[i] = acc; acc += mcount[i]; }
-    out->match_begin[n] = acc;
-    uint64_t mo = 0, po = 0;
-    for (unsigned c = 0; c < T; ++c) {
-        Chunk& ch = chunks[c];
-        for (size_t k = 0; k < ch.matches.size(); ++k) {
-            gm_match m = ch.matches[k];
-            m.pos_begin += (uint32_t)po; m.pos_end += (uint32_t)po;
-            out->matches[mo + k] = m;
-        }
-        if (!ch.positions.empty()) memcpy(out->positions + po, ch.positions.data(), ch.positions.size() * sizeof(gm_pos));
-        mo += ch.matches.size(); po += ch.positions.size();
+    if (n == 0) { out->match_begin[0] = 0; return GM_OK; }
+    uint64_t n_hits = 0;
+    HIPCHK(hipMemcpyAsync(&n_hits, b->hit_begin.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    pc.lap("device");
+    if (n_hits > b->raw_cap) { gm_set_error("internal: raw hit buffer too small"); return GM_E_CAPACITY; }
+    if (n_hits > 0xFFFFFFF0ull) { gm_set_error("more than 2^32 accepted hits in one batch; use smaller batches"); return GM_E_CAPACITY; }
+    b->n_raw = n_hits;
+    const size_t nh = (size_t)n_hits + 16;
+    if (b->g_sorted.ensure(nh * sizeof(GmRawHit)) || b->g_ord.ensure(nh * 4) || b->g_lead.ensure(nh * 4) || b->g_krank.ensure(nh * 4) ||
+        b->g_khash.ensure(nh * 8) || b->g_positions.ensure(nh * sizeof(GmDevPos)) || b->g_matches.ensure(nh * sizeof(GmDevMatch)) ||
+        b->g_nmatch.ensure((size_t)n * 4) || b->g_mbegin.ensure(((size_t)n + 1) * 8) || b->g_multi.ensure((size_t)n * 4 + 64) ||
+        b->scan_tmp.ensure(((size_t)n / 1024 + 8) * 8) || b->o_small.ensure(64)) return GM_E_NOMEM;
+    GmDevGroup g;
+    g.sorted = b->g_sorted.as<GmRawHit>(); g.ord_score = b->g_ord.as<float>(); g.lead = b->g_lead.as<uint32_t>(); g.krank = b->g_krank.as<uint32_t>();
+    g.khash = b->g_khash.as<unsigned long long>(); g.n_match = b->g_nmatch.as<uint32_t>(); g.match_begin = b->g_mbegin.as<uint64_t>();
+    g.multi_list = b->g_multi.as<uint32_t>(); g.n_multi = b->o_small.as<uint32_t>();
+    g.matches = b->g_matches.as<GmDevMatch>(); g.positions = b->g_positions.as<GmDevPos>();
+    HIPCHK(hipMemsetAsync(b->o_small.p, 0, 64, st));
+    if (p->unique_only && !p->nw) HIPCHK(hipMemsetAsync(b->g_positions.p, 0, nh * sizeof(GmDevPos), st));      // dropped hits leave holes
+    KCHK(gmk_group_count(ix->dev, b->dev, g, p->nw, p->unique_only, p->max_matches, st));
+    KCHK(gmk_scan_u32(g.n_match, n, g.match_begin, b->scan_tmp.as<unsigned long long>(), st));
+    KCHK(gmk_group_write(b->dev, g, st));
+    // what the host pass needs: per-read status / top score, the CSR of the hits and their scores in processing order
+    if (b->h_top.ensure((size_t)n * 4) || b->h_hbegin.ensure(((size_t)n + 1) * 8) || b->h_ord.ensure(nh * 4)) return GM_E_NOMEM;
+    uint64_t n_m = 0;
+    HIPCHK(hipMemcpyAsync(&n_m, g.match_begin + n, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out->status, b->status.p, n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out->self_score, b->self_score.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(b->h_top.p, b->top_score.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(b->h_hbegin.p, b->hit_begin.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, st));
+    if (n_hits) HIPCHK(hipMemcpyAsync(b->h_ord.p, g.ord_score, (size_t)n_hits * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out->match_begin, g.match_begin, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    pc.lap("group");
+    if (n_m > out->matches_cap || n_hits > out->positions_cap) {
+        out->matches_cap = n_m; out->positions_cap = n_hits;
+        gm_set_error("output buffers too small");
+        return GM_E_CAPACITY;
     }
-    pc.lap("merge");
+    if (n_m) HIPCHK(hipMemcpyAsync(out->matches, g.matches, (size_t)n_m * sizeof(gm_match), hipMemcpyDeviceToHost, st));
+    if (n_hits) HIPCHK(hipMemcpyAsync(out->positions, g.positions, (size_t)n_hits * sizeof(gm_pos), hipMemcpyDeviceToHost, st));
+    // the fp64 pass (process_hits :134-165: denominator += exp(align_score) for every new key and every new place of an old key, in
+    // processing order) runs while the records are still in flight
+    const float* top = b->h_top.as<float>(); const uint64_t* hb = b->h_hbegin.as<uint64_t>(); const float* ord = b->h_ord.as<float>();
+    for (uint32_t i = 0; i < n; ++i) {
+        const int8_t s = out->status[i];
+        double den = 0.0, tp = 0.0;
+        if (s == GM_READ_OK) {
+            for (uint64_t h = hb[i]; h < hb[i + 1]; ++h) { const float sc = ord[h]; if (sc != -INFINITY) den += exp((double)sc); }
+            tp = (double)top[i];
+        } else if (s == GM_READ_TOO_SHORT) tp = -2.0;
+        else if (s == GM_READ_TOO_POOR) tp = -3.0;
+        else if (s == GM_READ_TOO_MANY) tp = 999999.0;
+        out->denominator[i] = den; out->top_score[i] = tp;
+    }
+    pc.lap("exp");
+    HIPCHK(hipStreamSynchronize(st));
+    pc.lap("records");
     return GM_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
-// gm_output_batch: traceback on the device, posterior / MAPQ / CIGAR on the host, coverage deposit on the device
+// gm_output_batch = the block loop over create_match_output (src/Driver.cpp:2360-2373).
+// Host: ONE flat fp64 pass over the matches (posterior = exp(score) / denominator, winner = first strict maximum in key order,
+// MAPQ = round(-10 log10(1 - p)): glibc exp / log / round).  Device: traceback of every kept sequence, run-length CIGAR text, SAM
+// rows, coverage deposit (+ the per-nucleotide track of -b / -d).  Nothing per read is done on the host beyond that pass.
 // ------------------------------------------------------------------------------------------------
-static std::string ops_to_cigar(const uint8_t* ops, uint32_t n) {     // run lengths, as bin_seq.cpp:578-698 builds them
-    std::string s;
-    uint32_t i = 0;
-    while (i < n) {
-        uint32_t j = i;
-        while (j < n && ops[j] == ops[i]) ++j;
-        s += std::to_string(j - i);
-        s += (char)ops[i];
-        i = j;
-    }
-    return s;
-}
-
-static void fix_cigar_for_deletions(std::string& c) {                  // SequenceOperations.h:32-42
-    if (c.empty() || c.back() != 'D') return;
-    int i;
-    for (i = (int)c.size() - 2; i >= 0; --i) if (!isdigit((unsigned char)c[i])) break;
-    c = c.substr(0, (size_t)(i + 1));
-}
-
 extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, const gm_reads* reads, const gm_hits* hits, gm_sam_out* out, void* stream) {
     if (!ix || !p || !b || !reads || !hits || !out) return GM_E_ARG;
-    if (hits->n != b->n) { gm_set_error("hits do not belong to the batch"); return GM_E_ARG; }
+    if (hits->n != b->n || reads->n != b->n) { gm_set_error("hits / reads do not belong to the batch"); return GM_E_ARG; }
     PhaseClock pc("gm_output_batch");
     HIPCHK(hipSetDevice(ix->device));
     hipStream_t st = S_(stream);
@@ -1045,182 +1011,101 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
     int rc = sync_params(ix, p, dp, st);
     if (rc) return rc;
     const uint32_t n = hits->n;
-    const uint64_t n_m = hits->match_begin[n];
+    const uint64_t n_m64 = n ? hits->match_begin[n] : 0;
     out->n_recs = 0; out->cigar_len = 0;
-    if (n_m == 0) return GM_OK;
-    // one traceback per ScoredSeq, oriented by its first strand (NormalScoredSeq::score, ScoredSeq::get_SAM)
-    std::vector<GmCand> items(n_m);
-    for (uint64_t m = 0; m < n_m; ++m) {
-        const gm_match& mm = hits->matches[m];
-        items[m].rs = mm.read * 2 + mm.first_strand; items[m].b = (uint32_t)mm.first_pos; items[m].step = 0; items[m].flags = 0; items[m].pad = 0; items[m].score = 0;
-    }
-    const uint32_t ops_stride = 2 * ((b->stride + 7u) & ~7u) + 8;
-    if (b->tb_items.ensure(n_m * sizeof(GmCand)) || b->tb_ops.ensure(n_m * ops_stride) || b->tb_len.ensure(n_m * 2)) return GM_E_NOMEM;
-    HIPCHK(hipMemcpyAsync(b->tb_items.p, items.data(), n_m * sizeof(GmCand), hipMemcpyHostToDevice, st));
-    fill_dev_batch(b);
-    KCHK(gmk_traceback(ix->dev, dp, b->dev, b->tb_items.as<GmCand>(), (uint32_t)n_m, b->tb_ops.as<uint8_t>(), ops_stride, b->tb_len.as<uint16_t>(), st));
-    if (b->h_ops.ensure(n_m * ops_stride) || b->h_ops_len.ensure(n_m * 2)) return GM_E_NOMEM;
-    const uint8_t* ops = b->h_ops.as<uint8_t>();
-    const uint16_t* ops_len = b->h_ops_len.as<uint16_t>();
-    HIPCHK(hipMemcpyAsync(b->h_ops.p, b->tb_ops.p, n_m * ops_stride, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(b->h_ops_len.p, b->tb_len.p, n_m * 2, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    pc.lap("traceback");
-    struct OutChunk {
-        std::vector<gm_sam_rec> recs; std::string pool;
-        std::vector<uint64_t> dpos; std::vector<uint32_t> dspan; std::vector<float> dw;
-        std::vector<uint8_t> dcodes; std::vector<uint64_t> dcoff;     // -b / -d: nucleotide of every deposited base
-        uint32_t max_span = 0;
+    if (n_m64 == 0) return GM_OK;
+    if (n_m64 > 0x7FFFFFFFull) { gm_set_error("too many matches in one batch"); return GM_E_CAPACITY; }
+    const uint32_t n_m = (uint32_t)n_m64;
+    // ---- host pass: ScoredSeq::get_SAM :300-309, is_greater :223-228, Driver.cpp:672-701 ----
+    if (b->h_post.ensure((size_t)n_m * 4) || b->h_mapq.ensure((size_t)n_m * 4) || b->h_emit.ensure(n_m)) return GM_E_NOMEM;
+    float* post = b->h_post.as<float>(); int32_t* mapq = b->h_mapq.as<int32_t>(); uint8_t* emit = b->h_emit.as<uint8_t>();
+    memset(emit, 0, n_m);
+    uint64_t n_p = 0;
+    const double log10v = log(10);
+    auto mapq_of = [&](double total) {
+        int q;
+        if (total == 1) q = 30; else q = (int)round(-10 * log(1 - total) / log10v);
+        return q > 30 ? 30 : q;
     };
-    const bool nuc = p->mode != GM_MODE_NORMAL && ix->nuc_on;
-    std::vector<float> lut;
-    if (nuc) { lut.resize(1024); build_lut(lut.data()); }
-    const unsigned want = host_threads();
-    std::vector<OutChunk> chunks(want);
-    const unsigned T = parallel_chunks(n, 4096, want, [&](unsigned ci, uint32_t lo, uint32_t hi) {
-    OutChunk& oc = chunks[ci];
-    std::vector<gm_sam_rec>& recs = oc.recs; std::string& pool = oc.pool;
-    std::vector<uint64_t>& dpos = oc.dpos; std::vector<uint32_t>& dspan = oc.dspan; std::vector<float>& dw = oc.dw;
-    std::vector<uint8_t>& dcodes = oc.dcodes; std::vector<uint64_t>& dcoff = oc.dcoff;
-    uint32_t& max_span = oc.max_span;
-    std::string al, cons;
-    // gapped read string of a match (bin_seq.cpp:578-698 on the argmax consensus, ScoredSeq.h:57-103), as g_gen_CONVERSION codes
-    auto aligned_codes = [&](const gm_match& mm, uint64_t midx, bool same_strand, std::vector<uint8_t>& out) {
-        const uint32_t r = mm.read, L = b->len_host[r];
-        const uint8_t* rb = reads->bases + (size_t)r * reads->stride; const uint8_t* rq = reads->quals + (size_t)r * reads->stride;
-        const float* lt = lut.data() + ((r < b->illumina_until) ? 512 : 0);
-        cons.resize(L);
-        for (uint32_t i = 0; i < L; ++i) {
-            uint32_t src = mm.first_strand ? L - 1 - i : i;
-            float pp = lt[2 * rq[src]], qq = lt[2 * rq[src] + 1];
-            int code; switch (rb[src]) { case 'a': case 'A': code = 0; break; case 'c': case 'C': code = 1; break; case 'g': case 'G': code = 2; break;
-                                         case 't': case 'T': code = 3; break; default: code = 4; }
-            if (mm.first_strand && code < 4) code = 3 - code;
-            float c[4] = { qq, qq, qq, qq };
-            if (code < 4) c[code] = pp;
-            char ch;                                                   // ScoredSeq::max_char
-            if (c[0] == c[1] && c[0] == c[2] && c[0] == c[3]) ch = 'n';
-            else if (c[0] >= c[1]) { if (c[0] >= c[2]) ch = c[0] >= c[3] ? 'a' : 't'; else ch = c[2] >= c[3] ? 'g' : 't'; }
-            else { if (c[1] >= c[2]) ch = c[1] >= c[3] ? 'c' : 't'; else ch = c[2] >= c[3] ? 'g' : 't'; }
-            cons[i] = ch;
-        }
-        const uint8_t* op = &ops[midx * ops_stride];
-        const uint32_t n_op = ops_len[midx];
-        al.resize(n_op);
-        uint32_t rr = 0;
-        for (uint32_t k = 0; k < n_op; ++k) {
-            if (op[k] == 'M') { al[k] = rr < L ? cons[rr] : '\0'; ++rr; }
-            else if (op[k] == 'I') { al[k] = rr + 1 < L ? cons[rr + 1] : '\0'; ++rr; }     // consense[i], sic (bin_seq.cpp:607)
-            else al[k] = '-';
-        }
-        for (uint32_t k = 0; k < n_op; ++k) {
-            char ch;
-            if (same_strand) ch = al[k];
-            else {
-                switch (al[n_op - 1 - k]) { case 'a': ch = 't'; break; case 't': ch = 'a'; break; case 'c': ch = 'g'; break; case 'g': ch = 'c'; break;
-                                            case '-': ch = '-'; break; default: ch = 'n'; }
-            }
-            uint8_t cv;
-            switch (ch) { case 'a': cv = 0; break; case 'c': cv = 1; break; case 'g': cv = 2; break; case 't': cv = 3; break; case 'n': cv = 4; break;
-                          case '\0': cv = 6; break; default: cv = 4; }
-            out.push_back(cv);
-        }
-    };
-    auto emit = [&](uint32_t read, const gm_match& mm, uint64_t midx, double den) {
-        double total = exp((double)mm.score) / den;                    // ScoredSeq.h:300
-        int mapq;
-        if (total == 1) mapq = 30; else mapq = (int)round(-10 * log(1 - total) / log(10));
-        if (mapq > 30) mapq = 30;
-        std::string cigar;
-        if (p->nw) {
-            cigar = ops_to_cigar(&ops[midx * ops_stride], ops_len[midx]);
-            if (cigar.empty()) cigar = "*"; else fix_cigar_for_deletions(cigar);
-        } else {
-            cigar = std::to_string(b->len_host[read]) + "M";
-        }
-        uint32_t off = (uint32_t)pool.size();
-        pool += cigar; pool.push_back('\0');
-        for (uint32_t q = mm.pos_begin; q < mm.pos_end; ++q) {
-            gm_sam_rec s;
-            memset(&s, 0, sizeof s);
-            s.read = read; s.pos = hits->positions[q].pos; s.strand = hits->positions[q].strand;
-            s.contig = host_pos2rid(ix->h, s.pos);
-            int base = (int)(s.pos - ix->h.contigs[s.contig].offset);     // int chr_base_pos, GenomeBwt.cpp:632
-            s.chr_pos = (uint64_t)(unsigned long)base + 1;
-            s.mapq = mapq; s.a_score = mm.score; s.post_prob = (float)total; s.sim_matches = (int32_t)(mm.pos_end - mm.pos_begin);
-            s.cigar_off = off;
-            recs.push_back(s);
-        }
-    };
-    for (uint32_t i = lo; i < hi; ++i) {
-        if (hits->status[i] != GM_READ_OK) continue;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t m0 = hits->match_begin[i], m1 = hits->match_begin[i + 1];
+        if (m0 == m1) continue;
+        if (hits->status[i] != GM_READ_OK) { for (uint64_t m = m0; m < m1; ++m) { post[m] = 0; mapq[m] = 0; } continue; }
         const double den = hits->denominator[i];
         int64_t best = -1;
         double best_log = exp(-1.0);                                   // the empty NormalScoredSeq, ScoredSeq.h:117-120
-        for (uint64_t m = hits->match_begin[i]; m < hits->match_begin[i + 1]; ++m) {
+        for (uint64_t m = m0; m < m1; ++m) {
             const gm_match& mm = hits->matches[m];
-            double lg = exp((double)mm.score);
-            float wgt = (float)(lg / den);                             // AddScore(const float& amt), NormalScoredSeq.cpp:70
-            for (uint32_t q = mm.pos_begin; q < mm.pos_end; ++q) {
-                dpos.push_back(hits->positions[q].pos); dspan.push_back(ops_len[m]); dw.push_back(wgt);
-                max_span = std::max<uint32_t>(max_span, ops_len[m]);
-                if (nuc) { dcoff.push_back(dcodes.size()); aligned_codes(mm, m, hits->positions[q].strand == mm.first_strand, dcodes); }
-            }
-            if (p->print_all_sam) emit(i, mm, m, den);
+            if (mm.read != i || mm.pos_end < mm.pos_begin) { gm_set_error("gm_hits: match does not belong to its read"); return GM_E_ARG; }
+            n_p = std::max<uint64_t>(n_p, mm.pos_end);
+            const double lg = exp((double)mm.score);
+            const double total = lg / den;                             // ScoredSeq.h:300
+            post[m] = (float)total;                                    // AddScore(const float& amt), NormalScoredSeq.cpp:70
+            mapq[m] = 0;
+            if (p->print_all_sam) { emit[m] = 1; mapq[m] = mapq_of(total); }
             if (lg > best_log) { best = (int64_t)m; best_log = lg; }  // is_greater: strict, first in key order wins
         }
-        if (!p->print_all_sam && best >= 0 && (double)hits->matches[best].score > hits->top_score[i] - 0.00001)   // Driver.cpp:695
-            emit(i, hits->matches[best], (uint64_t)best, den);
-    }
-    });
-    // concatenate in read order
-    std::vector<gm_sam_rec> recs; std::string pool;
-    std::vector<uint64_t> dpos; std::vector<uint32_t> dspan; std::vector<float> dw; std::vector<uint8_t> dcodes; std::vector<uint64_t> dcoff;
-    uint32_t max_span = 0;
-    if (T == 1) {
-        OutChunk& oc = chunks[0];
-        recs.swap(oc.recs); pool.swap(oc.pool); dpos.swap(oc.dpos); dspan.swap(oc.dspan); dw.swap(oc.dw); dcodes.swap(oc.dcodes); dcoff.swap(oc.dcoff);
-        max_span = oc.max_span;
-    } else {
-        size_t nr = 0, np_ = 0, nd = 0, nc = 0;
-        for (unsigned c = 0; c < T; ++c) { nr += chunks[c].recs.size(); np_ += chunks[c].pool.size(); nd += chunks[c].dpos.size(); nc += chunks[c].dcodes.size(); }
-        recs.reserve(nr); pool.reserve(np_); dpos.reserve(nd); dspan.reserve(nd); dw.reserve(nd); dcodes.reserve(nc); dcoff.reserve(nuc ? nd : 0);
-        for (unsigned c = 0; c < T; ++c) {
-            OutChunk& oc = chunks[c];
-            const uint32_t poff = (uint32_t)pool.size(); const uint64_t coff = dcodes.size();
-            for (gm_sam_rec s : oc.recs) { s.cigar_off += poff; recs.push_back(s); }
-            pool += oc.pool;
-            dpos.insert(dpos.end(), oc.dpos.begin(), oc.dpos.end()); dspan.insert(dspan.end(), oc.dspan.begin(), oc.dspan.end());
-            dw.insert(dw.end(), oc.dw.begin(), oc.dw.end());
-            for (uint64_t v : oc.dcoff) dcoff.push_back(v + coff);
-            dcodes.insert(dcodes.end(), oc.dcodes.begin(), oc.dcodes.end());
-            max_span = std::max(max_span, oc.max_span);
+        if (!p->print_all_sam && best >= 0 && (double)hits->matches[best].score > hits->top_score[i] - 0.00001) {   // Driver.cpp:695
+            emit[best] = 1;
+            mapq[best] = mapq_of(exp((double)hits->matches[best].score) / den);
         }
     }
-    pc.lap("posterior+cigar");
+    if (n_p > hits->positions_cap) { gm_set_error("gm_hits: positions out of range"); return GM_E_ARG; }
+    pc.lap("fp64");
+    // ---- device ----
+    const uint32_t ops_stride = 2 * ((b->stride + 7u) & ~7u) + 8;
+    const bool nuc = p->mode != GM_MODE_NORMAL && ix->nuc_on;
+    if (b->g_matches.ensure((size_t)n_m * sizeof(GmDevMatch)) || b->g_positions.ensure((size_t)(n_p + 1) * sizeof(GmDevPos)) ||
+        b->o_posmatch.ensure((size_t)(n_p + 1) * 4) || b->o_post.ensure((size_t)n_m * 4) || b->o_mapq.ensure((size_t)n_m * 4) || b->o_emit.ensure(n_m) ||
+        b->tb_items.ensure((size_t)n_m * sizeof(GmCand)) || b->tb_ops.ensure((size_t)n_m * ops_stride) || b->tb_len.ensure((size_t)n_m * 2) ||
+        b->o_reccnt.ensure((size_t)n_m * 4) || b->o_cigcnt.ensure((size_t)n_m * 4) || b->o_recoff.ensure(((size_t)n_m + 1) * 8) ||
+        b->o_cigoff.ensure(((size_t)n_m + 1) * 8) || b->scan_tmp.ensure(((size_t)std::max<uint32_t>(n_m, n) / 1024 + 8) * 8) || b->o_small.ensure(64) ||
+        (nuc && b->o_codes.ensure((size_t)n_m * ops_stride))) return GM_E_NOMEM;
+    const GmDevMatch* d_m = b->g_matches.as<GmDevMatch>(); const GmDevPos* d_p = b->g_positions.as<GmDevPos>();
+    HIPCHK(hipMemcpyAsync(b->g_matches.p, hits->matches, (size_t)n_m * sizeof(gm_match), hipMemcpyHostToDevice, st));
+    if (n_p) HIPCHK(hipMemcpyAsync(b->g_positions.p, hits->positions, (size_t)n_p * sizeof(gm_pos), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b->o_post.p, post, (size_t)n_m * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b->o_mapq.p, mapq, (size_t)n_m * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b->o_emit.p, emit, n_m, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(b->o_posmatch.p, 0xFF, (size_t)(n_p + 1) * 4, st));
+    HIPCHK(hipMemsetAsync(b->o_small.p, 0, 64, st));
+    fill_dev_batch(b);
+    KCHK(gmk_out_items(d_m, n_m, 0, b->tb_items.as<GmCand>(), b->o_posmatch.as<uint32_t>(), st));
+    // one traceback per ScoredSeq, oriented by its first strand (NormalScoredSeq::score, ScoredSeq::get_SAM)
+    KCHK(gmk_traceback(ix->dev, dp, b->dev, b->tb_items.as<GmCand>(), n_m, b->tb_ops.as<uint8_t>(), ops_stride, b->tb_len.as<uint16_t>(), st));
+    KCHK(gmk_out_count(b->dev, d_m, n_m, b->o_emit.as<uint8_t>(), b->tb_ops.as<uint8_t>(), ops_stride, b->tb_len.as<uint16_t>(), p->nw,
+                       b->o_reccnt.as<uint32_t>(), b->o_cigcnt.as<uint32_t>(), b->o_small.as<uint32_t>(), st));
+    KCHK(gmk_scan_u32(b->o_reccnt.as<uint32_t>(), n_m, b->o_recoff.as<uint64_t>(), b->scan_tmp.as<unsigned long long>(), st));
+    KCHK(gmk_scan_u32(b->o_cigcnt.as<uint32_t>(), n_m, b->o_cigoff.as<uint64_t>(), b->scan_tmp.as<unsigned long long>(), st));
+    uint64_t n_recs = 0, cig_len = 0; uint32_t max_span = 0;
+    HIPCHK(hipMemcpyAsync(&n_recs, b->o_recoff.as<uint64_t>() + n_m, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&cig_len, b->o_cigoff.as<uint64_t>() + n_m, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&max_span, b->o_small.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    pc.lap("traceback+count");
     // capacity first: a call that is going to be repeated with larger buffers must not deposit coverage twice
-    bool fits = recs.size() <= out->recs_cap && pool.size() <= out->cigar_cap;
-    out->n_recs = recs.size(); out->cigar_len = pool.size();
-    if (!fits) { out->recs_cap = recs.size(); out->cigar_cap = pool.size(); gm_set_error("output buffers too small"); return GM_E_CAPACITY; }
-    if (ix->cov_bins && !dpos.empty()) {
-        size_t nd = dpos.size();
-        if (b->dep_pos.ensure(nd * 8) || b->dep_span.ensure(nd * 4) || b->dep_w.ensure(nd * 4)) return GM_E_NOMEM;
-        HIPCHK(hipMemcpyAsync(b->dep_pos.p, dpos.data(), nd * 8, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(b->dep_span.p, dspan.data(), nd * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(b->dep_w.p, dw.data(), nd * 4, hipMemcpyHostToDevice, st));
-        if (nuc) {
-            if (b->dep_codes.ensure(dcodes.size() + 16) || b->dep_coff.ensure(nd * 8)) return GM_E_NOMEM;
-            HIPCHK(hipMemcpyAsync(b->dep_codes.p, dcodes.data(), dcodes.size(), hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(b->dep_coff.p, dcoff.data(), nd * 8, hipMemcpyHostToDevice, st));
-        }
-        KCHK(gmk_coverage_add(ix->d_cov.as<float>(), ix->cov_bins, ix->cov_bin_size, b->dep_pos.as<uint64_t>(), b->dep_span.as<uint32_t>(),
-                              b->dep_w.as<float>(), (uint32_t)nd, max_span, nuc ? ix->d_nuc.as<float>() : nullptr,
-                              nuc ? b->dep_codes.as<uint8_t>() : nullptr, nuc ? b->dep_coff.as<uint64_t>() : nullptr, st));
-        HIPCHK(hipStreamSynchronize(st));
-        pc.lap("coverage");
+    out->n_recs = n_recs; out->cigar_len = cig_len;
+    if (n_recs > out->recs_cap || cig_len > out->cigar_cap) {
+        out->recs_cap = n_recs; out->cigar_cap = cig_len;
+        gm_set_error("output buffers too small");
+        return GM_E_CAPACITY;
     }
-    if (!recs.empty()) memcpy(out->recs, recs.data(), recs.size() * sizeof(gm_sam_rec));
-    if (!pool.empty()) memcpy(out->cigar_pool, pool.data(), pool.size());
+    if (cig_len > 0xFFFFFFFFull) { gm_set_error("CIGAR pool beyond 4 GB in one batch; use smaller batches"); return GM_E_CAPACITY; }
+    if (b->o_recs.ensure((size_t)(n_recs + 1) * sizeof(GmDevSamRec)) || b->o_pool.ensure((size_t)cig_len + 16)) return GM_E_NOMEM;
+    if (n_recs) {
+        KCHK(gmk_out_write(ix->dev, b->dev, d_m, d_p, n_m, b->o_emit.as<uint8_t>(), b->o_mapq.as<int32_t>(), b->o_post.as<float>(), b->tb_ops.as<uint8_t>(),
+                           ops_stride, b->tb_len.as<uint16_t>(), p->nw, b->o_recoff.as<uint64_t>(), b->o_cigoff.as<uint64_t>(),
+                           b->o_recs.as<GmDevSamRec>(), b->o_pool.as<char>(), st));
+        HIPCHK(hipMemcpyAsync(out->recs, b->o_recs.p, (size_t)n_recs * sizeof(gm_sam_rec), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(out->cigar_pool, b->o_pool.p, (size_t)cig_len, hipMemcpyDeviceToHost, st));
+    }
+    if (ix->cov_bins && n_p && max_span) {
+        if (nuc) KCHK(gmk_out_codes(b->dev, dp, d_m, n_m, b->tb_ops.as<uint8_t>(), ops_stride, b->tb_len.as<uint16_t>(), b->o_codes.as<uint8_t>(), st));
+        KCHK(gmk_out_deposit(ix->d_cov.as<float>(), ix->cov_bins, ix->cov_bin_size, d_m, d_p, b->o_posmatch.as<uint32_t>(), n_p, b->tb_len.as<uint16_t>(),
+                             b->o_post.as<float>(), max_span, nuc ? ix->d_nuc.as<float>() : nullptr, nuc ? b->o_codes.as<uint8_t>() : nullptr, ops_stride, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    pc.lap("records+coverage");
     return GM_OK;
 }
 

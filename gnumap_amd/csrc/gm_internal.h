@@ -99,7 +99,29 @@ struct GmDevBatch {
     uint32_t* big_list;             // 2n
 };
 
-// Launchers (gm_kernels.hip).  All asynchronous on `stream`; they return a hipError_t cast to int.
+// device mirrors of the public records (include/gnumap_hip.h: gm_match, gm_pos, gm_sam_rec; layouts asserted in gm_api.cpp), so that
+// the kernels of gm_output.hip write them in HBM in their final form
+struct GmDevMatch { uint32_t read; float score; unsigned long long first_pos; uint8_t first_strand; uint8_t pad[3]; uint32_t pos_begin, pos_end; uint32_t tail; };
+struct GmDevPos { unsigned long long pos; uint8_t strand; uint8_t pad[7]; };
+struct GmDevSamRec { uint32_t read, pad0; unsigned long long pos; uint32_t contig, pad1; unsigned long long chr_pos; uint8_t strand; uint8_t pad2[3];
+                     int32_t mapq; float a_score, post_prob; int32_t sim_matches; uint32_t cigar_off; };
+
+// workspace of the grouping kernels (process_hits' unique map on the device); per-hit arrays share the CSR of hit_begin
+struct GmDevGroup {
+    GmRawHit* sorted;               // accepted hits of a read in the reference's processing order
+    float* ord_score;               // their scores in that order (-inf: dropped by -u with --no_nw): the host sums exp() over these
+    uint32_t* lead;                 // index (within the read) of the first hit with the same key; 0xFFFFFFFF = dropped
+    uint32_t* krank;                // leaders: rank of the key among the read's keys (std::map<string> order)
+    unsigned long long* khash;
+    uint32_t* n_match;              // n: matches of a read (0 unless its status stays OK)
+    uint64_t* match_begin;          // n+1: exclusive scan of n_match
+    uint32_t* multi_list;           // reads with >= 2 accepted hits
+    uint32_t* n_multi;
+    GmDevMatch* matches;
+    GmDevPos* positions;            // same CSR as the hits (a read's positions live in [hit_begin[r], hit_begin[r+1]))
+};
+
+// Launchers (gm_kernels.hip, gm_output.hip).  All asynchronous on `stream`; they return a hipError_t cast to int.
 #ifdef __cplusplus
 extern "C++" {
 int gmk_expand_full_sa(const GmDevIndex& ix, uint32_t* full_sa, void* stream);
@@ -121,6 +143,20 @@ int gmk_sa_interval(const GmDevIndex& ix, const uint8_t* kmers, uint32_t n, uint
 int gmk_locate(const GmDevIndex& ix, const uint32_t* ranks, uint32_t n, int use_full_sa, uint32_t* out, void* stream);
 int gmk_traceback(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, const GmCand* items, uint32_t n,
                   uint8_t* ops, uint32_t ops_stride, uint16_t* ops_len, void* stream);
+int gmk_scan_u32(const uint32_t* in, uint64_t n, uint64_t* out, unsigned long long* tmp, void* stream);
+int gmk_group_count(const GmDevIndex& ix, const GmDevBatch& b, const GmDevGroup& g, int nw, int unique_only, uint32_t max_matches, void* stream);
+int gmk_group_write(const GmDevBatch& b, const GmDevGroup& g, void* stream);
+int gmk_out_items(const GmDevMatch* matches, uint32_t n_m, uint32_t read_base, GmCand* items, uint32_t* pos_match, void* stream);
+int gmk_out_count(const GmDevBatch& b, const GmDevMatch* matches, uint32_t n_m, const uint8_t* emit, const uint8_t* ops, uint32_t ops_stride,
+                  const uint16_t* ops_len, int nw, uint32_t* rec_cnt, uint32_t* cig_cnt, uint32_t* max_span, void* stream);
+int gmk_out_write(const GmDevIndex& ix, const GmDevBatch& b, const GmDevMatch* matches, const GmDevPos* positions, uint32_t n_m, const uint8_t* emit,
+                  const int32_t* mapq, const float* post, const uint8_t* ops, uint32_t ops_stride, const uint16_t* ops_len, int nw,
+                  const uint64_t* rec_off, const uint64_t* cig_off, GmDevSamRec* recs, char* pool, void* stream);
+int gmk_out_codes(const GmDevBatch& b, const GmDevParams& p, const GmDevMatch* matches, uint32_t n_m, const uint8_t* ops, uint32_t ops_stride,
+                  const uint16_t* ops_len, uint8_t* codes, void* stream);
+int gmk_out_deposit(float* cov, uint64_t bins, uint32_t bin_size, const GmDevMatch* matches, const GmDevPos* positions, const uint32_t* pos_match,
+                    uint64_t n_p, const uint16_t* ops_len, const float* post, uint32_t max_span, float* nuc, const uint8_t* codes, uint32_t ops_stride,
+                    void* stream);
 int gmk_coverage_add(float* cov, uint64_t bins, uint32_t bin_size, const uint64_t* pos, const uint32_t* span, const float* w,
                      uint32_t n, uint32_t max_span, float* nuc, const uint8_t* codes, const uint64_t* code_off, void* stream);
 }

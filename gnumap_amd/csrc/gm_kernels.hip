@@ -2917,6 +2917,11 @@ static int scan_u32(const uint32_t* in, uint64_t n, uint64_t* out, unsigned long
     return (int)hipGetLastError();
 }
 
+int gmk_scan_u32(const uint32_t* in, uint64_t n, uint64_t* out, unsigned long long* tmp, void* stream) {
+    if (n == 0) return (int)hipMemsetAsync(out, 0, 8, S_(stream));
+    return scan_u32(in, n, out, tmp, stream);
+}
+
 int gmk_scan_entries(const GmDevBatch& b, void* stream) {
     if (b.n == 0) return 0;
     // scan scratch: the tail of hit_begin's sibling buffer is not available yet, so the host gives us retry_off as scratch

@@ -194,7 +194,17 @@ typedef struct { uint32_t read; uint32_t pos; float score; uint16_t step; uint8_
 int gm_batch_raw_hits(gm_batch*, gm_raw_hit* out, uint64_t cap, uint64_t* n_out,
                       int8_t* status, float* self_score, float* top_score);
 
-/* ---- the drop-in pair for the two block loops of parallel_thread_run ---- */
+/* ---- the drop-in pair for the two block loops of parallel_thread_run ----
+ * gm_map_batch   = upload + gm_map_batch_device + the unique-sequence map of process_hits as device kernels (processing order, key
+ *                  grouping on the 2-bit reference, std::map order, -T / -u exits); the host does one flat fp64 pass
+ *                  (denominator += exp(score) in the reference's order) on the calling thread.
+ * gm_output_batch= one flat fp64 pass on the calling thread (posterior, winner, MAPQ), then traceback, run-length CIGAR text,
+ *                  SAM rows and the coverage deposit as device kernels.  `reads` must be the block the batch was mapped with (it
+ *                  is still resident in HBM); `hits` may have been edited by the caller (it is uploaded again).
+ * Both are synchronous on hip_stream and use only the calling thread: a driver overlaps blocks by calling them from two or more
+ * threads with one gm_batch and one stream each.  Host buffers from gm_host_alloc are page-locked (DMA at link rate). */
+void* gm_host_alloc(size_t bytes);                               /* page-locked host memory for gm_reads / gm_hits / gm_sam_out buffers */
+void gm_host_free(void*);
 int gm_map_batch(gm_index*, const gm_params*, gm_batch*, const gm_reads*, gm_hits* out, void* hip_stream);
 int gm_output_batch(gm_index*, const gm_params*, gm_batch*, const gm_reads*, const gm_hits*, gm_sam_out* out, void* hip_stream);
 
