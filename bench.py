@@ -1,25 +1,40 @@
 #!/usr/bin/env python3
-"""bench.py — reads/s of the MI355X seed-and-extend hot path (gm_map_batch_device through the C ABI of
-libgnumap_hip.so) on the workload BASELINE.json quotes its metric on:
+"""bench.py — reads/s of the MI355X seed-and-extend hot path through the C ABI of libgnumap_hip.so, on the workload
+BASELINE.json quotes its metric on ("reads/sec (100 bp, -a 0.9) vs human ref"):
 
-    configs[1]: C. elegans-scale synthetic reference (100 Mbp, 6 contigs, seed 42) + 10 M synthetic 100-bp reads per GPU
-    (1 % substitutions, 0.05 % insertions, 0.05 % deletions, Phred 20-40, 50 % reverse strand), gnumap defaults at -a 0.9
-    (-m 10 -j 5 -k 2, no -h cap), NormalScoredSeq NW scoring.
+    default = human-scale synthetic reference (3.1 Gbp, 24 contigs, seed 42, 19 GB of index resident in HBM) + 10 M synthetic
+    100-bp reads per GPU (1 % substitutions, 0.05 % insertions, 0.05 % deletions, Phred 20-40, 50 % reverse strand),
+    -a 0.9 -m 14 -j 7 -k 2, no -h cap, NormalScoredSeq NW.
+    Why -m 14 -j 7: the reference's default -m 10 means ~3000 SA hits per seed at 3.1 Gbp (10^5 per read; its own human script
+    maps ONE read that way); 14 is the shortest seed whose expected chance hits per seed (11.5) stay below the true locus'
+    votes, it needs no -h cap (so nothing is skipped) and keeps more sensitivity than the -m 20 -j 10 -h 150 SURVEY.md suggests.
+    Other BASELINE configurations by flag:  configs[1]: --genome-mbp 100 --contigs 6 --mer 10 --jump 5
+                                            configs[2] shape: --genome-mbp 156 --contigs 1 --mer 10 --jump 5 --max-kmer-hits 150
+                                            configs[4] shape: --no-nw
 
-A "step" is one pass of the hot path (prep -> seed -> locate+vote -> NW -> hit compaction) over the whole read set,
-which is resident in HBM before the timed region starts.  N > 1: one process per GPU (torch.distributed / RCCL), reads
-sharded with no data-path collective (weak scaling: per-GPU work fixed); the per-position coverage track is the only
-thing that is all-reduced (once, outside the per-step loop, like the reference's MPI Allreduce at end of run).
+`value`: a "step" is one pass of the device hot path (gm_map_batch_device: prep -> seed -> locate+vote -> NW -> hit compaction)
+over the whole read set, resident in HBM before the timed region starts.  `abi_reads_per_s` (same JSON line) is the rate of the
+path the ABI actually exports to a host driver: gm_map_batch + gm_output_batch on HOST buffers (upload, device path, unique-map
+grouping, fp64 posterior pass on the host, traceback, CIGAR, SAM rows, coverage deposit, download), blocks of 262 144 reads
+driven by `--abi-threads` (2) host threads with one gm_batch + one HIP stream each.
 
-One JSON line on stdout (rank 0).  `roofline` is computed for the kernel with the largest device time, from
-algorithmic bytes (kernel-side work counters x the per-unit byte costs of DESIGN.md) and HIP-event timings taken
-inside the library on the launch stream.  `cpu_baseline` times the CPU restatement (oracle/, "port") on a bounded
-sample of the same reads with the reference's own data structures (sampled SA, LF-walk locate).
+N > 1: one process per GPU (torch.distributed / RCCL), reads sharded with no data-path collective (weak scaling: per-GPU work
+fixed); the per-position coverage track is the only thing that is all-reduced (once, in place, outside the per-step loop, like
+the reference's MPI Allreduce at end of run); a known per-rank deposit pattern is checked after the reduction.
+
+One JSON line on stdout (rank 0).  `roofline` is computed for the kernel with the largest device time, from algorithmic bytes
+(kernel-side work counters x the per-unit byte costs of DESIGN.md) and HIP-event timings taken inside the library on the
+launch stream.  `cpu_baseline` times the reference program itself (oracle/_ref/gnumap_ref, the unmodified src/Driver.cpp -c
+pthread path; kind "reference") on a bounded sample of the same reads on this box's host cores, or the CPU restatement (kind
+"port") when the reference binary did not travel.
 """
 import argparse
 import json
 import os
+import re
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -36,27 +51,27 @@ def log(*a):
 
 
 def make_genome(path, mbp, seed, n_contigs):
-    """i.i.d. uniform ACGT, split into contigs, FASTA with 100-column lines (deterministic)"""
+    """i.i.d. uniform ACGT, split into contigs, FASTA with 100-column lines (deterministic), written in slabs"""
     rng = np.random.default_rng(seed)
     G = int(mbp * 1_000_000)
-    codes = rng.integers(0, 4, G, dtype=np.uint8)
     sizes = [G // n_contigs] * n_contigs
     sizes[-1] += G - sum(sizes)
     acgt = np.frombuffer(b"ACGT", np.uint8)
     with open(path, "wb") as f:
-        off = 0
         for c, n in enumerate(sizes):
             f.write(b">chr%d synthetic seed %d\n" % (c + 1, seed))
-            seq = acgt[codes[off:off + n]]
-            rows = n // 100
-            block = np.empty((rows, 101), np.uint8)
-            block[:, :100] = seq[:rows * 100].reshape(rows, 100)
-            block[:, 100] = 10
-            f.write(block.tobytes())
-            if n % 100:
-                f.write(seq[rows * 100:].tobytes() + b"\n")
-            off += n
-    return codes
+            done = 0
+            while done < n:
+                m = min(n - done, 200_000_000)
+                seq = acgt[rng.integers(0, 4, m, dtype=np.uint8)]
+                rows = m // 100
+                block = np.empty((rows, 101), np.uint8)
+                block[:, :100] = seq[:rows * 100].reshape(rows, 100)
+                block[:, 100] = 10
+                f.write(block.tobytes())
+                if m % 100:
+                    f.write(seq[rows * 100:].tobytes() + b"\n")
+                done += m
 
 
 def make_reads(codes_t, n, L, seed, device):
@@ -109,22 +124,62 @@ def algorithmic_bytes(c, L, n_reads):
     }
 
 
-def cpu_baseline(fa, B, Q, Ln, L, kw, target_s, threads):
+def write_fastq(path, B, Q, L, n):
+    with open(path, "wb") as f:
+        for s in range(0, n, 65536):
+            e = min(n, s + 65536)
+            f.write(b"".join(b"@r%d\n" % i + B[i, :L].tobytes() + b"\n+\n" + Q[i, :L].tobytes() + b"\n" for i in range(s, e)))
+
+
+def cpu_baseline_reference(fa, B, Q, L, a, target_s, threads, wd):
+    """the reference program itself (unmodified src/Driver.cpp etc., built by oracle/Makefile refbin) with -c <threads> on a bounded
+    sample; mapping time = its own "Time since start" minus the same figure of a 1-read run (index load)"""
+    exe = os.path.join(ROOT, "oracle", "_ref", "gnumap_ref")
+    if not os.path.exists(exe):
+        return None
+    flags = ["-a", "0.9", "-m", str(a.mer), "-k", "2", "-c", str(threads), "-v", "1"]
+    flags += ["-j", str(a.jump if a.jump else a.mer // 2)]
+    if a.max_kmer_hits:
+        flags += ["-h", str(a.max_kmer_hits)]
+    if a.no_nw:
+        flags += ["--no_nw"]
+    fq = os.path.join(wd, "cpu_sample.fq")
+
+    def run(n):
+        write_fastq(fq, B, Q, L, n)
+        r = subprocess.run([exe, "-g", fa, "-o", os.path.join(wd, "cpu_ref_out")] + flags + [fq], capture_output=True, text=True, timeout=1500)
+        m = re.search(r"Time since start: ([0-9.eE+-]+)", r.stderr + r.stdout)
+        if r.returncode != 0 or not m:
+            raise RuntimeError(f"reference program failed (rc {r.returncode}): {(r.stderr or r.stdout)[-400:]}")
+        return float(m.group(1))
+
+    try:
+        t_load = run(1)
+        n = min(len(B), 256 * threads)
+        t_map = 0.0
+        for _ in range(4):
+            t_map = max(run(n) - t_load, 1e-3)
+            if t_map >= 0.5 * target_s or n >= len(B):
+                break
+            n = int(min(len(B), max(2 * n, n / t_map * target_s)))
+    except Exception as e:                                    # the reference could not run here: say so, fall back to the port
+        log(f"[bench] reference program not usable as CPU baseline: {e}")
+        return None
+    return dict(value=n / t_map, unit="reads/s", cores=threads, kind="reference",
+                sample=f"first {n} of the benchmark reads through oracle/_ref/gnumap_ref (the unmodified reference program, -c {threads} pthreads, "
+                       f"flags {' '.join(flags)}), mapping time {t_map:.1f} s = its 'Time since start' minus that of a 1-read run ({t_load:.1f} s of index load)")
+
+
+def cpu_baseline_port(fa, B, Q, L, kw, target_s, threads):
     """the oracle ("port": same algorithm and index layout as the reference, sampled SA + LF-walk locate) on a bounded sample"""
     from reflib import OracleLib
     orc = OracleLib()
     oix = orc.index_load(fa)
     op = orc.params(**kw)
-
-    def write_fq(path, n):
-        with open(path, "wb") as f:
-            for i in range(n):
-                f.write(b"@r%d\n" % i + B[i, :L].tobytes() + b"\n+\n" + Q[i, :L].tobytes() + b"\n")
-
     tmp = os.path.join(os.path.dirname(fa), "cpu_sample.fq")
     n = min(32 * threads, len(B))
     while True:                                  # grow the sample until the run is long enough to be a fair rate
-        write_fq(tmp, n)
+        write_fastq(tmp, B, Q, L, n)
         st = orc.run(oix, op, tmp, "", threads=threads)
         if st.map_seconds >= 0.5 * target_s or n >= len(B):
             break
@@ -135,27 +190,69 @@ def cpu_baseline(fa, B, Q, Ln, L, kw, target_s, threads):
                        f"index preloaded, sampled-SA LF-walk locate as in the reference), {st.map_seconds:.1f} s")
 
 
+def abi_rate(g, ix, p, B, Q, Ln, n_reads, block, n_threads, torch):
+    """gm_map_batch + gm_output_batch on page-locked HOST buffers, `n_threads` host threads with one gm_batch + one stream each"""
+    n_reads = min(n_reads, len(B)) // block * block
+    if n_reads == 0:
+        return None
+    Bp = g.api.pinned_empty((n_reads, B.shape[1]), np.uint8); Qp = g.api.pinned_empty((n_reads, B.shape[1]), np.uint8)
+    Bp[:] = B[:n_reads]; Qp[:] = Q[:n_reads]
+    Lp = g.api.pinned_empty(n_reads, np.uint16); Lp[:] = Ln[:n_reads]
+    streams = [torch.cuda.Stream() for _ in range(n_threads)]
+    runners = [g.api.BlockRunner(ix, p, block, B.shape[1], stream=s.cuda_stream) for s in streams]
+    blocks = list(range(0, n_reads, block))
+    for r in runners:                                           # warm-up: buffers sized, workspaces allocated
+        r.run(Bp[:block], Qp[:block], Lp[:block])
+    torch.cuda.synchronize()
+    totals = [[0, 0] for _ in runners]
+    err = []
+
+    def work(k):
+        try:
+            for s in blocks[k::n_threads]:
+                m, nr = runners[k].run(Bp[s:s + block], Qp[s:s + block], Lp[s:s + block])
+                totals[k][0] += m; totals[k][1] += nr
+        except Exception as e:                                  # pragma: no cover
+            err.append(e)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(n_threads)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if err:
+        raise err[0]
+    return dict(reads_per_s=n_reads / dt, reads=n_reads, block=block, host_threads=n_threads, seconds=dt,
+                matches=sum(t[0] for t in totals), sam_records=sum(t[1] for t in totals))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genome-mbp", type=float, default=100.0)
-    ap.add_argument("--contigs", type=int, default=6)
+    ap.add_argument("--genome-mbp", type=float, default=3100.0)
+    ap.add_argument("--contigs", type=int, default=24)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
     ap.add_argument("--read-len", type=int, default=100)
-    ap.add_argument("--mer", type=int, default=10)
-    ap.add_argument("--jump", type=int, default=0)
+    ap.add_argument("--mer", type=int, default=14)
+    ap.add_argument("--jump", type=int, default=0, help="0 = mer / 2 (the reference's default)")
     ap.add_argument("--max-kmer-hits", type=int, default=0)
     ap.add_argument("--no-nw", action="store_true")
     ap.add_argument("--locate", choices=["full", "sampled"], default="full")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline leg (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--cpu-kind", choices=["auto", "reference", "port"], default="auto")
+    ap.add_argument("--abi-reads", type=int, default=4_194_304, help="reads of the gm_map_batch + gm_output_batch leg (0 = skip)")
+    ap.add_argument("--abi-block", type=int, default=262144)
+    ap.add_argument("--abi-threads", type=int, default=2)
     ap.add_argument("--workdir", default=os.environ.get("GM_BENCH_DIR", "/tmp/gnumap_bench"))
     a = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
     import gnumap_amd as g
     from gnumap_amd import dist as gd
 
@@ -164,27 +261,34 @@ def main():
         raise SystemExit("bench.py needs an MI355X: libgnumap_hip has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    gd.init("nccl", dev)                                      # RCCL over xGMI when WORLD_SIZE > 1
-    barrier = gd.barrier
 
     kw = dict(mer=a.mer, jump=a.jump, max_kmer_hits=a.max_kmer_hits, nw=0 if a.no_nw else 1)
     key = f"g{a.genome_mbp:g}m_c{a.contigs}_s42"
     wd = os.path.join(a.workdir, key)
     fa = os.path.join(wd, "genome.fa")
+    ready = fa + ".index_ready"
     t_setup = time.time()
+    # the reference + index are made once per box by local rank 0 BEFORE the process group exists (no rank waits inside a collective)
     if local == 0:
         os.makedirs(wd, exist_ok=True)
-        if not os.path.exists(fa + ".gnumap.sa"):
+        if not os.path.exists(ready):
             log(f"[bench] generating {a.genome_mbp:g} Mbp reference and building its index (once; untimed)")
             make_genome(fa, a.genome_mbp, 42, a.contigs)
             g.index_build(fa)
+            open(ready, "w").write("ok\n")
+    else:
+        while not os.path.exists(ready):
+            time.sleep(1.0)
+    gd.init("nccl", dev)                                      # RCCL over xGMI when WORLD_SIZE > 1
+    barrier = gd.barrier
     barrier()
     flags = g.GM_INDEX_FULL_SA if a.locate == "full" else 0
     ix = g.Index(fa, device=local, flags=flags)
     # the packed reference as 2-bit codes for the read generator
     pac = np.fromfile(fa + ".gnumap.pac", np.uint8)[: ix.info.l_pac // 4 + 1]
-    codes = np.stack([(pac >> 6) & 3, (pac >> 4) & 3, (pac >> 2) & 3, pac & 3], 1).reshape(-1)[: ix.info.l_pac]
-    codes_t = torch.from_numpy(codes).to(dev)
+    pac_t = torch.from_numpy(pac).to(dev)
+    codes_t = torch.stack([(pac_t >> 6) & 3, (pac_t >> 4) & 3, (pac_t >> 2) & 3, pac_t & 3], 1).reshape(-1)[: ix.info.l_pac]
+    del pac_t, pac
     B, Q, Ln = make_reads(codes_t, a.reads, a.read_len, gd.read_seed(1000, rank), dev)
     del codes_t
     torch.cuda.empty_cache()
@@ -215,17 +319,42 @@ def main():
     elapsed = gd.max_over_ranks(t1 - t0, dev)
     ktimes = batch.kernel_times()
     counters = batch.counters()
+    batch.set_profiling(False)
 
-    # the one collective of the path: RCCL all-reduce of the device-resident coverage track (once per run, outside the
-    # per-step loop, like the reference's MPI Allreduce at end of run: src/Driver.cpp:1660-1672)
-    allreduce_ms = None
+    # the path the ABI exports to a host driver (N = 1 only: it is a per-GPU figure and the host is shared)
+    abi = None
+    if a.abi_reads > 0 and world == 1:
+        abi = abi_rate(g, ix, p, B, Q, Ln, a.abi_reads, a.abi_block, a.abi_threads, torch)
+        log(f"[bench] ABI leg: {abi}")
+
+    # the one collective of the path: RCCL all-reduce of the device-resident coverage track, IN PLACE on the library's HBM buffer
+    # (once per run, outside the per-step loop, like the reference's MPI Allreduce at end of run: src/Driver.cpp:1660-1672).  A known
+    # per-rank deposit pattern goes in first and is checked afterwards.
+    allreduce = None
     if world > 1 or os.environ.get("GM_FORCE_DIST") == "1":
-        cov = gd.DeviceTrack(ix.coverage_device_ptr(), ix.coverage_bins()).tensor(dev)
+        ix.coverage_reset(p.bin_size)
+        bins = ix.coverage_bins()
+        common, own = 8000, 800000 * (rank + 1)              # every rank deposits at `common`, and alone at `own`
+        ix.coverage_add(np.array([common, own], np.uint64), np.array([64, 64], np.uint32), np.array([rank + 1.0, 1.0], np.float32))
+        cov = gd.DeviceTrack(ix.coverage_device_ptr(), bins).tensor(dev)
         torch.cuda.synchronize(); barrier()
         ta = time.perf_counter()
         gd.allreduce_coverage(cov)
         torch.cuda.synchronize()
-        allreduce_ms = (time.perf_counter() - ta) * 1e3
+        dt = gd.max_over_ranks(time.perf_counter() - ta, dev)
+        bs = p.bin_size
+        got_common = cov[common // bs: common // bs + 64 // bs].cpu().numpy()
+        want_common = bs * world * (world + 1) / 2.0
+        ok = bool(np.all(got_common == want_common))
+        for r in range(world):
+            o = 800000 * (r + 1)
+            ok = ok and bool(np.all(cov[o // bs: o // bs + 64 // bs].cpu().numpy() == float(bs)))
+        ok = ok and float(cov.sum().item()) == want_common * (64 // bs) + world * 64.0
+        if not ok:
+            raise SystemExit(f"[bench] rank {rank}: coverage all-reduce gave a wrong track ({got_common[:4]} vs {want_common})")
+        nbytes = bins * 4
+        allreduce = dict(ms=dt * 1e3, bytes=nbytes, algbw_GBps=nbytes / dt / 1e9, busbw_GBps=nbytes / dt / 1e9 * 2 * (world - 1) / max(world, 1),
+                         in_place=True, checked=True)
 
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
@@ -241,12 +370,14 @@ def main():
         dom = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_step"]) if per_kernel else None
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        wkey = f"{key}_L{a.read_len}_m{a.mer}_{a.locate}"
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
-                # PMC passes are taken at 1 M reads per launch; traffic scales linearly with the reads of a launch
-                if j.get("workload_key") == f"{key}_L{a.read_len}_m{a.mer}_{a.locate}" and j.get("kernel") == dom:
-                    traffic = int(j["hbm_bytes_per_read"] * a.reads / max(1, per_kernel[dom]["launches"] // a.steps))
+                # PMC passes are separate rocprofv3 runs of this command at 1 M reads per launch (tools/collect_profiles.sh); traffic scales
+                # linearly with the reads of a launch
+                if j.get("workload_key") == wkey and dom in j.get("kernels", {}):
+                    traffic = int(j["kernels"][dom]["hbm_bytes_per_read"] * a.reads / max(1, per_kernel[dom]["launches"] // a.steps))
             except Exception:
                 traffic = None
         roof = None
@@ -257,12 +388,17 @@ def main():
         cpu = None
         if a.cpu_seconds > 0 and world == 1:         # rank 0 at N = 1 only
             threads = a.cpu_threads or min(16, os.cpu_count() or 1)
-            cpu = cpu_baseline(fa, B, Q, Ln, a.read_len, kw, a.cpu_seconds, threads)
-        # which BASELINE.json configuration the run has the shape of (default flags = configs[1], the one the metric is quoted on)
-        if a.genome_mbp == 100.0 and a.mer == 10 and not a.no_nw:
-            shape = "configs[1]"
+            if a.cpu_kind in ("auto", "reference"):
+                cpu = cpu_baseline_reference(fa, B, Q, a.read_len, a, a.cpu_seconds, threads, wd)
+            if cpu is None and a.cpu_kind != "reference":
+                cpu = cpu_baseline_port(fa, B, Q, a.read_len, kw, a.cpu_seconds, threads)
+        # which BASELINE.json configuration the run has the shape of
+        if a.genome_mbp >= 3000 and not a.no_nw:
+            shape = "the metric's configuration (human-scale reference, 100-bp reads, NormalScoredSeq NW)" if a.read_len == 100 else "human-scale reference"
         elif a.genome_mbp >= 3000:
-            shape = "configs[4] shape (human-scale reference, --no_nw)" if a.no_nw else "human-scale reference (configs[3]/[4] size, NormalScoredSeq)"
+            shape = "configs[4] shape (human-scale reference, --no_nw)"
+        elif a.genome_mbp == 100.0 and a.mer == 10 and not a.no_nw:
+            shape = "configs[1]"
         else:
             shape = "non-default workload"
         out = {
@@ -275,9 +411,11 @@ def main():
                        "reads_per_gpu": a.reads, "read_len": a.read_len, "genome_mbp": a.genome_mbp, "sharding": f"reads x{world} (no data-path collective)"},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "abi_reads_per_s": round(abi["reads_per_s"], 1) if abi else None,
+            "abi": abi,
             "kernels": {k: {"ms_per_step": round(v["ms_per_step"], 4), "launches_per_step": v["launches"] // a.steps, "alg_GBps": round(v["GBps"], 2)} for k, v in per_kernel.items()},
             "counters_per_step": counters,
-            "coverage_allreduce_ms": allreduce_ms,
+            "coverage_allreduce": allreduce,
             "pcie_inclusive_reads_per_s": round(pcie_inclusive, 1),
         }
         print(json.dumps(out), flush=True)

@@ -79,7 +79,7 @@ SAM_DTYPE = np.dtype([("read", "<u4"), ("pos", "<u8"), ("contig", "<u4"), ("chr_
 EXPORTS = ["gm_last_error", "gm_version", "gm_index_build", "gm_index_build_on", "gm_index_open", "gm_index_close", "gm_index_get_info", "gm_index_contig_name",
            "gm_index_contig_offset", "gm_index_window", "gm_params_default", "gm_params_finalize", "gm_batch_create", "gm_batch_destroy",
            "gm_batch_upload", "gm_map_batch_device", "gm_batch_counters", "gm_batch_set_profiling", "gm_batch_kernel_times", "gm_kernel_name",
-           "gm_batch_raw_hits", "gm_host_alloc", "gm_host_free", "gm_map_batch", "gm_output_batch",
+           "gm_batch_raw_hits", "gm_stream_create", "gm_stream_destroy", "gm_host_alloc", "gm_host_free", "gm_map_batch", "gm_output_batch",
            "gm_dev_sa_interval", "gm_dev_locate", "gm_dev_nw_score", "gm_dev_traceback", "gm_coverage_reset", "gm_coverage_bins",
            "gm_coverage_device_ptr", "gm_coverage_add", "gm_coverage_download", "gm_coverage_allreduce", "gm_coverage_write_sgr", "gm_coverage_enable_nuc", "gm_coverage_nuc_device_ptr",
            "gm_coverage_download_nuc", "gm_coverage_write_gmp"]
@@ -119,6 +119,8 @@ def load_library():
     L.gm_batch_kernel_times.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.gm_kernel_name.argtypes = [C.c_int]; L.gm_kernel_name.restype = C.c_char_p
     L.gm_batch_raw_hits.argtypes = [C.c_void_p, C.c_void_p, u64, C.POINTER(u64), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gm_stream_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    L.gm_stream_destroy.argtypes = [C.c_void_p, C.c_void_p]; L.gm_stream_destroy.restype = None
     L.gm_host_alloc.argtypes = [C.c_size_t]; L.gm_host_alloc.restype = C.c_void_p
     L.gm_host_free.argtypes = [C.c_void_p]; L.gm_host_free.restype = None
     L.gm_map_batch.argtypes = [C.c_void_p, C.POINTER(gm_params), C.c_void_p, C.POINTER(gm_reads), C.POINTER(gm_hits), C.c_void_p]
@@ -264,6 +266,18 @@ class Index:
     def coverage_device_ptr(self):
         return lib().gm_coverage_device_ptr(self.h)
 
+    def coverage_enable_nuc(self):
+        """-b / -d: the five per-nucleotide arrays reads[A,C,G,T,N][loc] in HBM (call after coverage_reset)"""
+        _chk(lib().gm_coverage_enable_nuc(self.h))
+
+    def coverage_nuc_device_ptr(self):
+        return lib().gm_coverage_nuc_device_ptr(self.h)
+
+    def coverage_add(self, pos, span, w, stream=None):
+        """gm_coverage_add: amount_genome[(pos+t)/bin] += w for t < span (GenomeBwt::AddScore)"""
+        pos = np.ascontiguousarray(pos, np.uint64); span = np.ascontiguousarray(span, np.uint32); w = np.ascontiguousarray(w, np.float32)
+        _chk(lib().gm_coverage_add(self.h, pos.ctypes.data, span.ctypes.data, w.ctypes.data, len(pos), stream))
+
     def coverage_download(self):
         out = np.zeros(self.coverage_bins(), np.float32)
         _chk(lib().gm_coverage_download(self.h, out.ctypes.data))
@@ -369,3 +383,67 @@ class Batch:
         raw = pool.tobytes()
         cigars = [raw[o:raw.index(b"\0", o)] for o in recs["cigar_off"]]
         return recs, cigars
+
+
+def pinned_empty(shape, dtype):
+    """numpy array over page-locked host memory from gm_host_alloc (freed when the array's owner object is collected)"""
+    dt = np.dtype(dtype)
+    nbytes = int(np.prod(shape)) * dt.itemsize
+    ptr = lib().gm_host_alloc(max(nbytes, 1))
+    if not ptr:
+        raise GnumapError(-7, lib().gm_last_error().decode())
+    buf = (C.c_uint8 * max(nbytes, 1)).from_address(ptr)
+    arr = np.frombuffer(buf, dtype=np.uint8, count=nbytes).view(dt).reshape(shape)
+    _PINNED[id(buf)] = (buf, ptr)
+    return arr
+
+
+_PINNED = {}
+
+
+class BlockRunner:
+    """The two ABI calls of one block loop iteration (gm_map_batch + gm_output_batch) on caller-owned, page-locked, REUSED buffers:
+    what a host driver thread does per block.  One BlockRunner = one gm_batch + one HIP stream + one set of output buffers."""
+
+    def __init__(self, index, params, max_reads, stride, stream=None):
+        self.index, self.params, self.max_reads, self.stride, self.stream = index, params, max_reads, stride, stream
+        self.batch = Batch(index, max_reads, stride)
+        n = max_reads
+        self.status = pinned_empty(n, np.int8); self.self_score = pinned_empty(n, np.float32)
+        self.top = pinned_empty(n, np.float64); self.den = pinned_empty(n, np.float64); self.mbegin = pinned_empty(n + 1, np.uint64)
+        self._alloc_hits(2 * n + 64, 2 * n + 64)
+        self._alloc_out(2 * n + 64, 16 * n + 1024)
+
+    def _alloc_hits(self, mcap, pcap):
+        self.matches = pinned_empty(mcap, MATCH_DTYPE); self.positions = pinned_empty(pcap, POS_DTYPE)
+
+    def _alloc_out(self, rcap, ccap):
+        self.recs = pinned_empty(rcap, SAM_DTYPE); self.pool = pinned_empty(ccap, np.uint8)
+
+    def run(self, B, Q, Ln):
+        """B, Q: [n, stride] uint8 (ideally page-locked), Ln: [n] uint16.  Returns (n_matches, n_records)."""
+        n = B.shape[0]
+        r = _reads_struct(B, Q, Ln)
+        L = lib()
+        while True:
+            h = gm_hits()
+            h.n = n; h.status = self.status.ctypes.data; h.self_score = self.self_score.ctypes.data; h.top_score = self.top.ctypes.data
+            h.denominator = self.den.ctypes.data; h.match_begin = self.mbegin.ctypes.data
+            h.matches = self.matches.ctypes.data; h.matches_cap = len(self.matches)
+            h.positions = self.positions.ctypes.data; h.positions_cap = len(self.positions)
+            rc = L.gm_map_batch(self.index.h, C.byref(self.params.c), self.batch.h, C.byref(r), C.byref(h), self.stream)
+            if rc == GM_E_CAPACITY:
+                self._alloc_hits(int(h.matches_cap) + 64, int(h.positions_cap) + 64)
+                continue
+            _chk(rc)
+            break
+        while True:
+            so = gm_sam_out()
+            so.recs = self.recs.ctypes.data; so.recs_cap = len(self.recs); so.cigar_pool = self.pool.ctypes.data; so.cigar_cap = len(self.pool)
+            rc = L.gm_output_batch(self.index.h, C.byref(self.params.c), self.batch.h, C.byref(r), C.byref(h), C.byref(so), self.stream)
+            if rc == GM_E_CAPACITY:
+                self._alloc_out(int(so.recs_cap) + 64, int(so.cigar_cap) + 64)
+                continue
+            _chk(rc)
+            break
+        return int(self.mbegin[n]), int(so.n_recs)

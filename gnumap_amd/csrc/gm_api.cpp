@@ -85,7 +85,7 @@ struct gm_index {
     uint64_t cov_bins = 0;
     uint32_t cov_bin_size = 0;
     // parameter tables resident in HBM: S256 (256x4 floats) + lut (512 float2)
-    std::vector<float> ptab_host;
+    std::map<std::vector<float>, DevBuf> ptabs;   // by content
     std::map<int, DevBuf> kmer_tabs;        // memoised backward search of the last T characters of a seed, per T
     std::map<int, DevBuf> kmer_ctabs;       // its compact form (16 B per 8 codes), per T
     std::mutex mu;
@@ -202,15 +202,22 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
     std::vector<float> tab(256 * 4 + 512 * 2);
     memcpy(tab.data(), p->S, sizeof(float) * 1024);
     build_lut(tab.data() + 1024);
+    // parameter tables are kept per CONTENT and never overwritten: batches of one index may run concurrently with different
+    // gm_params (e.g. --illumina switched off from some block on) without one call rewriting what another call's kernels read
+    const float* d_tab = nullptr;
     {
         std::lock_guard<std::mutex> lk(ix->mu);
-        if (ix->ptab_host != tab) {
-            int rc = ix->d_ptab.ensure(tab.size() * sizeof(float));
+        auto it = ix->ptabs.find(tab);
+        if (it == ix->ptabs.end()) {
+            if (ix->ptabs.size() >= 64) { gm_set_error("more than 64 distinct parameter tables on one index"); return GM_E_NOMEM; }
+            DevBuf nb;
+            int rc = nb.ensure(tab.size() * sizeof(float));
             if (rc) return rc;
-            HIPCHK(hipMemcpyAsync(ix->d_ptab.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(nb.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, st));
             HIPCHK(hipStreamSynchronize(st));
-            ix->ptab_host = tab;
+            it = ix->ptabs.emplace(tab, nb).first;
         }
+        d_tab = it->second.as<float>();
     }
     dp.mer = p->mer; dp.jump = p->jump; dp.kmin = p->min_seed_hits; dp.nw = p->nw; dp.fast = p->fast;
     dp.pos_strand = p->pos_strand; dp.neg_strand = p->neg_strand; dp.align_is_fraction = p->align_is_fraction;
@@ -272,8 +279,8 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
         }
     }
     dp.hcap = p->max_kmer_hits; dp.gap = p->gap; dp.align_score = p->align_score; dp.cutoff = p->cutoff;
-    dp.S256 = ix->d_ptab.as<float>();
-    dp.lut = reinterpret_cast<const float2*>(ix->d_ptab.as<float>() + 1024);
+    dp.S256 = d_tab;
+    dp.lut = reinterpret_cast<const float2*>(d_tab + 1024);
     return GM_OK;
 }
 
@@ -366,6 +373,7 @@ extern "C" void gm_index_close(gm_index* ix) {
         (void)hipSetDevice(ix->device);
         ix->d_bwt.release(); ix->d_sa.release(); ix->d_full.release(); ix->d_pac.release(); ix->d_contig.release();
         ix->d_cov.release(); ix->d_ptab.release(); ix->d_planes.release(); ix->d_nuc.release();
+        for (auto& kv : ix->ptabs) kv.second.release();
         for (auto& kv : ix->kmer_tabs) kv.second.release();
         for (auto& kv : ix->kmer_ctabs) kv.second.release();
     }
@@ -422,7 +430,10 @@ extern "C" int gm_index_window(const gm_index* ix, uint64_t begin, uint32_t L, c
 // batches
 // ------------------------------------------------------------------------------------------------
 extern "C" int gm_batch_create(gm_index* ix, uint32_t max_reads, uint32_t max_len, gm_batch** out) {
-    if (!ix || !out || max_reads == 0 || max_len == 0 || max_len > 4096) return GM_E_ARG;     /* reads themselves: <= 2048 bases (LDS budget of the DP kernels) */
+    if (!ix || !out || max_reads == 0 || max_len == 0) return GM_E_ARG;
+    if (max_len > 2048) { gm_set_error("gm_batch_create: reads of at most 2048 bases (LDS budget of the seed and DP kernels)"); return GM_E_ARG; }
+    // the vote kernels run one workgroup of 128 threads per read x strand and HIP refuses launches of 2^32 threads or more
+    if (max_reads > 16000000u) { gm_set_error("gm_batch_create: at most 16 000 000 reads per batch (2 x reads x 128 threads per launch must stay below 2^32); use several batches"); return GM_E_ARG; }
     if (ix->host_only) { gm_set_error("index opened host-only"); return GM_E_NO_DEVICE; }
     HIPCHK(hipSetDevice(ix->device));
     gm_batch* b = new gm_batch();
@@ -897,9 +908,23 @@ struct PhaseClock {                         // GM_TIMING=1: host-side phase time
     ~PhaseClock() { if (on) fprintf(stderr, "[gm_timing] %s:%s\n", what, line.c_str()); }
 };
 
+extern "C" int gm_stream_create(gm_index* ix, void** out) {
+    if (!ix || !out || ix->host_only) return GM_E_ARG;
+    HIPCHK(hipSetDevice(ix->device));
+    hipStream_t s = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = s;
+    return GM_OK;
+}
+extern "C" void gm_stream_destroy(gm_index* ix, void* s) {
+    if (!ix || !s) return;
+    (void)hipSetDevice(ix->device);
+    (void)hipStreamDestroy(S_(s));
+}
+
 extern "C" void* gm_host_alloc(size_t bytes) {
     void* q = nullptr;
-    if (hipHostMalloc(&q, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { gm_set_error("hipHostMalloc failed"); return nullptr; }
+    if (hipHostMalloc(&q, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) { gm_set_error("hipHostMalloc failed"); return nullptr; }
     return q;
 }
 extern "C" void gm_host_free(void* q) { if (q) (void)hipHostFree(q); }
@@ -1019,21 +1044,21 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
     // ---- host pass: ScoredSeq::get_SAM :300-309, is_greater :223-228, Driver.cpp:672-701 ----
     if (b->h_post.ensure((size_t)n_m * 4) || b->h_mapq.ensure((size_t)n_m * 4) || b->h_emit.ensure(n_m)) return GM_E_NOMEM;
     float* post = b->h_post.as<float>(); int32_t* mapq = b->h_mapq.as<int32_t>(); uint8_t* emit = b->h_emit.as<uint8_t>();
-    memset(emit, 0, n_m);
     uint64_t n_p = 0;
-    const double log10v = log(10);
+    const double log10v = log(10), e_m1 = exp(-1.0);                   // e_m1: the empty NormalScoredSeq a winner has to beat, ScoredSeq.h:117-120
     auto mapq_of = [&](double total) {
         int q;
         if (total == 1) q = 30; else q = (int)round(-10 * log(1 - total) / log10v);
         return q > 30 ? 30 : q;
     };
+    const int all = p->print_all_sam;
     for (uint32_t i = 0; i < n; ++i) {
         const uint64_t m0 = hits->match_begin[i], m1 = hits->match_begin[i + 1];
         if (m0 == m1) continue;
-        if (hits->status[i] != GM_READ_OK) { for (uint64_t m = m0; m < m1; ++m) { post[m] = 0; mapq[m] = 0; } continue; }
-        const double den = hits->denominator[i];
+        if (hits->status[i] != GM_READ_OK) { for (uint64_t m = m0; m < m1; ++m) { post[m] = 0; mapq[m] = 0; emit[m] = 0; } continue; }
+        const double den = hits->denominator[i], top = hits->top_score[i];
         int64_t best = -1;
-        double best_log = exp(-1.0);                                   // the empty NormalScoredSeq, ScoredSeq.h:117-120
+        double best_log = e_m1, best_total = 0;
         for (uint64_t m = m0; m < m1; ++m) {
             const gm_match& mm = hits->matches[m];
             if (mm.read != i || mm.pos_end < mm.pos_begin) { gm_set_error("gm_hits: match does not belong to its read"); return GM_E_ARG; }
@@ -1041,26 +1066,26 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
             const double lg = exp((double)mm.score);
             const double total = lg / den;                             // ScoredSeq.h:300
             post[m] = (float)total;                                    // AddScore(const float& amt), NormalScoredSeq.cpp:70
-            mapq[m] = 0;
-            if (p->print_all_sam) { emit[m] = 1; mapq[m] = mapq_of(total); }
-            if (lg > best_log) { best = (int64_t)m; best_log = lg; }  // is_greater: strict, first in key order wins
+            emit[m] = (uint8_t)all;
+            mapq[m] = all ? mapq_of(total) : 0;
+            if (lg > best_log) { best = (int64_t)m; best_log = lg; best_total = total; }   // is_greater: strict, first in key order wins
         }
-        if (!p->print_all_sam && best >= 0 && (double)hits->matches[best].score > hits->top_score[i] - 0.00001) {   // Driver.cpp:695
+        if (!all && best >= 0 && (double)hits->matches[best].score > top - 0.00001) {      // Driver.cpp:695
             emit[best] = 1;
-            mapq[best] = mapq_of(exp((double)hits->matches[best].score) / den);
+            mapq[best] = mapq_of(best_total);
         }
     }
     if (n_p > hits->positions_cap) { gm_set_error("gm_hits: positions out of range"); return GM_E_ARG; }
     pc.lap("fp64");
     // ---- device ----
-    const uint32_t ops_stride = 2 * ((b->stride + 7u) & ~7u) + 8;
+    const uint32_t ops_words = gm_ops_words(b->stride), codes_stride = 32u * ops_words;
     const bool nuc = p->mode != GM_MODE_NORMAL && ix->nuc_on;
     if (b->g_matches.ensure((size_t)n_m * sizeof(GmDevMatch)) || b->g_positions.ensure((size_t)(n_p + 1) * sizeof(GmDevPos)) ||
         b->o_posmatch.ensure((size_t)(n_p + 1) * 4) || b->o_post.ensure((size_t)n_m * 4) || b->o_mapq.ensure((size_t)n_m * 4) || b->o_emit.ensure(n_m) ||
-        b->tb_items.ensure((size_t)n_m * sizeof(GmCand)) || b->tb_ops.ensure((size_t)n_m * ops_stride) || b->tb_len.ensure((size_t)n_m * 2) ||
+        b->tb_items.ensure((size_t)n_m * sizeof(GmCand)) || b->tb_ops.ensure((size_t)n_m * ops_words * 8) || b->tb_len.ensure((size_t)n_m * 2) ||
         b->o_reccnt.ensure((size_t)n_m * 4) || b->o_cigcnt.ensure((size_t)n_m * 4) || b->o_recoff.ensure(((size_t)n_m + 1) * 8) ||
         b->o_cigoff.ensure(((size_t)n_m + 1) * 8) || b->scan_tmp.ensure(((size_t)std::max<uint32_t>(n_m, n) / 1024 + 8) * 8) || b->o_small.ensure(64) ||
-        (nuc && b->o_codes.ensure((size_t)n_m * ops_stride))) return GM_E_NOMEM;
+        (nuc && b->o_codes.ensure((size_t)n_m * codes_stride))) return GM_E_NOMEM;
     const GmDevMatch* d_m = b->g_matches.as<GmDevMatch>(); const GmDevPos* d_p = b->g_positions.as<GmDevPos>();
     HIPCHK(hipMemcpyAsync(b->g_matches.p, hits->matches, (size_t)n_m * sizeof(gm_match), hipMemcpyHostToDevice, st));
     if (n_p) HIPCHK(hipMemcpyAsync(b->g_positions.p, hits->positions, (size_t)n_p * sizeof(gm_pos), hipMemcpyHostToDevice, st));
@@ -1070,11 +1095,11 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
     HIPCHK(hipMemsetAsync(b->o_posmatch.p, 0xFF, (size_t)(n_p + 1) * 4, st));
     HIPCHK(hipMemsetAsync(b->o_small.p, 0, 64, st));
     fill_dev_batch(b);
-    KCHK(gmk_out_items(d_m, n_m, 0, b->tb_items.as<GmCand>(), b->o_posmatch.as<uint32_t>(), st));
-    // one traceback per ScoredSeq, oriented by its first strand (NormalScoredSeq::score, ScoredSeq::get_SAM)
-    KCHK(gmk_traceback(ix->dev, dp, b->dev, b->tb_items.as<GmCand>(), n_m, b->tb_ops.as<uint8_t>(), ops_stride, b->tb_len.as<uint16_t>(), st));
-    KCHK(gmk_out_count(b->dev, d_m, n_m, b->o_emit.as<uint8_t>(), b->tb_ops.as<uint8_t>(), ops_stride, b->tb_len.as<uint16_t>(), p->nw,
-                       b->o_reccnt.as<uint32_t>(), b->o_cigcnt.as<uint32_t>(), b->o_small.as<uint32_t>(), st));
+    KCHK(gmk_out_items(d_m, n_m, 0, b->o_emit.as<uint8_t>(), b->tb_items.as<GmCand>(), b->o_posmatch.as<uint32_t>(), b->o_reccnt.as<uint32_t>(), st));
+    // one traceback per ScoredSeq, oriented by its first strand (NormalScoredSeq::score, ScoredSeq::get_SAM); the kernel also sizes the
+    // CIGAR text of the printed ones and finds the longest aligned length
+    KCHK(gmk_traceback(ix->dev, dp, b->dev, b->tb_items.as<GmCand>(), n_m, b->tb_ops.as<unsigned long long>(), ops_words, b->tb_len.as<uint16_t>(),
+                       b->o_emit.as<uint8_t>(), b->o_cigcnt.as<uint32_t>(), b->o_small.as<uint32_t>(), st));
     KCHK(gmk_scan_u32(b->o_reccnt.as<uint32_t>(), n_m, b->o_recoff.as<uint64_t>(), b->scan_tmp.as<unsigned long long>(), st));
     KCHK(gmk_scan_u32(b->o_cigcnt.as<uint32_t>(), n_m, b->o_cigoff.as<uint64_t>(), b->scan_tmp.as<unsigned long long>(), st));
     uint64_t n_recs = 0, cig_len = 0; uint32_t max_span = 0;
@@ -1093,16 +1118,16 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
     if (cig_len > 0xFFFFFFFFull) { gm_set_error("CIGAR pool beyond 4 GB in one batch; use smaller batches"); return GM_E_CAPACITY; }
     if (b->o_recs.ensure((size_t)(n_recs + 1) * sizeof(GmDevSamRec)) || b->o_pool.ensure((size_t)cig_len + 16)) return GM_E_NOMEM;
     if (n_recs) {
-        KCHK(gmk_out_write(ix->dev, b->dev, d_m, d_p, n_m, b->o_emit.as<uint8_t>(), b->o_mapq.as<int32_t>(), b->o_post.as<float>(), b->tb_ops.as<uint8_t>(),
-                           ops_stride, b->tb_len.as<uint16_t>(), p->nw, b->o_recoff.as<uint64_t>(), b->o_cigoff.as<uint64_t>(),
+        KCHK(gmk_out_write(ix->dev, b->dev, d_m, d_p, n_m, b->o_emit.as<uint8_t>(), b->o_mapq.as<int32_t>(), b->o_post.as<float>(), b->tb_ops.as<unsigned long long>(),
+                           ops_words, b->tb_len.as<uint16_t>(), p->nw, b->o_recoff.as<uint64_t>(), b->o_cigoff.as<uint64_t>(),
                            b->o_recs.as<GmDevSamRec>(), b->o_pool.as<char>(), st));
         HIPCHK(hipMemcpyAsync(out->recs, b->o_recs.p, (size_t)n_recs * sizeof(gm_sam_rec), hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(out->cigar_pool, b->o_pool.p, (size_t)cig_len, hipMemcpyDeviceToHost, st));
     }
     if (ix->cov_bins && n_p && max_span) {
-        if (nuc) KCHK(gmk_out_codes(b->dev, dp, d_m, n_m, b->tb_ops.as<uint8_t>(), ops_stride, b->tb_len.as<uint16_t>(), b->o_codes.as<uint8_t>(), st));
+        if (nuc) KCHK(gmk_out_codes(b->dev, dp, d_m, n_m, b->tb_ops.as<unsigned long long>(), ops_words, b->tb_len.as<uint16_t>(), b->o_codes.as<uint8_t>(), codes_stride, st));
         KCHK(gmk_out_deposit(ix->d_cov.as<float>(), ix->cov_bins, ix->cov_bin_size, d_m, d_p, b->o_posmatch.as<uint32_t>(), n_p, b->tb_len.as<uint16_t>(),
-                             b->o_post.as<float>(), max_span, nuc ? ix->d_nuc.as<float>() : nullptr, nuc ? b->o_codes.as<uint8_t>() : nullptr, ops_stride, st));
+                             b->o_post.as<float>(), max_span, nuc ? ix->d_nuc.as<float>() : nullptr, nuc ? b->o_codes.as<uint8_t>() : nullptr, codes_stride, st));
     }
     HIPCHK(hipStreamSynchronize(st));
     pc.lap("records+coverage");
@@ -1214,13 +1239,20 @@ extern "C" int gm_dev_traceback(gm_index* ix, const gm_params* p, const gm_reads
         if (read_idx[i] >= reads->n || pos[i] > 0xFFFFFFFFull) { gm_batch_destroy(b); return GM_E_ARG; }
         c[i].rs = read_idx[i] * 2 + (strand[i] ? 1 : 0); c[i].b = (uint32_t)pos[i]; c[i].step = 0; c[i].flags = 0; c[i].pad = 0; c[i].score = 0;
     }
+    const uint32_t ow = gm_ops_words(b->stride);
+    std::vector<unsigned long long> packed((size_t)n * ow);
     do {
-        if (b->tb_items.ensure((size_t)n * sizeof(GmCand) + 16) || b->tb_ops.ensure((size_t)n * ops_stride + 16) || b->tb_len.ensure((size_t)n * 2 + 16)) { rc = GM_E_NOMEM; break; }
+        if (b->tb_items.ensure((size_t)n * sizeof(GmCand) + 16) || b->tb_ops.ensure((size_t)n * ow * 8 + 16) || b->tb_len.ensure((size_t)n * 2 + 16)) { rc = GM_E_NOMEM; break; }
         if (n && hipMemcpy(b->tb_items.p, c.data(), (size_t)n * sizeof(GmCand), hipMemcpyHostToDevice) != hipSuccess) { rc = GM_E_HIP; break; }
-        if (n && hipMemset(b->tb_ops.p, 0, (size_t)n * ops_stride) != hipSuccess) { rc = GM_E_HIP; break; }
-        if (gmk_traceback(ix->dev, dp, b->dev, b->tb_items.as<GmCand>(), n, b->tb_ops.as<uint8_t>(), ops_stride, b->tb_len.as<uint16_t>(), nullptr)) { rc = GM_E_HIP; break; }
-        if (n && hipMemcpy(ops, b->tb_ops.p, (size_t)n * ops_stride, hipMemcpyDeviceToHost) != hipSuccess) { rc = GM_E_HIP; break; }
+        if (n && hipMemset(b->tb_ops.p, 0, (size_t)n * ow * 8) != hipSuccess) { rc = GM_E_HIP; break; }
+        if (gmk_traceback(ix->dev, dp, b->dev, b->tb_items.as<GmCand>(), n, b->tb_ops.as<unsigned long long>(), ow, b->tb_len.as<uint16_t>(), nullptr, nullptr, nullptr, nullptr)) { rc = GM_E_HIP; break; }
+        if (n && hipMemcpy(packed.data(), b->tb_ops.p, (size_t)n * ow * 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = GM_E_HIP; break; }
         if (n && hipMemcpy(ops_len, b->tb_len.p, (size_t)n * 2, hipMemcpyDeviceToHost) != hipSuccess) { rc = GM_E_HIP; break; }
+        for (uint32_t i = 0; i < n; ++i) {                                // the public form: one character per operation
+            char* o = ops + (size_t)i * ops_stride;
+            memset(o, 0, ops_stride);
+            for (uint32_t k = 0; k < ops_len[i] && k < ops_stride; ++k) o[k] = "MID?"[(packed[(size_t)i * ow + (k >> 5)] >> (2 * (k & 31))) & 3];
+        }
     } while (0);
     gm_batch_destroy(b);
     if (rc) { gm_set_error("gm_dev_traceback: HIP failure"); return rc; }

@@ -141,21 +141,21 @@ int gmk_scan_hits(const GmDevBatch& b, void* stream);
 int gmk_scatter(const GmDevBatch& b, uint32_t grid, void* stream);
 int gmk_sa_interval(const GmDevIndex& ix, const uint8_t* kmers, uint32_t n, uint32_t m, uint32_t* start, uint32_t* end, void* stream);
 int gmk_locate(const GmDevIndex& ix, const uint32_t* ranks, uint32_t n, int use_full_sa, uint32_t* out, void* stream);
+// traceback operations: 2 bits each (0 M, 1 I, 2 D), operation k in 64-bit word k / 32 at bits 2 (k % 32); ops_words words per item
+inline uint32_t gm_ops_words(uint32_t stride) { return (2u * ((stride + 7u) & ~7u) + 8u + 31u) / 32u; }
 int gmk_traceback(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, const GmCand* items, uint32_t n,
-                  uint8_t* ops, uint32_t ops_stride, uint16_t* ops_len, void* stream);
+                  unsigned long long* ops, uint32_t ops_words, uint16_t* ops_len, const uint8_t* emit, uint32_t* cig_cnt, uint32_t* max_span, void* stream);
 int gmk_scan_u32(const uint32_t* in, uint64_t n, uint64_t* out, unsigned long long* tmp, void* stream);
 int gmk_group_count(const GmDevIndex& ix, const GmDevBatch& b, const GmDevGroup& g, int nw, int unique_only, uint32_t max_matches, void* stream);
 int gmk_group_write(const GmDevBatch& b, const GmDevGroup& g, void* stream);
-int gmk_out_items(const GmDevMatch* matches, uint32_t n_m, uint32_t read_base, GmCand* items, uint32_t* pos_match, void* stream);
-int gmk_out_count(const GmDevBatch& b, const GmDevMatch* matches, uint32_t n_m, const uint8_t* emit, const uint8_t* ops, uint32_t ops_stride,
-                  const uint16_t* ops_len, int nw, uint32_t* rec_cnt, uint32_t* cig_cnt, uint32_t* max_span, void* stream);
+int gmk_out_items(const GmDevMatch* matches, uint32_t n_m, uint32_t read_base, const uint8_t* emit, GmCand* items, uint32_t* pos_match, uint32_t* rec_cnt, void* stream);
 int gmk_out_write(const GmDevIndex& ix, const GmDevBatch& b, const GmDevMatch* matches, const GmDevPos* positions, uint32_t n_m, const uint8_t* emit,
-                  const int32_t* mapq, const float* post, const uint8_t* ops, uint32_t ops_stride, const uint16_t* ops_len, int nw,
+                  const int32_t* mapq, const float* post, const unsigned long long* ops, uint32_t ops_words, const uint16_t* ops_len, int nw,
                   const uint64_t* rec_off, const uint64_t* cig_off, GmDevSamRec* recs, char* pool, void* stream);
-int gmk_out_codes(const GmDevBatch& b, const GmDevParams& p, const GmDevMatch* matches, uint32_t n_m, const uint8_t* ops, uint32_t ops_stride,
-                  const uint16_t* ops_len, uint8_t* codes, void* stream);
+int gmk_out_codes(const GmDevBatch& b, const GmDevParams& p, const GmDevMatch* matches, uint32_t n_m, const unsigned long long* ops, uint32_t ops_words,
+                  const uint16_t* ops_len, uint8_t* codes, uint32_t codes_stride, void* stream);
 int gmk_out_deposit(float* cov, uint64_t bins, uint32_t bin_size, const GmDevMatch* matches, const GmDevPos* positions, const uint32_t* pos_match,
-                    uint64_t n_p, const uint16_t* ops_len, const float* post, uint32_t max_span, float* nuc, const uint8_t* codes, uint32_t ops_stride,
+                    uint64_t n_p, const uint16_t* ops_len, const float* post, uint32_t max_span, float* nuc, const uint8_t* codes, uint32_t codes_stride,
                     void* stream);
 int gmk_coverage_add(float* cov, uint64_t bins, uint32_t bin_size, const uint64_t* pos, const uint32_t* span, const float* w,
                      uint32_t n, uint32_t max_span, float* nuc, const uint8_t* codes, const uint64_t* code_off, void* stream);

@@ -356,17 +356,18 @@ __global__ void __launch_bounds__(256) k_prep(GmDevIndex ix, GmDevParams p, GmDe
 // ------------------------------------------------------------------------------------------------
 // seed: one lane per read x strand walks the read exactly like align_sequence does
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 8) k_seed(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
-    // the 128 reads of this workgroup (2 lanes per read: + and - strand) are staged into LDS with coalesced 16-byte loads
+__global__ void __launch_bounds__(256, 8) k_seed(GmDevIndex ix, GmDevParams p, GmDevBatch b, uint32_t TR) {
+    // the TR reads of a tile (2 lanes per read: + and - strand; TR = 128 unless long reads leave less room in LDS: gmk_seed) are
+    // staged into LDS with coalesced 16-byte loads
     extern __shared__ __attribute__((aligned(16))) unsigned char s_reads[];
     unsigned long long nk = 0, nocc = 0, nblk = 0, ntab = 0, nseed_all = 0, nent_all = 0;
     // persistent workgroups: a tile is 128 reads; the work counters go to HBM once per wave at the very end (one atomic per
     // wave per tile on six shared addresses used to cost more than the seed search itself: ~90 M atomics/s per address)
-    const uint32_t n_tiles = (b.n + 127u) / 128u;
+    const uint32_t n_tiles = (b.n + TR - 1u) / TR;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const uint32_t r0 = tile * 128u;
+    const uint32_t r0 = tile * TR;
     {
-        const uint32_t nr = b.n - r0 < 128u ? b.n - r0 : 128u;
+        const uint32_t nr = b.n - r0 < TR ? b.n - r0 : TR;
         const size_t bytes = (size_t)nr * b.stride;                       // stride is a multiple of 8; r0 * stride of 16 when stride % 16 == 0
         const unsigned char* src = b.bases + (size_t)r0 * b.stride;
         if ((((size_t)src) & 15) == 0) {
@@ -379,9 +380,9 @@ __global__ void __launch_bounds__(256, 8) k_seed(GmDevIndex ix, GmDevParams p, G
         }
     }
     __syncthreads();
-    const uint32_t rs = tile * 256u + threadIdx.x;
+    const uint32_t rs = tile * 2u * TR + threadIdx.x;
     unsigned long long nseed = 0, nent = 0;
-    if (rs < 2 * b.n) {
+    if (threadIdx.x < 2u * TR && rs < 2 * b.n) {
         uint32_t r = rs >> 1, strand = rs & 1;
         bool on = b.status[r] == 0 && (strand ? p.neg_strand : p.pos_strand);
         if (on) {
@@ -1195,269 +1196,7 @@ __global__ void __launch_bounds__(NT) k_vote_block(GmDevIndex ix, GmDevParams p,
     }
 }
 
-// ---- k_vote_pipe: the dense-seed vote kernel, a workgroup walks R consecutive read x strands ----------------------
-// Same algorithm as k_vote_block (counting filter -> compacted list -> exact table), rebuilt around what the counters
-// show (rocprofv3 --pmc, 1 M reads): the kernel is VALU-bound - 66 % VALU busy, ~100 vector instructions per hit, LDS only
-// 33 % busy - not latency- or LDS-bound.  So:
-//   * per-hit work is branch-light: a sentinel seed ends the prefix walk, invalid entries carry tag 64 whose read offset
-//     is 0xFFFFFFFF so their window start saturates to 0 and they drop out with the `b != 0` test every pass needs anyway;
-//   * the per-read x strand fixed cost is cut: 0 is the empty key (b = 0 never enters the table), so the zeroed filter
-//     IS the empty table; the filter is scanned and zeroed with 16-byte LDS operations; inserted slots are remembered in a
-//     list, and emit + clean-up touch only those - no 512-slot sweep, no re-zeroing of 8 KB;
-//   * the located positions of read x strand i+1 (and the seeds of i+2, by wave 0) are loaded while i is voted on;
-//     barriers are LDS-only (s_waitcnt lgkmcnt(0); s_barrier) so that they do not wait for those loads.
-// Read x strands with more than GMB_ENTRIES hits go to k_vote_fast_list through b.big_list.
-#define GMP_R 16
-#define GMP_KCAP 448                     // distinct positions the 512-slot table takes
 __device__ __forceinline__ void gm_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-template <bool MASK64, bool FULL, int R, int NT>
-__global__ void __launch_bounds__(NT, NT == 256 ? (R > 1 ? 6 : 8) : 5) k_vote_pipe(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
-    constexpr int U = GMB_ENTRIES / NT, TS = 512, NW = NT / 64, LSEG = GMB_LCAP / NW, ZK = 512 / NT;
-    __shared__ uint4 s_r0v[512];                     // 8 KB: counting filter (8192 x 8 bit), then keys | vals | low masks | high masks x 512
-    __shared__ uint32_t s_lbp[GMB_LCAP];
-    __shared__ uint8_t s_lt[GMB_LCAP];
-    __shared__ uint2 s_sd[2][66];                    // per seed {end of its entries in the flat hit list, SA rank of entry 0 minus its start}
-    __shared__ uint32_t s_pos[2][66], s_chunk[2][64], s_cnt0[64];
-    __shared__ uint16_t s_klist[GMP_KCAP];
-    __shared__ unsigned long long s_coff[2];
-    __shared__ uint32_t s_ns[2], s_E[2], s_nkeys[2], s_full[2], s_lcnt[NW];
-    uint32_t* const s_r0 = reinterpret_cast<uint32_t*>(s_r0v);
-    const int tid = threadIdx.x, lane = gm_lane(), wave = tid >> 6;
-    const uint32_t rs0 = blockIdx.x * R;
-    const uint32_t rs_end = (rs0 + R < 2 * b.n) ? rs0 + R : 2 * b.n;
-
-    // ---- wave 0: seeds of a read x strand, global -> registers (fetch) -> LDS buffer (commit)
-    GmSeed nx; nx.k = 0; nx.l = 0; nx.pos = 0;
-    uint32_t nx_ns = 0; unsigned long long nx_coff = 0;
-    auto fetch_seeds = [&](uint32_t rs) {
-        nx.k = 0; nx.l = 0; nx.pos = 0; nx_ns = 0; nx_coff = 0;
-        if (rs < rs_end) {
-            nx_ns = b.n_seeds[rs];
-            if ((uint32_t)lane < b.max_seeds) nx = b.seeds[(size_t)rs * b.max_seeds + lane];     // lanes >= n_seeds are masked at commit
-            if (!FULL) nx_coff = b.entry_off[rs];
-        }
-    };
-    auto commit_seeds = [&](int buf, uint32_t rs) {
-        uint32_t ns = nx_ns;
-        if (p.nw && p.fast && ns > 1) ns = 1;
-        uint32_t cnt = (uint32_t)lane < ns ? nx.l - nx.k + 1 : 0;
-        uint32_t incl = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
-        uint32_t E0 = __shfl(incl, 63);
-        if (E0 > GMB_ENTRIES) {                      // wave-uniform: too many hits for the register path
-            if (lane == 0) { uint32_t at = atomicAdd(b.n_big, 1u); b.big_list[at] = rs; }
-            ns = 0; E0 = 0;
-        }
-        const bool real = (uint32_t)lane < ns;       // entries >= ns are sentinels: they end the walk and give offset 0xFFFFFFFF
-        s_sd[buf][lane] = real ? make_uint2(incl, nx.k - (incl - cnt)) : make_uint2(0xFFFFFFFFu, 0u);
-        s_pos[buf][lane] = real ? nx.pos : 0xFFFFFFFFu;
-        if (lane == 0) {
-            s_sd[buf][64] = make_uint2(0xFFFFFFFFu, 0u); s_pos[buf][64] = 0xFFFFFFFFu;
-            s_ns[buf] = ns; s_E[buf] = E0; s_coff[buf] = nx_coff;
-        }
-        // seed of the first entry of every 32-entry chunk; s_sd[buf] was written by this same wave, LDS operations of one
-        // wave complete in order
-        const uint32_t e = (uint32_t)lane * 32u;
-        uint32_t lo = 0, hi = ns;
-        while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (s_sd[buf][mid].x <= e) lo = mid + 1; else hi = mid; }
-        s_chunk[buf][lane] = lo;
-    };
-
-    uint32_t cc[U], tp_next[U / 4];                  // located positions in flight, their seed tags (4 x 8 bit per register)
-    auto issue = [&](int buf) {                      // loads of the read x strand whose seeds are in LDS buffer `buf`
-        const uint32_t E = s_E[buf];
-        const uint32_t* src = FULL ? ix.full_sa : b.coords + s_coff[buf];
-#pragma unroll
-        for (int q = 0; q < U / 4; ++q) tp_next[q] = 0;
-        // entry e = u * NT + tid: the seed index only grows with u, so each lane walks the seed array once
-        uint32_t t = s_chunk[buf][tid >> 5];
-        uint2 sd = s_sd[buf][t];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {                // each load leaves as soon as its address is known; nothing waits for it here
-            const uint32_t e = (uint32_t)u * NT + (uint32_t)tid;
-            while (sd.x <= e) { ++t; sd = s_sd[buf][t]; }
-            const bool in = e < E;
-            cc[u] = src[in ? (FULL ? sd.y + e : e) : 0u];
-            tp_next[u >> 2] |= (in ? t : 64u) << ((u & 3) * 8);
-        }
-    };
-
-    // ---- prologue
-    if (wave == 0) {
-        fetch_seeds(rs0); commit_seeds(0, rs0);
-        if (R > 1) { fetch_seeds(rs0 + 1); commit_seeds(1, rs0 + 1); fetch_seeds(rs0 + 2); }
-    }
-#pragma unroll
-    for (int k = 0; k < ZK; ++k) s_r0v[tid + NT * k] = make_uint4(0u, 0u, 0u, 0u);
-    if (tid < 64) s_cnt0[tid] = 0;
-    if (tid < 2) { s_nkeys[tid] = 0; s_full[tid] = 0; }
-    gm_lds_barrier();
-    issue(0);
-
-    for (uint32_t rs = rs0; rs < rs_end; ++rs) {
-        const int cur = (int)((rs - rs0) & 1u);
-        const uint32_t E = s_E[cur];
-        // ---- S1: take delivery of this read x strand's positions, then put the next one's loads in flight
-        uint32_t bpv[U], tp[U / 4];
-#pragma unroll
-        for (int q = 0; q < U / 4; ++q) tp[q] = tp_next[q];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t t = (tp[u >> 2] >> ((u & 3) * 8)) & 255u;
-            bpv[u] = __builtin_elementwise_sub_sat(cc[u], s_pos[cur][t]);      // :267; tag 64 (no entry) -> 0
-        }
-        if (R > 1 && rs + 1 < rs_end) issue(cur ^ 1);
-        if (E != 0) {                                // block-uniform
-            const bool filter = p.kmin >= 2 && E > 256;
-            uint32_t wcount = 0;                     // wave-uniform fill of this wave's list segment
-            if (filter) {
-                // ---- S2: pass 1, one non-returning ds_add per hit into the counting filter
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (bpv[u] != 0) {
-                        const uint32_t h = (bpv[u] * 0x9E3779B1u) >> (32 - GMB_FBITS);
-                        atomicAdd(&s_r0[h & 2047u], 1u << ((h >> 11) << 3));
-                    }
-                gm_lds_barrier();
-                // ---- S3: pass 2a, hits whose slot counted >= 2 -> list (ballot + plain stores)
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    bool pass = false;
-                    if (bpv[u] != 0) {
-                        uint32_t bx = bpv[u];
-                        asm volatile("" : "+v"(bx));         // recompute the hash: 16 slot addresses kept alive from pass 1 cost 32 registers
-                        const uint32_t h = (bx * 0x9E3779B1u) >> (32 - GMB_FBITS);
-                        pass = ((s_r0[h & 2047u] >> ((h >> 11) << 3)) & 255u) >= 2u;
-                    } else {
-                        const uint32_t t = (tp[u >> 2] >> ((u & 3) * 8)) & 255u;
-                        if (t < 64u) atomicAdd(&s_cnt0[t], 1u);
-                    }
-                    const unsigned long long m = __ballot(pass);
-                    if (pass) {
-                        const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, wcount));
-                        if (at < (uint32_t)LSEG) { s_lbp[wave * LSEG + at] = bpv[u]; s_lt[wave * LSEG + at] = (uint8_t)((tp[u >> 2] >> ((u & 3) * 8)) & 255u); }
-                    }
-                    wcount += (uint32_t)__popcll(m);
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const bool pass = bpv[u] != 0;
-                    const uint32_t t = (tp[u >> 2] >> ((u & 3) * 8)) & 255u;
-                    if (!pass && t < 64u) atomicAdd(&s_cnt0[t], 1u);
-                    const unsigned long long m = __ballot(pass);
-                    if (pass) {
-                        const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, wcount));
-                        if (at < (uint32_t)LSEG) { s_lbp[wave * LSEG + at] = bpv[u]; s_lt[wave * LSEG + at] = (uint8_t)t; }
-                    }
-                    wcount += (uint32_t)__popcll(m);
-                }
-            }
-            if (lane == 0) { s_lcnt[wave] = wcount < (uint32_t)LSEG ? wcount : (uint32_t)LSEG; if (wcount > (uint32_t)LSEG) s_full[cur] = 1; }
-            gm_lds_barrier();
-            if (filter) {
-                // ---- S4: the filter is dead: check it for saturation (a byte >= 128) and zero it - that is the empty table
-                uint32_t acc = 0;
-#pragma unroll
-                for (int k = 0; k < ZK; ++k) {
-                    const uint4 v = s_r0v[tid + NT * k];
-                    acc |= v.x | v.y | v.z | v.w;
-                    s_r0v[tid + NT * k] = make_uint4(0u, 0u, 0u, 0u);
-                }
-                if (acc & 0x80808080u) s_full[cur] = 1;
-                gm_lds_barrier();
-            }
-            // ---- S5: pass 2b, the list through the exact table (key 0 = empty)
-            uint32_t* const keys = s_r0; uint32_t* const vals = s_r0 + TS; uint32_t* const mlo = s_r0 + 2 * TS; uint32_t* const mhi = s_r0 + 3 * TS;
-            {
-                const uint32_t n_l = s_lcnt[wave];
-                bool full = false;
-                for (uint32_t i0 = 0; i0 < n_l; i0 += 64) {
-                    const uint32_t i = i0 + (uint32_t)lane;
-                    if (i < n_l) {
-                        const uint32_t bp = s_lbp[wave * LSEG + i], t = s_lt[wave * LSEG + i];
-                        uint32_t slot = (bp * 0x85EBCA6Bu) >> 23;
-                        bool found = false;
-                        for (int probe = 0; probe < TS; ++probe) {
-                            const uint32_t old = atomicCAS(&keys[slot], 0u, bp);
-                            if (old == 0u) {
-                                const uint32_t at = atomicAdd(&s_nkeys[cur], 1u);
-                                if (at < GMP_KCAP) s_klist[at] = (uint16_t)slot;
-                                found = true; break;
-                            }
-                            if (old == bp) { found = true; break; }
-                            slot = (slot + 1) & (TS - 1);
-                        }
-                        if (!found) full = true;
-                        else {
-                            atomicAdd(&vals[slot], 1u);
-                            if (t < 32) atomicOr(&mlo[slot], 1u << t);
-                            else if (MASK64) atomicOr(&mhi[slot], 1u << (t - 32));
-                        }
-                    }
-                }
-                if (full) s_full[cur] = 1;
-            }
-            gm_lds_barrier();
-            const uint32_t nk_all = s_nkeys[cur];
-            const bool failed = s_full[cur] || nk_all > GMP_KCAP;
-            // ---- S6: emit the inserted positions (NW step = kmin-th lowest step that voted) and zero their slots again
-            if (!failed) {
-                for (uint32_t i0 = 0; i0 < nk_all; i0 += NT) {       // block-uniform trip count
-                    const uint32_t i = i0 + (uint32_t)tid;
-                    bool emit = false; uint32_t key = 0, step = 0;
-                    if (i < nk_all) {
-                        const uint32_t slot = s_klist[i];
-                        key = keys[slot];
-                        const uint32_t v = vals[slot], ml = mlo[slot], mh = MASK64 ? mhi[slot] : 0u;
-                        keys[slot] = 0; vals[slot] = 0; mlo[slot] = 0; if (MASK64) mhi[slot] = 0;
-                        emit = v >= (uint32_t)p.kmin;
-                        if (emit) {
-                            if (p.nw) {
-                                unsigned long long m = (unsigned long long)ml | ((unsigned long long)mh << 32);
-                                for (int r = 1; r < p.kmin && m; ++r) m &= m - 1;
-                                step = m ? (uint32_t)(__ffsll((long long)m) - 1) : 0u;
-                            } else step = v > 65535u ? 65535u : v;
-                        }
-                    }
-                    gm_emit<GmLdsTable>(b, emit, rs, key, step, 4);
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < ZK; ++k) s_r0v[tid + NT * k] = make_uint4(0u, 0u, 0u, 0u);
-            }
-            if (tid < 64) {                          // b = 0: cumulative per-step counts
-                uint32_t run = s_cnt0[tid];
-                s_cnt0[tid] = 0;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(run, off); if (lane >= off) run += t; }
-                const uint32_t total = __shfl(run, 63);
-                const unsigned long long reached = __ballot(run >= (uint32_t)p.kmin);
-                const bool emit = !failed && tid == 0 && total >= (uint32_t)p.kmin;
-                const uint32_t step = p.nw ? (uint32_t)(__ffsll((long long)reached) - 1) : (total > 65535u ? 65535u : total);
-                gm_emit<GmLdsTable>(b, emit, rs, 0u, step, 4);
-            }
-            if (failed && tid == 0) {                // hand this read x strand to the global-table kernel
-                b.rs_overflow[rs] = 1;
-                const uint32_t j = atomicAdd(b.n_retry, 1u);
-                const uint32_t need = 2 * E; uint32_t sz = 1024; while (sz < need && sz < 0x80000000u) sz <<= 1;
-                const unsigned long long off = atomicAdd(&b.counters[GMK_HEAVY_SLOTS], (unsigned long long)sz);
-                b.retry_list[j] = rs;
-                b.retry_off[j] = off;
-                atomicAdd(&b.counters[GMK_OVERFLOW_RS], 1ull);
-            }
-        } else if (R > 1) {
-            gm_lds_barrier();                        // everyone is done with s_pos[cur] before wave 0 overwrites the buffer
-        }
-        if (R > 1) {
-            if (tid == 0) { s_nkeys[cur ^ 1] = 0; s_full[cur ^ 1] = 0; }
-            if (wave == 0) { commit_seeds(cur, rs + 2); fetch_seeds(rs + 3); }
-            gm_lds_barrier();
-        }
-    }
-}
 
 // ---- k_vote_slots: the dense-seed vote kernel with wave-uniform seeds ------------------------------------------------
 // Counters (rocprofv3 --pmc, 1 M reads) show k_vote_block / k_vote_pipe issue ~85 vector and ~95 scalar instructions per
@@ -2115,217 +1854,6 @@ __global__ void __launch_bounds__(64, 6) k_vote_tiny2(GmDevIndex ix, GmDevParams
     }
 }
 
-// ---- vote kernel v4 (dense seeds): seed-uniform load steps, tag filter with plain LDS stores ----------------------
-// The workgroup walks "steps": step s covers NT consecutive SA ranks of ONE seed, so the seed (its step index, SA base and
-// read offset) is wave-uniform and no per-hit table lookups are needed.  All steps' loads are issued back to back.
-// Duplicate detection without LDS atomics: votes for the same position always come from DIFFERENT seeds, so
-//   P1  every hit writes its seed tag (one byte) into slot h(b)                       (plain store, last writer wins)
-//   P2  a hit that reads back a different tag sets the slot's dup flag               (plain load + plain store of 1)
-//   P3  hits whose slot is flagged are compacted into a list (ballot + plain stores)  -> about 1 in 5
-// If two different tags met in a slot at least one of them sees the other's tag, so the flag cannot be missed.  Only the
-// compacted list goes through the exact table (CAS + two non-returning atomics, full waves).
-#define GMC_SLOTS 8192
-template <bool MASK64, int NT>
-__global__ void __launch_bounds__(NT, 4) k_vote_steps(GmDevIndex ix, GmDevParams p, GmDevBatch b, int use_full_sa) {
-    constexpr int SMAX = NT == 64 ? 40 : 24;
-    constexpr int NW = NT / 64;
-    constexpr int LSEG = GMB_LCAP / NW;
-    __shared__ __attribute__((aligned(16))) uint32_t s_tag[GMC_SLOTS / 4];    // 8 KB: tags, then keys[1024] + vals[1024]
-    __shared__ __attribute__((aligned(16))) uint32_t s_dup[GMC_SLOTS / 8];    // 4 KB: dup flags (1 byte per 2 slots), then low step masks
-    __shared__ __attribute__((aligned(16))) uint32_t s_mhi[MASK64 ? GMB_TSIZE : 4];
-    __shared__ uint32_t s_lbp[GMB_LCAP];
-    __shared__ uint8_t s_lt[GMB_LCAP];
-    __shared__ uint32_t s_stk[SMAX], s_stw[SMAX], s_cnt0[64];     // per step: first SA rank | (valid lanes, read offset, seed index) packed
-    __shared__ uint32_t s_S, s_E, s_nkeys, s_full, s_lcnt[NW];
-    const uint32_t rs = blockIdx.x;
-    const int tid = threadIdx.x, lane = gm_lane(), wave = tid >> 6;
-    uint32_t ns = b.n_seeds[rs];
-    if (ns == 0) return;                             // block-uniform
-    if (p.nw && p.fast) ns = 1;
-    const GmSeed* seeds = b.seeds + (size_t)rs * b.max_seeds;
-    const uint64_t coff0 = use_full_sa ? 0 : b.entry_off[rs];
-    if (tid < 64) {                                  // wave 0: seeds -> step table
-        GmSeed mine; mine.k = 0; mine.l = 0; mine.pos = 0;
-        uint32_t cnt = 0;
-        if ((uint32_t)tid < ns) { mine = seeds[tid]; cnt = mine.l - mine.k + 1; }
-        uint32_t nch = (cnt + NT - 1) / NT;
-        uint32_t incl = nch, einc = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t t1 = __shfl_up(incl, off), t2 = __shfl_up(einc, off);
-            if (lane >= off) { incl += t1; einc += t2; }
-        }
-        const uint32_t S = __shfl(incl, 63), E = __shfl(einc, 63);
-        if (S <= SMAX) {
-            uint32_t s0 = incl - nch, e0 = einc - cnt;
-            for (uint32_t q = 0; q < nch; ++q) {
-                uint32_t left = cnt - q * NT;
-                // full SA: absolute rank of the step's first hit; sampled mode: its index in coords[]
-                s_stk[s0 + q] = use_full_sa ? mine.k + q * NT : e0 + q * NT;
-                s_stw[s0 + q] = (left < (uint32_t)NT ? left : (uint32_t)NT) | (mine.pos << 8) | ((uint32_t)tid << 24);   // n <= 128, pos < 2^16, t < 64
-            }
-        }
-        s_cnt0[tid] = 0;
-        if (tid == 0) { s_S = S; s_E = E; s_nkeys = 0; s_full = 0; }
-    }
-    {   // clear tags + dup flags with 16-byte stores
-        uint4 z = make_uint4(0, 0, 0, 0);
-        for (int q = tid; q < GMC_SLOTS / 16; q += NT) reinterpret_cast<uint4*>(s_tag)[q] = z;
-        for (int q = tid; q < GMC_SLOTS / 32; q += NT) reinterpret_cast<uint4*>(s_dup)[q] = z;
-    }
-    __syncthreads();
-    const uint32_t S = s_S, E = s_E;
-    if (S > SMAX) {                                  // too many steps for the register file: the global-table kernel takes it
-        if (tid == 0) {
-            b.rs_overflow[rs] = 1;
-            uint32_t j = atomicAdd(b.n_retry, 1u);
-            uint32_t need = 2 * E; uint32_t sz = 1024; while (sz < need && sz < 0x80000000u) sz <<= 1;
-            unsigned long long off = atomicAdd(&b.counters[GMK_HEAVY_SLOTS], (unsigned long long)sz);
-            b.retry_list[j] = rs; b.retry_off[j] = off;
-            atomicAdd(&b.counters[GMK_OVERFLOW_RS], 1ull);
-        }
-        return;
-    }
-    const bool filter = p.kmin >= 2 && E > 256;
-    uint8_t* tag8 = reinterpret_cast<uint8_t*>(s_tag);
-    uint8_t* dup8 = reinterpret_cast<uint8_t*>(s_dup);
-    // ---- loads: one per step, all in flight together
-    uint32_t bpv[SMAX];
-    unsigned long long vmask = 0;                    // bit s: this lane holds a hit in step s
-    uint32_t stw[SMAX];                              // wave-uniform step words, kept in scalar registers
-#pragma unroll
-    for (int q = 0; q < SMAX; ++q) {
-        bpv[q] = 0; stw[q] = 0;
-        if ((uint32_t)q < S) {
-            stw[q] = __builtin_amdgcn_readfirstlane(s_stw[q]);
-            const uint32_t k0 = __builtin_amdgcn_readfirstlane(s_stk[q]);
-            if ((uint32_t)tid < (stw[q] & 255u)) {
-                vmask |= 1ull << q;
-                bpv[q] = use_full_sa ? ix.full_sa[k0 + (uint32_t)tid] : b.coords[coff0 + k0 + (uint32_t)tid];
-            }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < SMAX; ++q)
-        if ((uint32_t)q < S) { uint32_t sp = (stw[q] >> 8) & 0xFFFFu; bpv[q] = (bpv[q] <= sp) ? 0u : bpv[q] - sp; }     // :267
-    if (p.dbg & 1) {
-        uint32_t acc = 0;
-#pragma unroll
-        for (int q = 0; q < SMAX; ++q) acc ^= bpv[q];
-        if (acc == 0x12345678u) b.rs_overflow[rs] = 3;
-        return;
-    }
-    // ---- P1 / P2: tag filter
-    if (filter && !(p.dbg & 2)) {
-#pragma unroll
-        for (int q = 0; q < SMAX; ++q)
-            if ((uint32_t)q < S && ((vmask >> q) & 1) && bpv[q] != 0) {
-                uint32_t h = (bpv[q] * 0x9E3779B1u) >> (32 - GMB_FBITS);
-                tag8[h] = (uint8_t)((stw[q] >> 24) + 1);
-            }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < SMAX; ++q)
-            if ((uint32_t)q < S && ((vmask >> q) & 1) && bpv[q] != 0) {
-                uint32_t h = (bpv[q] * 0x9E3779B1u) >> (32 - GMB_FBITS);
-                if (tag8[h] != (uint8_t)((stw[q] >> 24) + 1)) dup8[h >> 1] = 1;
-            }
-    }
-    __syncthreads();
-    // ---- P3: compaction of the flagged hits
-    uint32_t wcount = 0;
-#pragma unroll
-    for (int q = 0; q < SMAX; ++q) {
-        if ((uint32_t)q < S) {                       // block-uniform
-            bool pass = false;
-            const uint32_t t = stw[q] >> 24;
-            if ((vmask >> q) & 1) {
-                if (bpv[q] == 0) atomicAdd(&s_cnt0[t], 1u);
-                else if (!filter) pass = true;
-                else { uint32_t h = (bpv[q] * 0x9E3779B1u) >> (32 - GMB_FBITS); pass = dup8[h >> 1] != 0; }
-            }
-            unsigned long long m = __ballot(pass);
-            if (pass) {
-                uint32_t at = wcount + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (at < (uint32_t)LSEG) { s_lbp[wave * LSEG + at] = bpv[q]; s_lt[wave * LSEG + at] = (uint8_t)t; }
-            }
-            wcount += (uint32_t)__popcll(m);
-        }
-    }
-    if (lane == 0) { s_lcnt[wave] = wcount < (uint32_t)LSEG ? wcount : (uint32_t)LSEG; if (wcount > (uint32_t)LSEG) s_full = 1; }
-    __syncthreads();
-    // ---- the filter memory becomes the exact table: keys (EMPTY) | vals (0) | low masks (0)
-    {
-        uint4 e4 = make_uint4(GM_EMPTY, GM_EMPTY, GM_EMPTY, GM_EMPTY), z = make_uint4(0, 0, 0, 0);
-        for (int q = tid; q < GMC_SLOTS / 16; q += NT) reinterpret_cast<uint4*>(s_tag)[q] = q < GMB_TSIZE / 4 ? e4 : z;
-        for (int q = tid; q < GMB_TSIZE / 4; q += NT) reinterpret_cast<uint4*>(s_dup)[q] = z;
-        if (MASK64) for (int q = tid; q < GMB_TSIZE / 4; q += NT) reinterpret_cast<uint4*>(s_mhi)[q] = z;
-    }
-    __syncthreads();
-    GmLdsTable tb; tb.keys = s_tag; tb.vals = s_tag + GMB_TSIZE; tb.mask = GMB_TSIZE - 1; tb.bits = GMB_TBITS;
-    uint32_t* mlo = s_dup;
-    if (!(p.dbg & 4)) {
-        const uint32_t n_l = s_lcnt[wave];
-        uint32_t nfresh = 0; bool full = false;
-        for (uint32_t i0 = 0; i0 < n_l; i0 += 64) {
-            uint32_t i = i0 + (uint32_t)lane;
-            bool fresh = false;
-            if (i < n_l) {
-                uint32_t bp = s_lbp[wave * LSEG + i], t = s_lt[wave * LSEG + i];
-                uint32_t slot = gm_table_insert(tb, bp, &fresh);
-                if (slot == GM_EMPTY) full = true;
-                else {
-                    atomicAdd(&tb.vals[slot], 1u);
-                    if (t < 32) atomicOr(&mlo[slot], 1u << t);
-                    else if (MASK64) atomicOr(&s_mhi[slot], 1u << (t - 32));
-                }
-            }
-            nfresh += (uint32_t)__popcll(__ballot(fresh));
-        }
-        if (lane == 0 && nfresh) atomicAdd(&s_nkeys, nfresh);
-        if (full) s_full = 1;
-    }
-    __syncthreads();
-    if (s_full || s_nkeys > GMB_TLIMIT) {            // hand this read x strand to the global-table kernel
-        if (tid == 0) {
-            b.rs_overflow[rs] = 1;
-            uint32_t j = atomicAdd(b.n_retry, 1u);
-            uint32_t need = 2 * E; uint32_t sz = 1024; while (sz < need && sz < 0x80000000u) sz <<= 1;
-            unsigned long long off = atomicAdd(&b.counters[GMK_HEAVY_SLOTS], (unsigned long long)sz);
-            b.retry_list[j] = rs; b.retry_off[j] = off;
-            atomicAdd(&b.counters[GMK_OVERFLOW_RS], 1ull);
-        }
-        return;
-    }
-    for (uint32_t q0 = (uint32_t)tid * 4; q0 < GMB_TSIZE; q0 += NT * 4) {       // emit: 4 slots per lane per trip
-        const uint4 k4 = *reinterpret_cast<const uint4*>(tb.keys + q0);
-        const uint4 v4 = *reinterpret_cast<const uint4*>(tb.vals + q0);
-        const uint32_t kk[4] = { k4.x, k4.y, k4.z, k4.w }, vv[4] = { v4.x, v4.y, v4.z, v4.w };
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            bool emit = kk[w] != GM_EMPTY && vv[w] >= (uint32_t)p.kmin;
-            uint32_t step = 0;
-            if (emit) {
-                if (p.nw) {
-                    unsigned long long m = (unsigned long long)mlo[q0 + w] | (MASK64 ? ((unsigned long long)s_mhi[q0 + w] << 32) : 0ull);
-                    for (int r = 1; r < p.kmin && m; ++r) m &= m - 1;
-                    step = m ? (uint32_t)(__ffsll((long long)m) - 1) : 0u;
-                } else step = vv[w] > 65535u ? 65535u : vv[w];
-            }
-            gm_emit<GmLdsTable>(b, emit, rs, kk[w], step, 4);
-        }
-    }
-    if (tid < 64) {                                  // b = 0: cumulative per-step counts
-        uint32_t run = s_cnt0[tid];
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(run, off); if (lane >= off) run += t; }
-        uint32_t total = __shfl(run, 63);
-        unsigned long long reached = __ballot(run >= (uint32_t)p.kmin);
-        bool emit = tid == 0 && total >= (uint32_t)p.kmin;
-        uint32_t step = p.nw ? (uint32_t)(__ffsll((long long)reached) - 1) : (total > 65535u ? 65535u : total);
-        gm_emit<GmLdsTable>(b, emit, rs, 0u, step, 4);
-    }
-}
 
 // retry path: one workgroup per overflowed read x strand, exact vote table in HBM (pre-set to EMPTY/0 by the host)
 struct GmGlobalTable {
@@ -2694,8 +2222,15 @@ __global__ void __launch_bounds__(256) k_scatter_hits(GmDevBatch b) {
 // traceback: forward banded DP (same 8-lane anti-diagonal sweep) recording one 2-bit move per cell in LDS,
 // then lane 0 of the group walks the moves back from (L,L).
 // ------------------------------------------------------------------------------------------------
+// Operations are written 2 bits each (0 = M, 1 = I, 2 = D), operation k in word k / 32 at bits 2 (k % 32): 8-byte stores instead of
+// one byte store per operation.  With `emit` the lane that walks the path also adds up the length of the run-length CIGAR text
+// (bin_seq.cpp:578-698; one trailing run of D stripped, SequenceOperations.h:32-42) for the matches that will be printed, and the
+// longest aligned length of the launch (the grid of the coverage deposit).
+__device__ __forceinline__ uint32_t gm_digits(uint32_t v) { return v >= 10000 ? 5u : v >= 1000 ? 4u : v >= 100 ? 3u : v >= 10 ? 2u : 1u; }
+
 __global__ void __launch_bounds__(256) k_traceback(GmDevIndex ix, GmDevParams p, GmDevBatch b, const GmCand* items, uint32_t n,
-                                                   uint8_t* ops, uint32_t ops_stride, uint16_t* ops_len, uint32_t Lp, uint32_t mvw) {
+                                                   unsigned long long* ops, uint32_t ops_words, uint16_t* ops_len, uint32_t Lp, uint32_t mvw,
+                                                   const uint8_t* emit, uint32_t* cig_cnt, uint32_t* max_span) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const uint32_t G = blockDim.x >> 3;
     GmNwLds S = gm_nw_lds(s_raw, Lp, G);
@@ -2720,7 +2255,7 @@ __global__ void __launch_bounds__(256) k_traceback(GmDevIndex ix, GmDevParams p,
         if (have) c = items[ci];
         uint32_t r = c.rs >> 1, strand = c.rs & 1;
         uint32_t L = have ? b.len[r] : 0;
-        bool ok = have && L > 0 && gm_window_ok(ix, coff, c.b, L) && 2 * L <= ops_stride;
+        bool ok = have && L > 0 && gm_window_ok(ix, coff, c.b, L) && 2 * L <= 32 * ops_words;
         if (ok) gm_stage(ix, b, rows, win, r, strand, L, c.b, d);
         if (d < 7) for (uint32_t q = 0; q < mvw; ++q) mv[q] = 0;
         __syncthreads();
@@ -2764,10 +2299,12 @@ __global__ void __launch_bounds__(256) k_traceback(GmDevIndex ix, GmDevParams p,
             }
         }
         __syncthreads();
+        uint32_t my_span = 0;
         if (have && d == 0) {
             uint16_t outlen = 0;
+            uint32_t ctext = 1;                                       // "*" when there is no path (ScoredSeq.h:318-324)
             if (ok) {
-                uint8_t* out = ops + (size_t)ci * ops_stride;
+                unsigned long long* out = ops + (size_t)ci * ops_words;
                 // pass 1: path length
                 int i = (int)L, j = (int)L, nops = 0; bool bad = false;
                 while (i != 0 && j != 0) {
@@ -2779,19 +2316,40 @@ __global__ void __launch_bounds__(256) k_traceback(GmDevIndex ix, GmDevParams p,
                 }
                 if (!bad) {
                     nops += i + j;
-                    int pos = nops - 1;
+                    // pass 2: the operations from the last to the first
+                    int k = nops - 1;
+                    unsigned long long cur = 0;
+                    uint32_t run_code = 3, run_len = 0, text = 0; bool first_run = true;
+                    auto push = [&](uint32_t code) {
+                        cur |= (unsigned long long)code << (2 * (k & 31));
+                        if ((k & 31) == 0) { out[k >> 5] = cur; cur = 0; }
+                        --k;
+                        if (code == run_code) { ++run_len; return; }
+                        if (run_len) { if (!(first_run && run_code == 2)) text += gm_digits(run_len) + 1; first_run = false; }
+                        run_code = code; run_len = 1;
+                    };
                     i = (int)L; j = (int)L;
                     while (i != 0 && j != 0) {
                         int dl = j - i;
                         uint32_t m = (mvg[(size_t)(dl + 3) * mvw + (i >> 4)] >> ((i & 15) << 1)) & 3u;
-                        if (m == 0) { out[pos--] = 'M'; --i; --j; } else if (m == 1) { out[pos--] = 'I'; --i; } else { out[pos--] = 'D'; --j; }
+                        push(m);
+                        if (m == 0) { --i; --j; } else if (m == 1) { --i; } else { --j; }
                     }
-                    while (i > 0) { out[pos--] = 'I'; --i; }
-                    while (j > 0) { out[pos--] = 'D'; --j; }
+                    while (i > 0) { push(1); --i; }
+                    while (j > 0) { push(2); --j; }
+                    if (run_len && !(first_run && run_code == 2)) text += gm_digits(run_len) + 1;
                     outlen = (uint16_t)nops;
+                    if (nops) ctext = text;
                 }
             }
             ops_len[ci] = outlen;
+            my_span = outlen;
+            if (cig_cnt) cig_cnt[ci] = emit[ci] ? (p.nw ? ctext : gm_digits(L) + 1u) + 1u : 0u;       // --no_nw prints "<L>M" (ScoredSeq.h:330-340)
+        }
+        if (max_span) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(my_span, off); my_span = o > my_span ? o : my_span; }
+            if (lane == 0 && my_span) atomicMax(max_span, my_span);
         }
         __syncthreads();
     }
@@ -2905,7 +2463,11 @@ int gmk_seed(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, vo
     if (b.n == 0) return 0;
     // (measured: a grid of exactly the resident workgroups is slower here, 8.7 against 7.6 ms at 10 M reads)
     static const uint32_t seed_grid = [] { const char* e = getenv("GM_SEED_GRID"); return e ? (uint32_t)atoi(e) : 256u * 12u; }();
-    hipLaunchKernelGGL(k_seed, dim3((uint32_t)std::min<uint64_t>(cdiv(2ull * b.n, 256), seed_grid)), dim3(256), (size_t)128 * b.stride, S_(stream), ix, p, b);
+    // reads per tile: 128 (every lane of the 256 holds a read x strand) while the tile fits 64 KB of LDS, fewer whole waves for long reads
+    uint32_t TR = 128;
+    while (TR > 32 && (size_t)TR * b.stride > 64u * 1024u) TR -= 32;
+    if ((size_t)TR * b.stride > 64u * 1024u) return (int)hipErrorInvalidValue;     // stride > 2048: gm_batch_upload refuses it
+    hipLaunchKernelGGL(k_seed, dim3((uint32_t)std::min<uint64_t>(cdiv(b.n, TR), seed_grid)), dim3(256), (size_t)TR * b.stride, S_(stream), ix, p, b, TR);
     return (int)hipGetLastError();
 }
 
@@ -2940,15 +2502,6 @@ int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, in
     if (dense && b.max_seeds <= 64) {
         static const int nt = [] { const char* e = getenv("GM_VOTE_NT"); int v = e ? atoi(e) : 128; return v == 64 || v == 256 ? v : 128; }();
         const bool m64 = b.max_seeds > 32;
-        static const bool steps_form = [] { const char* e = getenv("GM_VOTE_KERNEL"); return e && !strcmp(e, "steps"); }();   // measured slower than the block form
-        if (steps_form) {
-#define GM_LAUNCH_VS(M, N) hipLaunchKernelGGL((k_vote_steps<M, N>), dim3(2 * b.n), dim3(N), 0, S_(stream), ix, p, b, use_full_sa)
-            if (nt == 64) { if (m64) GM_LAUNCH_VS(true, 64); else GM_LAUNCH_VS(false, 64); }
-            else { if (m64) GM_LAUNCH_VS(true, 128); else GM_LAUNCH_VS(false, 128); }
-#undef GM_LAUNCH_VS
-            return (int)hipGetLastError();
-        }
-        static const bool pipe_form = [] { const char* e = getenv("GM_VOTE_KERNEL"); return e && !strcmp(e, "pipe"); }();
         static const char* const kenv = getenv("GM_VOTE_KERNEL");
         const bool slots_form = kenv ? !strcmp(kenv, "slots") : dense <= 2;      // dense == 2: the 64-slot form; 3: rounds of the block form
         if (slots_form) {                           // default: wave-uniform seed slots + the list kernel for what it hands over
@@ -2963,22 +2516,6 @@ int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, in
             else { if (use_full_sa) GM_LAUNCH_VSL(false, true); else GM_LAUNCH_VSL(false, false); }
 #undef GM_LAUNCH_VSL1
 #undef GM_LAUNCH_VSL
-            if (m64) hipLaunchKernelGGL(k_vote_fast_list<true>, dim3(lgrid), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
-            else hipLaunchKernelGGL(k_vote_fast_list<false>, dim3(lgrid), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
-            return (int)hipGetLastError();
-        }
-        if (pipe_form) {                            // k_vote_pipe + the list kernel for what it hands over
-            static const int rr = [] { const char* e = getenv("GM_VOTE_R"); int v = e ? atoi(e) : GMP_R; return v == 1 ? 1 : GMP_R; }();
-            const uint32_t grid = (uint32_t)cdiv(2ull * b.n, (uint64_t)rr);
-            const uint32_t lgrid = (uint32_t)std::min<uint64_t>(cdiv(2ull * b.n, 4), 256 * 20);
-            static const int pnt = [] { const char* e = getenv("GM_VOTE_NT"); int v = e ? atoi(e) : 256; return v == 128 ? 128 : 256; }();
-#define GM_LAUNCH_VP(M, F, RR, N) hipLaunchKernelGGL((k_vote_pipe<M, F, RR, N>), dim3(grid), dim3(N), 0, S_(stream), ix, p, b)
-#define GM_LAUNCH_VP2(M, F) do { if (pnt == 128) { if (rr == 1) GM_LAUNCH_VP(M, F, 1, 128); else GM_LAUNCH_VP(M, F, GMP_R, 128); } \
-                                 else { if (rr == 1) GM_LAUNCH_VP(M, F, 1, 256); else GM_LAUNCH_VP(M, F, GMP_R, 256); } } while (0)
-            if (m64) { if (use_full_sa) GM_LAUNCH_VP2(true, true); else GM_LAUNCH_VP2(true, false); }
-            else { if (use_full_sa) GM_LAUNCH_VP2(false, true); else GM_LAUNCH_VP2(false, false); }
-#undef GM_LAUNCH_VP2
-#undef GM_LAUNCH_VP
             if (m64) hipLaunchKernelGGL(k_vote_fast_list<true>, dim3(lgrid), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
             else hipLaunchKernelGGL(k_vote_fast_list<false>, dim3(lgrid), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
             return (int)hipGetLastError();
@@ -3067,7 +2604,7 @@ int gmk_locate(const GmDevIndex& ix, const uint32_t* ranks, uint32_t n, int use_
 }
 
 int gmk_traceback(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, const GmCand* items, uint32_t n,
-                  uint8_t* ops, uint32_t ops_stride, uint16_t* ops_len, void* stream) {
+                  unsigned long long* ops, uint32_t ops_words, uint16_t* ops_len, const uint8_t* emit, uint32_t* cig_cnt, uint32_t* max_span, void* stream) {
     if (n == 0) return 0;
     uint32_t Lp = lp_of(b.stride);
     uint32_t mvw = (Lp + 1 + 15) / 16 + 1;
@@ -3076,7 +2613,7 @@ int gmk_traceback(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& 
     const uint32_t G = threads / 8;
     size_t lds = GM_NW_HDR + (size_t)G * Lp * 3 + (size_t)G * 7 * mvw * 4;
     uint32_t grid = cdiv(n, G); if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(k_traceback, dim3(grid), dim3(threads), lds, S_(stream), ix, p, b, items, n, ops, ops_stride, ops_len, Lp, mvw);
+    hipLaunchKernelGGL(k_traceback, dim3(grid), dim3(threads), lds, S_(stream), ix, p, b, items, n, ops, ops_words, ops_len, Lp, mvw, emit, cig_cnt, max_span);
     return (int)hipGetLastError();
 }
 

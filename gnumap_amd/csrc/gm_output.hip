@@ -258,63 +258,50 @@ __global__ void __launch_bounds__(64) k_group_write_multi(GmDevBatch b, GmDevGro
 // ------------------------------------------------------------------------------------------------
 // output stage
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_out_items(const GmDevMatch* matches, uint32_t n_m, uint32_t read_base, GmCand* items, uint32_t* pos_match) {
+__global__ void __launch_bounds__(256) k_out_items(const GmDevMatch* matches, uint32_t n_m, uint32_t read_base, const uint8_t* emit, GmCand* items,
+                                                   uint32_t* pos_match, uint32_t* rec_cnt) {
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= n_m) return;
     const GmDevMatch mm = matches[m];
     GmCand c; c.rs = (mm.read - read_base) * 2u + mm.first_strand; c.b = (uint32_t)mm.first_pos; c.step = 0; c.flags = 0; c.pad = 0; c.score = 0;
     items[m] = c;
     for (uint32_t q = mm.pos_begin; q < mm.pos_end; ++q) pos_match[q] = m;
+    rec_cnt[m] = emit[m] ? mm.pos_end - mm.pos_begin : 0u;               // one SAM row per place of a printed sequence (ScoredSeq.h:375-401)
 }
 
-// run-length CIGAR of a traceback (bin_seq.cpp:578-698); "" -> "*", otherwise one trailing run of D is stripped
-// (fix_CIGAR_for_deletions, SequenceOperations.h:32-42).  out == nullptr: length only.
-__device__ __forceinline__ uint32_t go_cigar(const uint8_t* ops, uint32_t n_op, char* out) {
-    if (n_op == 0) { if (out) out[0] = '*'; return 1; }
+// run-length CIGAR text of a traceback (bin_seq.cpp:578-698) from the packed operations (2 bits each: 0 M, 1 I, 2 D); "" -> "*",
+// otherwise one trailing run of D is stripped (fix_CIGAR_for_deletions, SequenceOperations.h:32-42).  Returns the length written.
+__device__ __forceinline__ uint32_t go_op(const unsigned long long* ops, uint32_t k) { return (uint32_t)(ops[k >> 5] >> (2u * (k & 31u))) & 3u; }
+
+__device__ __forceinline__ uint32_t go_digits(uint32_t v) { return v >= 10000 ? 5u : v >= 1000 ? 4u : v >= 100 ? 3u : v >= 10 ? 2u : 1u; }
+
+__device__ __forceinline__ uint32_t go_cigar(const unsigned long long* ops, uint32_t n_op, char* out) {
+    if (n_op == 0) { out[0] = '*'; return 1; }
     uint32_t end = n_op;
-    if (ops[n_op - 1] == 'D') { while (end > 0 && ops[end - 1] == 'D') --end; }
+    if (go_op(ops, n_op - 1) == 2u) { while (end > 0 && go_op(ops, end - 1) == 2u) --end; }
     uint32_t w = 0, i = 0;
+    unsigned long long word = 0;
     while (i < end) {
-        uint32_t j = i;
-        const uint8_t op = ops[i];
-        while (j < end && ops[j] == op) ++j;
-        uint32_t run = j - i, digits = run >= 1000 ? 4u : run >= 100 ? 3u : run >= 10 ? 2u : 1u;
-        if (run >= 10000) digits = 5;
-        if (out) {
-            uint32_t v = run;
-            for (uint32_t d = digits; d > 0; --d) { out[w + d - 1] = (char)('0' + v % 10u); v /= 10u; }
-            out[w + digits] = (char)op;
+        if ((i & 31u) == 0 || i == 0) word = ops[i >> 5];
+        const uint32_t op = (uint32_t)(word >> (2u * (i & 31u))) & 3u;
+        uint32_t j = i + 1;
+        while (j < end) {
+            if ((j & 31u) == 0) word = ops[j >> 5];
+            if (((uint32_t)(word >> (2u * (j & 31u))) & 3u) != op) break;
+            ++j;
         }
+        const uint32_t run = j - i, digits = go_digits(run);
+        uint32_t v = run;
+        for (uint32_t d = digits; d > 0; --d) { out[w + d - 1] = (char)('0' + v % 10u); v /= 10u; }
+        out[w + digits] = op == 0 ? 'M' : op == 1 ? 'I' : 'D';
         w += digits + 1;
         i = j;
     }
     return w;
 }
 
-__device__ __forceinline__ uint32_t go_digits(uint32_t v) { return v >= 10000 ? 5u : v >= 1000 ? 4u : v >= 100 ? 3u : v >= 10 ? 2u : 1u; }
-
-// per match: how many SAM rows and CIGAR bytes it emits; the largest aligned length of the batch (deposit grid)
-__global__ void __launch_bounds__(256) k_out_count(GmDevBatch b, const GmDevMatch* matches, uint32_t n_m, const uint8_t* emit, const uint8_t* ops,
-                                                   uint32_t ops_stride, const uint16_t* ops_len, int nw, uint32_t* rec_cnt, uint32_t* cig_cnt, uint32_t* max_span) {
-    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t span = 0;
-    if (m < n_m) {
-        span = ops_len[m];
-        uint32_t nr = 0, nc = 0;
-        if (emit[m]) {
-            const GmDevMatch mm = matches[m];
-            nr = mm.pos_end - mm.pos_begin;
-            nc = (nw ? go_cigar(ops + (size_t)m * ops_stride, ops_len[m], nullptr) : go_digits(b.len[mm.read - b.read_base]) + 1u) + 1u;
-        }
-        rec_cnt[m] = nr; cig_cnt[m] = nc;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(span, off); span = o > span ? o : span; }
-    if ((threadIdx.x & 63) == 0 && span) atomicMax(max_span, span);
-}
-
 __global__ void __launch_bounds__(256) k_out_write(GmDevIndex ix, GmDevBatch b, const GmDevMatch* matches, const GmDevPos* positions, uint32_t n_m,
-                                                   const uint8_t* emit, const int32_t* mapq, const float* post, const uint8_t* ops, uint32_t ops_stride,
+                                                   const uint8_t* emit, const int32_t* mapq, const float* post, const unsigned long long* ops, uint32_t ops_words,
                                                    const uint16_t* ops_len, int nw, const uint64_t* rec_off, const uint64_t* cig_off,
                                                    GmDevSamRec* recs, char* pool) {
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -323,7 +310,7 @@ __global__ void __launch_bounds__(256) k_out_write(GmDevIndex ix, GmDevBatch b, 
     const uint64_t co = cig_off[m];
     char* cg = pool + co;
     uint32_t cl;
-    if (nw) cl = go_cigar(ops + (size_t)m * ops_stride, ops_len[m], cg);
+    if (nw) cl = go_cigar(ops + (size_t)m * ops_words, ops_len[m], cg);
     else {                                                              // --no_nw: "<L>M" (ScoredSeq.h:330-340)
         uint32_t L = b.len[mm.read - b.read_base], d = go_digits(L), v = L;
         for (uint32_t q = d; q > 0; --q) { cg[q - 1] = (char)('0' + v % 10u); v /= 10u; }
@@ -364,52 +351,65 @@ __device__ __forceinline__ uint32_t go_cons_code(const GmDevBatch& b, const floa
     return c[2] >= c[3] ? 2u : 3u;
 }
 
-__global__ void __launch_bounds__(256) k_out_codes(GmDevBatch b, GmDevParams p, const GmDevMatch* matches, uint32_t n_m, const uint8_t* ops, uint32_t ops_stride,
-                                                   const uint16_t* ops_len, uint8_t* codes) {
+__global__ void __launch_bounds__(256) k_out_codes(GmDevBatch b, GmDevParams p, const GmDevMatch* matches, uint32_t n_m, const unsigned long long* ops,
+                                                   uint32_t ops_words, const uint16_t* ops_len, uint8_t* codes, uint32_t codes_stride) {
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= n_m) return;
     const GmDevMatch mm = matches[m];
     const uint32_t r = mm.read - b.read_base, L = b.len[r];
     const float2* lut = p.lut + ((r < b.illumina_until) ? 256 : 0);
-    const uint8_t* op = ops + (size_t)m * ops_stride;
-    uint8_t* out = codes + (size_t)m * ops_stride;
+    const unsigned long long* op = ops + (size_t)m * ops_words;
+    uint8_t* out = codes + (size_t)m * codes_stride;
     const uint32_t n_op = ops_len[m];
     uint32_t rr = 0;
     for (uint32_t k = 0; k < n_op; ++k) {
         uint8_t cv;
-        if (op[k] == 'M') { cv = rr < L ? (uint8_t)go_cons_code(b, lut, r, L, mm.first_strand, rr) : 6; ++rr; }
-        else if (op[k] == 'I') { cv = rr + 1 < L ? (uint8_t)go_cons_code(b, lut, r, L, mm.first_strand, rr + 1) : 6; ++rr; }
+        const uint32_t o = go_op(op, k);
+        if (o == 0) { cv = rr < L ? (uint8_t)go_cons_code(b, lut, r, L, mm.first_strand, rr) : 6; ++rr; }
+        else if (o == 1) { cv = rr + 1 < L ? (uint8_t)go_cons_code(b, lut, r, L, mm.first_strand, rr + 1) : 6; ++rr; }
         else cv = 5;                                                    // '-'
         out[k] = cv;
     }
 }
 
 // coverage deposit of every kept sequence at every one of its places: amount_genome[(pos+t)/bin] += (float)posterior for t < aligned
-// length (GenomeBwt::AddScore src/GenomeBwt.cpp:483-490); -b / -d additionally reads[base][pos+t] += posterior with the gapped read
-// string reverse-complemented for places on the other strand than the first (BSScoredSeq.cpp:50-84)
+// length (GenomeBwt::AddScore src/GenomeBwt.cpp:483-490).  One thread per (place, bin): the bases of a place that fall into one bin
+// are added up in a register in base order - exactly the fp32 sequence the reference runs through on an untouched bin - and reach
+// HBM as ONE atomic per bin instead of one per base (8 x fewer atomics at the default bin size).  -b / -d (bin size 1) additionally
+// reads[base][pos+t] += posterior with the gapped read string reverse-complemented for places on the other strand than the first
+// (BSScoredSeq.cpp:50-84).
 __global__ void __launch_bounds__(256) k_out_deposit(float* cov, uint64_t bins, uint32_t bin_size, const GmDevMatch* matches, const GmDevPos* positions,
-                                                     const uint32_t* pos_match, uint64_t n_p, const uint16_t* ops_len, const float* post, uint32_t max_span,
-                                                     float* nuc, const uint8_t* codes, uint32_t ops_stride) {
+                                                     const uint32_t* pos_match, uint64_t n_p, const uint16_t* ops_len, const float* post, uint32_t bins_per_place,
+                                                     float* nuc, const uint8_t* codes, uint32_t codes_stride) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t q = gid / max_span; const uint32_t t = (uint32_t)(gid % max_span);
+    const uint64_t q = gid / bins_per_place; const uint32_t bi = (uint32_t)(gid % bins_per_place);
     if (q >= n_p) return;
     const uint32_t m = pos_match[q];
     if (m == 0xFFFFFFFFu) return;
     const uint32_t span = ops_len[m];
-    if (t >= span) return;
     const GmDevPos p = positions[q];
-    const uint64_t bin = (p.pos + t) / bin_size;
-    if (bin >= bins) return;
+    const uint64_t bin = p.pos / bin_size + bi;
+    if (bin >= bins || span == 0) return;
+    // bases t of this place inside the bin: pos + t in [bin * bin_size, (bin + 1) * bin_size)
+    const uint64_t lo = bin * bin_size > p.pos ? bin * bin_size - p.pos : 0;
+    uint64_t hi = (bin + 1) * bin_size - p.pos;
+    if (hi > span) hi = span;
+    if (lo >= hi) return;
     const float w = post[m];
-    atomicAdd(&cov[bin], w);
+    float acc = 0.0f;
+    for (uint64_t t = lo; t < hi; ++t) acc += w;
+    atomicAdd(&cov[bin], acc);
     if (nuc) {
-        const uint8_t* cd = codes + (size_t)m * ops_stride;
-        uint32_t c;
-        // codes: 0..3 acgt, 4 'n', 5 '-', 6 the NUL read past the consensus.  Same strand: '-' falls into the N slot (g_gen_CONVERSION
-        // default), NUL is ignored.  Other strand: reverse_comp first (SequenceOperations.h:56-96: acgt swapped, everything else 'n')
-        if (p.strand == matches[m].first_strand) { c = cd[t]; if (c == 5u) c = 4u; }
-        else { c = cd[span - 1u - t]; c = c < 4u ? 3u - c : 4u; }
-        if (c < 5u) atomicAdd(&nuc[(size_t)c * bins + bin], w);
+        const uint8_t* cd = codes + (size_t)m * codes_stride;
+        const bool same = p.strand == matches[m].first_strand;
+        for (uint32_t t = (uint32_t)lo; t < (uint32_t)hi; ++t) {
+            // codes: 0..3 acgt, 4 'n', 5 '-', 6 the NUL read past the consensus.  Same strand: '-' falls into the N slot (g_gen_CONVERSION
+            // default), NUL is ignored.  Other strand: reverse_comp first (SequenceOperations.h:56-96: acgt swapped, everything else 'n')
+            uint32_t c;
+            if (same) { c = cd[t]; if (c == 5u) c = 4u; }
+            else { c = cd[span - 1u - t]; c = c < 4u ? 3u - c : 4u; }
+            if (c < 5u) atomicAdd(&nuc[(size_t)c * bins + (p.pos + t) / bin_size], w);
+        }
     }
 }
 
@@ -433,42 +433,35 @@ int gmk_group_write(const GmDevBatch& b, const GmDevGroup& g, void* stream) {
     return (int)hipGetLastError();
 }
 
-int gmk_out_items(const GmDevMatch* matches, uint32_t n_m, uint32_t read_base, GmCand* items, uint32_t* pos_match, void* stream) {
+int gmk_out_items(const GmDevMatch* matches, uint32_t n_m, uint32_t read_base, const uint8_t* emit, GmCand* items, uint32_t* pos_match, uint32_t* rec_cnt, void* stream) {
     if (n_m == 0) return 0;
-    hipLaunchKernelGGL(k_out_items, dim3(cdiv(n_m, 256)), dim3(256), 0, S_(stream), matches, n_m, read_base, items, pos_match);
-    return (int)hipGetLastError();
-}
-
-int gmk_out_count(const GmDevBatch& b, const GmDevMatch* matches, uint32_t n_m, const uint8_t* emit, const uint8_t* ops, uint32_t ops_stride,
-                  const uint16_t* ops_len, int nw, uint32_t* rec_cnt, uint32_t* cig_cnt, uint32_t* max_span, void* stream) {
-    if (n_m == 0) return 0;
-    hipLaunchKernelGGL(k_out_count, dim3(cdiv(n_m, 256)), dim3(256), 0, S_(stream), b, matches, n_m, emit, ops, ops_stride, ops_len, nw, rec_cnt, cig_cnt, max_span);
+    hipLaunchKernelGGL(k_out_items, dim3(cdiv(n_m, 256)), dim3(256), 0, S_(stream), matches, n_m, read_base, emit, items, pos_match, rec_cnt);
     return (int)hipGetLastError();
 }
 
 int gmk_out_write(const GmDevIndex& ix, const GmDevBatch& b, const GmDevMatch* matches, const GmDevPos* positions, uint32_t n_m, const uint8_t* emit,
-                  const int32_t* mapq, const float* post, const uint8_t* ops, uint32_t ops_stride, const uint16_t* ops_len, int nw,
+                  const int32_t* mapq, const float* post, const unsigned long long* ops, uint32_t ops_words, const uint16_t* ops_len, int nw,
                   const uint64_t* rec_off, const uint64_t* cig_off, GmDevSamRec* recs, char* pool, void* stream) {
     if (n_m == 0) return 0;
-    hipLaunchKernelGGL(k_out_write, dim3(cdiv(n_m, 256)), dim3(256), 0, S_(stream), ix, b, matches, positions, n_m, emit, mapq, post, ops, ops_stride, ops_len,
+    hipLaunchKernelGGL(k_out_write, dim3(cdiv(n_m, 256)), dim3(256), 0, S_(stream), ix, b, matches, positions, n_m, emit, mapq, post, ops, ops_words, ops_len,
                        nw, rec_off, cig_off, recs, pool);
     return (int)hipGetLastError();
 }
 
-int gmk_out_codes(const GmDevBatch& b, const GmDevParams& p, const GmDevMatch* matches, uint32_t n_m, const uint8_t* ops, uint32_t ops_stride,
-                  const uint16_t* ops_len, uint8_t* codes, void* stream) {
+int gmk_out_codes(const GmDevBatch& b, const GmDevParams& p, const GmDevMatch* matches, uint32_t n_m, const unsigned long long* ops, uint32_t ops_words,
+                  const uint16_t* ops_len, uint8_t* codes, uint32_t codes_stride, void* stream) {
     if (n_m == 0) return 0;
-    hipLaunchKernelGGL(k_out_codes, dim3(cdiv(n_m, 256)), dim3(256), 0, S_(stream), b, p, matches, n_m, ops, ops_stride, ops_len, codes);
+    hipLaunchKernelGGL(k_out_codes, dim3(cdiv(n_m, 256)), dim3(256), 0, S_(stream), b, p, matches, n_m, ops, ops_words, ops_len, codes, codes_stride);
     return (int)hipGetLastError();
 }
 
 int gmk_out_deposit(float* cov, uint64_t bins, uint32_t bin_size, const GmDevMatch* matches, const GmDevPos* positions, const uint32_t* pos_match,
-                    uint64_t n_p, const uint16_t* ops_len, const float* post, uint32_t max_span, float* nuc, const uint8_t* codes, uint32_t ops_stride,
+                    uint64_t n_p, const uint16_t* ops_len, const float* post, uint32_t max_span, float* nuc, const uint8_t* codes, uint32_t codes_stride,
                     void* stream) {
     if (n_p == 0 || max_span == 0) return 0;
-    const uint64_t total = n_p * max_span;
+    const uint32_t bins_per_place = (max_span + bin_size - 1) / bin_size + 1;          // a place may start in the middle of a bin
+    const uint64_t total = n_p * bins_per_place;
     hipLaunchKernelGGL(k_out_deposit, dim3(cdiv(total, 256)), dim3(256), 0, S_(stream), cov, bins, bin_size, matches, positions, pos_match, n_p, ops_len,
-                       post, max_span, nuc, codes, ops_stride);
+                       post, bins_per_place, nuc, codes, codes_stride);
     return (int)hipGetLastError();
 }
-

@@ -157,6 +157,23 @@ static void parse_args(int argc, char** argv, Options& o) {
     if (o.fmt_threads < 1) o.fmt_threads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
 }
 
+// page-locked host array (gm_host_alloc): the library's copies to and from it are DMA at link rate, no staging through the CPU
+template <class T> struct PinVec {
+    T* p = nullptr; size_t cap = 0;
+    PinVec() = default;
+    PinVec(const PinVec&) = delete; PinVec& operator=(const PinVec&) = delete;
+    ~PinVec() { if (p) gm_host_free(p); }
+    void ensure(size_t n) {                       // contents are NOT kept
+        if (n <= cap) return;
+        if (p) gm_host_free(p);
+        cap = n + n / 8 + 64;
+        p = (T*)gm_host_alloc(cap * sizeof(T));
+        if (!p) { fprintf(stderr, "ERROR: out of page-locked host memory (%zu bytes)\n", cap * sizeof(T)); exit(1); }
+    }
+    T* data() { return p; } const T* data() const { return p; } size_t size() const { return cap; }
+    T& operator[](size_t i) { return p[i]; } const T& operator[](size_t i) const { return p[i]; }
+};
+
 // ---- blocks ------------------------------------------------------------------------------------------------------
 struct Block {
     uint64_t index = 0;
@@ -165,10 +182,10 @@ struct Block {
     std::vector<const char*> name, seq, qual;
     std::vector<uint32_t> name_len, qual_len;
     std::vector<uint16_t> len;
-    // packed for gm_reads
-    std::vector<uint8_t> bases, qbuf;
-    // results of the two batch calls
-    std::vector<gm_sam_rec> recs; std::vector<char> pool; uint64_t n_recs = 0;
+    // packed for gm_reads (page-locked)
+    PinVec<uint8_t> bases, qbuf; PinVec<uint16_t> plen;
+    // results of the two batch calls (page-locked)
+    PinVec<gm_sam_rec> recs; PinVec<char> pool; uint64_t n_recs = 0;
     int gpu = 0;
     int illumina = 0;                       // --illumina still in force when this block starts (the fallback is sticky, SeqReader.cpp:1171-1180)
     std::vector<std::string> text;          // SAM text, one piece per formatter thread
@@ -261,7 +278,8 @@ template <class F> static void run_slices(uint32_t n, int threads, uint32_t grai
 
 static void pack_block(Block& b, int threads) {          // rows of `stride` bytes, zero padded, as gm_reads wants them
     const size_t bytes = (size_t)b.n * b.stride;
-    if (b.bases.size() < bytes) { b.bases.resize(bytes); b.qbuf.resize(bytes); }
+    b.bases.ensure(bytes); b.qbuf.ensure(bytes); b.plen.ensure(b.n);
+    memcpy(b.plen.data(), b.len.data(), (size_t)b.n * 2);
     run_slices(b.n, threads, 8192, [&](int, uint32_t lo, uint32_t hi) {
         for (uint32_t i = lo; i < hi; ++i) {
             uint8_t* pb = &b.bases[(size_t)i * b.stride]; uint8_t* pq = &b.qbuf[(size_t)i * b.stride];
@@ -350,8 +368,9 @@ struct Worker {
     int gpu = 0;
     gm_index* ix = nullptr;
     gm_batch* batch = nullptr;
-    std::vector<int8_t> status; std::vector<float> self_score; std::vector<double> top, den; std::vector<uint64_t> mbegin;
-    std::vector<gm_match> matches; std::vector<gm_pos> positions;
+    void* stream = nullptr;                 // this worker's own HIP stream: its device work overlaps the other workers'
+    PinVec<int8_t> status; PinVec<float> self_score; PinVec<double> top, den; PinVec<uint64_t> mbegin;
+    PinVec<gm_match> matches; PinVec<gm_pos> positions;
     uint64_t n_reads = 0, n_matched = 0, n_records = 0;
     double t_pack = 0, t_map = 0, t_out = 0;
 };
@@ -363,10 +382,9 @@ static int process_block(Worker& w, const Options& o, Block& b) {
     gm_params bp = o.p; bp.illumina = b.illumina;
     auto c0 = std::chrono::steady_clock::now();
     pack_block(b, 4);
-    gm_reads reads; reads.n = n; reads.stride = b.stride; reads.bases = b.bases.data(); reads.quals = b.qbuf.data(); reads.len = b.len.data();
-    w.status.resize(n); w.self_score.resize(n); w.top.resize(n); w.den.resize(n); w.mbegin.resize(n + 1);
-    if (w.matches.size() < 2 * (size_t)n + 64) w.matches.resize(2 * (size_t)n + 64);
-    if (w.positions.size() < 2 * (size_t)n + 64) w.positions.resize(2 * (size_t)n + 64);
+    gm_reads reads; reads.n = n; reads.stride = b.stride; reads.bases = b.bases.data(); reads.quals = b.qbuf.data(); reads.len = b.plen.data();
+    w.status.ensure(n); w.self_score.ensure(n); w.top.ensure(n); w.den.ensure(n); w.mbegin.ensure((size_t)n + 1);
+    w.matches.ensure(2 * (size_t)n + 64); w.positions.ensure(2 * (size_t)n + 64);
     gm_hits hits;
     auto c1 = std::chrono::steady_clock::now();
     for (;;) {
@@ -374,19 +392,19 @@ static int process_block(Worker& w, const Options& o, Block& b) {
         hits.denominator = w.den.data(); hits.match_begin = w.mbegin.data();
         hits.matches = w.matches.data(); hits.matches_cap = w.matches.size();
         hits.positions = w.positions.data(); hits.positions_cap = w.positions.size();
-        int rc = gm_map_batch(w.ix, &bp, w.batch, &reads, &hits, nullptr);
-        if (rc == GM_E_CAPACITY) { w.matches.resize(hits.matches_cap + 64); w.positions.resize(hits.positions_cap + 64); continue; }
+        int rc = gm_map_batch(w.ix, &bp, w.batch, &reads, &hits, w.stream);
+        if (rc == GM_E_CAPACITY) { w.matches.ensure(hits.matches_cap + 64); w.positions.ensure(hits.positions_cap + 64); continue; }
         if (rc != GM_OK) { fprintf(stderr, "ERROR: gm_map_batch: %s\n", gm_last_error()); return rc; }
         break;
     }
     auto c2 = std::chrono::steady_clock::now();
-    if (b.recs.size() < (size_t)n + (size_t)n / 4 + 64) b.recs.resize((size_t)n + (size_t)n / 4 + 64);
-    if (b.pool.size() < 8 * (size_t)n + 1024) b.pool.resize(8 * (size_t)n + 1024);
+    b.recs.ensure((size_t)n + (size_t)n / 4 + 64);
+    b.pool.ensure(8 * (size_t)n + 1024);
     gm_sam_out so;
     for (;;) {
         so.recs = b.recs.data(); so.recs_cap = b.recs.size(); so.cigar_pool = b.pool.data(); so.cigar_cap = b.pool.size();
-        int rc = gm_output_batch(w.ix, &bp, w.batch, &reads, &hits, &so, nullptr);
-        if (rc == GM_E_CAPACITY) { b.recs.resize(so.recs_cap + 64); b.pool.resize(so.cigar_cap + 64); continue; }
+        int rc = gm_output_batch(w.ix, &bp, w.batch, &reads, &hits, &so, w.stream);
+        if (rc == GM_E_CAPACITY) { b.recs.ensure(so.recs_cap + 64); b.pool.ensure(so.cigar_cap + 64); continue; }
         if (rc != GM_OK) { fprintf(stderr, "ERROR: gm_output_batch: %s\n", gm_last_error()); return rc; }
         break;
     }
@@ -417,7 +435,7 @@ int main(int argc, char** argv) {
         for (int k = 0; k < o.workers; ++k) {
             Worker& w = workers[(size_t)g * (size_t)o.workers + (size_t)k];
             w.gpu = g; w.ix = gpu_ix[(size_t)g];
-            if (gm_batch_create(w.ix, o.batch, 4096, &w.batch) != GM_OK) { fprintf(stderr, "ERROR: %s\n", gm_last_error()); return 1; }
+            if (gm_batch_create(w.ix, o.batch, 2048, &w.batch) != GM_OK || gm_stream_create(w.ix, &w.stream) != GM_OK) { fprintf(stderr, "ERROR: %s\n", gm_last_error()); return 1; }
         }
     }
     gm_index_info info;
@@ -556,6 +574,7 @@ int main(int argc, char** argv) {
     for (auto& w : workers) {
         n_reads += w.n_reads; n_matched += w.n_matched; n_records += w.n_records; t_pack += w.t_pack; t_map += w.t_map; t_out += w.t_out;
         gm_batch_destroy(w.batch);
+        gm_stream_destroy(w.ix, w.stream);
     }
     const double t_cov = secs_since(t_cov0);
     for (auto ix : gpu_ix) gm_index_close(ix);

@@ -19,10 +19,12 @@ def init(backend, device=None):
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        import datetime
+        tmo = datetime.timedelta(minutes=60)          # a rank may spend minutes loading a human-size index replica
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
     return rank, world
 
 
@@ -63,19 +65,12 @@ def sum_over_ranks(value, device="cpu"):
 
 
 def allreduce_coverage(track):
-    """in-place SUM all-reduce of a float32 coverage track (a CPU tensor under gloo, the HBM-resident track under nccl).
-    A device track is a view of memory the library allocated, not the torch allocator: the collective runs on a torch-owned
-    staging tensor (two device-to-device copies of the track, outside the timed region) so that ProcessGroupNCCL only ever
-    sees storage it can record streams on."""
-    assert track.dtype == torch.float32
+    """IN-PLACE SUM all-reduce of a float32 coverage track: a CPU tensor under gloo, under nccl (= RCCL over xGMI) the
+    HBM-resident track of the library itself (DeviceTrack view of gm_coverage_device_ptr(); no staging copy: the
+    collective reads and writes the library's buffer)."""
+    assert track.dtype == torch.float32 and track.is_contiguous()
     if dist.is_available() and dist.is_initialized():
-        if track.is_cuda:
-            stage = torch.empty_like(track)
-            stage.copy_(track)
-            dist.all_reduce(stage, op=dist.ReduceOp.SUM)
-            track.copy_(stage)
-        else:
-            dist.all_reduce(track, op=dist.ReduceOp.SUM)
+        dist.all_reduce(track, op=dist.ReduceOp.SUM)
     return track
 
 

@@ -177,7 +177,7 @@ void gm_params_default(gm_params*);
 int gm_params_finalize(gm_params*);
 
 /* ---- batches: device-resident reads + workspace + raw results ---- */
-int gm_batch_create(gm_index*, uint32_t max_reads, uint32_t max_len, gm_batch** out);
+int gm_batch_create(gm_index*, uint32_t max_reads /* <= 16 000 000 */, uint32_t max_len /* <= 2048 */, gm_batch** out);
 void gm_batch_destroy(gm_batch*);
 int gm_batch_upload(gm_batch*, const gm_params*, const gm_reads*, void* hip_stream);       /* host -> HBM */
 /* the hot path proper, everything resident in HBM: prep -> seed -> locate+vote -> NW -> hit compaction.
@@ -203,6 +203,8 @@ int gm_batch_raw_hits(gm_batch*, gm_raw_hit* out, uint64_t cap, uint64_t* n_out,
  *                  is still resident in HBM); `hits` may have been edited by the caller (it is uploaded again).
  * Both are synchronous on hip_stream and use only the calling thread: a driver overlaps blocks by calling them from two or more
  * threads with one gm_batch and one stream each.  Host buffers from gm_host_alloc are page-locked (DMA at link rate). */
+int gm_stream_create(gm_index*, void** hip_stream_out);          /* a non-blocking HIP stream on the index's device (one per driver thread) */
+void gm_stream_destroy(gm_index*, void* hip_stream);
 void* gm_host_alloc(size_t bytes);                               /* page-locked host memory for gm_reads / gm_hits / gm_sam_out buffers */
 void gm_host_free(void*);
 int gm_map_batch(gm_index*, const gm_params*, gm_batch*, const gm_reads*, gm_hits* out, void* hip_stream);

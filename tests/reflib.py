@@ -160,6 +160,15 @@ class GmoResult(C.Structure):
                 ("ctr", GmoCounters)]
 
 
+class GmoSam(C.Structure):
+    _fields_ = [("pos", u64), ("strand", C.c_int), ("contig", C.c_int), ("chr_pos", u64), ("mapq", C.c_int), ("cigar", C.c_char * 1024),
+                ("a_score", C.c_float), ("post_prob", C.c_float), ("sim_matches", C.c_int)]
+
+
+class GmoDeposit(C.Structure):
+    _fields_ = [("pos", u64), ("span", C.c_uint32), ("w", C.c_float), ("codes", C.POINTER(C.c_uint8))]
+
+
 class GmoRunStats(C.Structure):
     _fields_ = [("n_reads", u64), ("n_matched", u64), ("n_records", u64), ("map_seconds", C.c_double), ("ctr", GmoCounters)]
 
@@ -186,6 +195,10 @@ class OracleLib:
         L.gmo_revcomp_str.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
         L.gmo_map_read.argtypes = [C.POINTER(GmoIndex), C.POINTER(GmoParams), fptr, C.c_char_p, C.c_int, C.POINTER(GmoResult)]
         L.gmo_result_free.argtypes = [C.POINTER(GmoResult)]
+        L.gmo_read_output.argtypes = [C.POINTER(GmoIndex), C.POINTER(GmoParams), C.POINTER(GmoResult), fptr, C.c_char_p, C.c_int,
+                                      C.POINTER(C.POINTER(GmoSam)), C.POINTER(C.POINTER(GmoDeposit)), C.POINTER(C.c_int), C.c_void_p]
+        self.libc = C.CDLL(None)
+        self.libc.free.argtypes = [C.c_void_p]
         L.gmo_run.argtypes = [C.POINTER(GmoIndex), C.POINTER(GmoParams), C.c_char_p, C.c_char_p, C.c_int, u64, C.c_char_p, C.POINTER(GmoRunStats)]
 
     def params(self, **kw):
@@ -240,6 +253,33 @@ class OracleLib:
                    ctr={n: getattr(r.ctr, n) for n, _ in GmoCounters._fields_})
         self.lib.gmo_result_free(C.byref(r))
         return out
+
+    def read_output(self, ix, p, P, cons: bytes):
+        """gmo_map_read + gmo_read_output of one read: (status, SAM records, coverage deposits [(pos, span, w, codes|None)])"""
+        P = np.ascontiguousarray(P, np.float32)
+        r = GmoResult()
+        self.lib.gmo_map_read(ix, C.byref(p), P, cons, len(cons), C.byref(r))
+        recs, deps = [], []
+        if r.status == 0:
+            pr = C.POINTER(GmoSam)(); pd = C.POINTER(GmoDeposit)(); nd = C.c_int()
+            n = self.lib.gmo_read_output(ix, C.byref(p), C.byref(r), P, cons, len(cons), C.byref(pr), C.byref(pd), C.byref(nd), None)
+            for k in range(n):
+                q = pr[k]
+                recs.append(dict(pos=q.pos, strand=q.strand, contig=q.contig, chr_pos=q.chr_pos, mapq=q.mapq, cigar=bytes(q.cigar),
+                                 a_score=q.a_score, post_prob=q.post_prob, sim_matches=q.sim_matches))
+            for k in range(nd.value):
+                d = pd[k]
+                codes = bytes(d.codes[t] for t in range(d.span)) if d.codes else None
+                deps.append((d.pos, d.span, d.w, codes))
+                if d.codes:
+                    self.libc.free(d.codes)
+            if n:
+                self.libc.free(pr)
+            if nd.value:
+                self.libc.free(pd)
+        st = r.status
+        self.lib.gmo_result_free(C.byref(r))
+        return st, recs, deps
 
     def run(self, ix, p, fastq, out_prefix, threads=1, max_reads=0, cmdline=""):
         st = GmoRunStats()

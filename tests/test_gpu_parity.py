@@ -219,7 +219,8 @@ def _long_reads(syn_fa, L, n, seed):
     return reads
 
 
-@pytest.mark.parametrize("L,kw", [(250, {}), (330, dict(mer=12, jump=4)), (600, {}), (1000, dict(mer=16, jump=8))])
+@pytest.mark.parametrize("L,kw", [(250, {}), (330, dict(mer=12, jump=4)), (600, {}), (1000, dict(mer=16, jump=8)),
+                                  (1500, dict(mer=16, jump=8)), (2048, dict(mer=20, jump=10))])      # > 1280 bases: k_seed tiles of fewer reads (LDS budget)
 def test_long_reads_all_vote_kernels(L, kw, ix_full, oracle, oix, syn_fa):
     """L=250: 64-bit step masks; L=600 at j=5: more than 64 seeds -> the ordered vote kernel"""
     reads = _long_reads(syn_fa, L, 24, L)
@@ -352,6 +353,28 @@ def test_coverage_device_view_for_rccl(ix_full):
     ix_full.coverage_reset(8)
 
 
+def test_rccl_allreduce_path_on_one_rank(ix_full, monkeypatch):
+    """gm_coverage_allreduce (what `gnumap --gpus N` calls): with GM_RCCL_FORCE=1 a single GPU goes through ncclCommInitAll /
+    ncclAllReduce (in place, own stream) / async-error check / destroy; a one-rank sum must leave the track as it was"""
+    monkeypatch.setenv("GM_RCCL_FORCE", "1")
+    ix_full.coverage_reset(8)
+    ix_full.coverage_add([800, 5000, 5004], [64, 16, 8], [1.5, 2.0, 0.25])
+    before = ix_full.coverage_download()
+    assert before.sum() == 64 * 1.5 + 16 * 2.0 + 8 * 0.25 and before[100] == 12.0
+    arr = (C.c_void_p * 1)(ix_full.h)
+    assert g.lib().gm_coverage_allreduce(arr, 1) == 0, g.lib().gm_last_error()
+    np.testing.assert_array_equal(ix_full.coverage_download(), before)
+    monkeypatch.delenv("GM_RCCL_FORCE")
+    assert g.lib().gm_coverage_allreduce(arr, 1) == 0
+    ix_full.coverage_reset(8)
+
+
+def test_batch_limits_are_refused_loudly(ix_full):
+    for reads, ln in ((16_000_001, 100), (1000, 2049)):
+        with pytest.raises(g.GnumapError):
+            g.Batch(ix_full, reads, ln)
+
+
 def test_pipelined_sub_batches_equal_single_pass(ix_full, syn_reads, packed, monkeypatch):
     """GM_PIPELINE=<n>: sub-batches over three streams must give the same raw hits as the single pass"""
     B, Q, Ln = packed
@@ -378,51 +401,47 @@ def test_pipelined_sub_batches_equal_single_pass(ix_full, syn_reads, packed, mon
     assert len(first) == len(last) and np.array_equal(first["pos"], last["pos"])
 
 
-_VARIANT_BASELINE = {}
+_VARIANT_ORACLE = {}
 
 
 @pytest.mark.parametrize("env", [dict(GM_VOTE="block"),                                             # dense seeds: k_vote_slots (the default dense kernel)
                                  dict(GM_VOTE="big"), dict(GM_VOTE="rounds"),                      # its 64-slot form; rounds of the block form
-                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="10"), dict(GM_VOTE="block", GM_VOTE_SLOTS="40"),   # 16-slot form (+ list kernel), 40-slot form
+                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="10"), dict(GM_VOTE="block", GM_VOTE_SLOTS="20"), dict(GM_VOTE="block", GM_VOTE_SLOTS="40"),   # 16- / 24- / 40-slot forms (+ list kernel)
                                  dict(GM_VOTE="block", GM_VOTE_SLOTS="0"), dict(GM_VOTE="block", GM_VOTE_SLOTS="0", GM_TEST_SAMPLED="1"),   # k_vote_tiny (+ list kernel, retry kernel)
                                  dict(GM_VOTE="block", GM_VOTE_KERNEL="block"), dict(GM_VOTE="block", GM_VOTE_KERNEL="block", GM_VOTE_NT="64"),
                                  dict(GM_VOTE="block", GM_VOTE_KERNEL="block", GM_VOTE_NT="256"), dict(GM_VOTE="block", GM_VOTE_KERNEL="block", GM_VOTE_TB="10"),
-                                 dict(GM_VOTE="block", GM_VOTE_KERNEL="steps"), dict(GM_VOTE="block", GM_VOTE_KERNEL="pipe"),
                                  dict(GM_VOTE="block", GM_VOTE_KERNEL="block", GM_RETRY_BUDGET="16384"),     # retry tables handed out in several launches
-                                 dict(GM_VOTE="block", GM_VOTE_KERNEL="pipe", GM_VOTE_NT="128", GM_VOTE_R="1"),
                                  dict(GM_VOTE="block", GM_TEST_SAMPLED="1"),                         # k_vote_slots on LF-walk coordinates (no full SA)
                                  dict(GM_VOTE="wave"), dict(GM_VOTE="wave", GM_VOTE_SPARSE="0"),
                                  dict(GM_NW="wave"), dict(GM_KMER_TABLE="0"), dict(GM_KMER_TABLE="6"), dict(GM_KMER_COMPACT="0"),
                                  dict(GM_KMER_TABLE="13"), dict(GM_KMER_TABLE="14"),           # tables extended one character at a time (m20_j2, k1)
                                  dict(GM_KMER_TABLE="15"), dict(GM_KMER_TABLE="16"),           # 2^30 / 2^32 codes (64-bit code arithmetic), 43 GB of HBM at 16
-                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="-1"), dict(GM_VOTE="block", GM_VOTE_SLOTS="-1", GM_TEST_SAMPLED="1")])   # k_vote_tiny2
+                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="-1"), dict(GM_VOTE="block", GM_VOTE_SLOTS="-1", GM_TEST_SAMPLED="1")],   # k_vote_tiny2
+                         ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()))
 @pytest.mark.parametrize("cfg", ["default", "no_nw", "k3", "h30", "m6_j2", "m20_j2", "k1"])
-def test_every_kernel_variant_matches_oracle(env, cfg, syn_fa, oracle, oix, syn_reads, packed):
-    """the dispatch heuristics pick kernels by seed density; force each variant on the same inputs (fresh process state is
-    not needed: the switches are read per launch or cached per variant name)"""
-    import subprocess, sys, json
+def test_every_kernel_variant_matches_oracle(env, cfg, syn_fa, oracle, oix, syn_reads, packed, tmp_path):
+    """the dispatch heuristics pick kernels by seed density; force each variant on the same inputs and compare the result of
+    gm_map_batch (status, self / top score, denominator, matches in key order, position sets) with the ORACLE, read by read"""
+    import subprocess, sys
     # kernel-variant switches are cached in static locals on first use, so each combination runs in its own process
+    out = str(tmp_path / "res.npz")
     code = f"""
-import sys, json, numpy as np
+import sys, os, numpy as np
 sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
 import gnumap_amd as g
 from conftest import read_fastq
 reads = read_fastq({os.path.join(ROOT, 'tests', 'golden', 'syn.fq')!r})
 B, Q, Ln = g.pack_reads([r[1] for r in reads], [r[2] for r in reads])
-import os
 ix = g.Index({syn_fa!r}, flags=0 if os.environ.get('GM_TEST_SAMPLED') else g.GM_INDEX_FULL_SA)
 p = g.Params(**{CONFIGS[cfg]!r})
 b = g.Batch(ix, len(reads), B.shape[1])
-b.upload(p, B, Q, Ln); b.map_device(p)
-hits, status, self_score, top = b.raw_hits()
-print(json.dumps(dict(hits=hits.tobytes().hex(), status=status.tobytes().hex(), top=top.tobytes().hex())))
+res = b.map(p, B, Q, Ln)
+np.savez({out!r}, **{{k: v for k, v in res.items() if not k.startswith('_')}})
 """
-    def run(e):
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **e), timeout=300)
-        assert r.returncode == 0, r.stderr[-1500:]
-        return json.loads(r.stdout.strip().splitlines()[-1])
-    if cfg not in _VARIANT_BASELINE:                 # the default dispatch on this configuration: computed once per configuration
-        _VARIANT_BASELINE[cfg] = run({})
-    outs = [_VARIANT_BASELINE[cfg], run(env)]
-    assert outs[0] == outs[1]
-    assert len(outs[0]["hits"]) > 16 * 2 * 100
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    res = dict(np.load(out))
+    if cfg not in _VARIANT_ORACLE:
+        _VARIANT_ORACLE[cfg] = _oracle_results(oracle, oix, oracle.params(**CONFIGS[cfg]), syn_reads)
+    _compare(res, _VARIANT_ORACLE[cfg], syn_reads)
+    assert len(res["matches"]) > 400

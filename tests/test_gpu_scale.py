@@ -1,7 +1,14 @@
-"""Maximum sizes: a reference with more than 2^31 positions (2.3 Gbp synthetic, 7 contigs).  The index is built on the box
-(suffix-array stage on the device), loaded into HBM, and reads drawn mostly from beyond coordinate 2^31 are compared read by read
-with the oracle; exact reads must recover their origin.  tools/scale_check.py is the same check as a command-line tool."""
+"""The BASELINE configurations at (or near) their own sizes, each compared read by read with the oracle on a random sample, and the
+maximum-size case: a reference with more than 2^31 positions.  The index is built on the box (suffix-array stage on the device) and
+loaded into HBM; tools/scale_check.py is the same check as a command-line tool.
+
+    configs[1]  100 Mbp, -m 10 -j 5            -> k_vote_slots<40> (the bench-dominant dense form) against the oracle directly
+    configs[2]  156 Mbp, -m 10 -j 5 -h 150     -> the 64-slot (BIG) form
+    configs[3]  2.3 Gbp, 150-bp reads, -b      -> k_vote_tiny2 with bisulfite scoring, .gmp arrays (per-nucleotide track) checked
+    configs[4]  2.3 Gbp, --no_nw               -> the hit-count-only path
+"""
 import os
+import shutil
 import sys
 
 import pytest
@@ -10,13 +17,59 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 
 
-def test_reference_beyond_2_31_positions(tmp_path):
+@pytest.fixture(scope="module")
+def workdir(tmp_path_factory):
+    d = tmp_path_factory.mktemp("scale")
+    yield str(d)
+    shutil.rmtree(d, ignore_errors=True)
+
+
+def _ok(out, sample):
+    assert out["oracle_sample"] == sample and out["oracle_mismatches"] == 0, out
+    assert out["exact_reads_checked"] > 500 and out["exact_reads_origin_found"] == out["exact_reads_checked"], out
+
+
+def _ok_output(out):
+    assert out["output_records"] > 0.5 * out["output_reads"] and out["output_record_mismatch"] == 0, out
+    assert out["coverage_bins_checked"] > 100 and out["coverage_bin_mismatches"] == 0 and out["track_totals_ok"], out
+
+
+def test_configs1_100mbp_m10_dense_vote_form(workdir):
+    import scale_check
+    out = scale_check.main(["--mbp", "100", "--contigs", "6", "--mer", "10", "--reads", "100000", "--sample", "200", "--steps", "1",
+                            "--check-output", "64", "--workdir", workdir])
+    _ok(out, 200); _ok_output(out)
+    assert 1500 < out["sa_hits_per_read"] < 5000            # ~1700 hits per read x strand: 36 slots -> the 40-slot form
+
+
+def test_configs2_156mbp_m10_h150_big_vote_form(workdir):
+    import scale_check
+    out = scale_check.main(["--mbp", "156", "--contigs", "1", "--mer", "10", "--max-kmer-hits", "150", "--reads", "100000", "--sample", "120",
+                            "--steps", "1", "--check-output", "48", "--workdir", workdir])
+    _ok(out, 120); _ok_output(out)
+
+
+def test_reference_beyond_2_31_positions(workdir):
     import scale_check
     out = scale_check.main(["--mbp", "2300", "--contigs", "7", "--mer", "14", "--reads", "200000", "--sample", "48", "--steps", "1",
-                            "--workdir", str(tmp_path)])
+                            "--check-output", "32", "--keep", "--workdir", workdir])
     assert out["l_pac"] == 2_300_000_000 and out["l_pac"] > 2 ** 31
-    assert out["oracle_sample"] == 48 and out["oracle_mismatches"] == 0
+    _ok(out, 48); _ok_output(out)
     assert out["oracle_tail_reads"] >= 10                     # sampled reads that lie beyond 2^31
-    assert out["exact_reads_checked"] > 1000 and out["exact_reads_origin_found"] == out["exact_reads_checked"]
     assert out["max_reported_pos"] > 2 ** 31
     assert out["vote_retries"] == 0
+
+
+def test_configs4_no_nw_at_scale(workdir):
+    import scale_check
+    out = scale_check.main(["--mbp", "2300", "--contigs", "7", "--mer", "14", "--no-nw", "--reads", "200000", "--sample", "48", "--steps", "1",
+                            "--check-output", "32", "--keep", "--workdir", workdir])
+    _ok(out, 48); _ok_output(out)
+
+
+def test_configs3_bisulfite_150bp_tiny2_form(workdir):
+    import scale_check
+    out = scale_check.main(["--mbp", "2300", "--contigs", "7", "--mer", "14", "--mode", "1", "--read-len", "150", "--reads", "200000", "--sample", "48",
+                            "--steps", "1", "--check-output", "32", "--keep", "--workdir", workdir])
+    _ok(out, 48); _ok_output(out)
+    assert out["nuc_bins_checked"] > 1000 and out["nuc_bin_mismatches"] == 0, out

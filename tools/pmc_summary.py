@@ -29,8 +29,23 @@ for k, v in sorted(agg.items()):
     if best is None or hbm > best[1]:
         best = (k, hbm)
 open(out_txt, "w").write(f"# rocprofv3 --pmc passes, {reads} reads per launch, workload {key}\n" + "\n".join(lines) + "\n")
-kernel = best[0]
-name = "k_vote" if kernel.startswith("k_vote") else kernel
-json.dump({"workload_key": key, "kernel": name, "kernel_symbol": kernel, "reads_per_launch": reads,
-           "hbm_bytes_per_launch": best[1], "hbm_bytes_per_read": best[1] / reads}, open(out_json, "w"), indent=1)
+def bench_name(k):                  # the names bench.py reports kernel times under (gm_kernel_name)
+    for pre, nm in (("k_vote_retry", "k_vote_retry"), ("k_vote", "k_vote"), ("k_nw", "k_nw"), ("k_scan", "k_compact(scan+scatter)"),
+                    ("k_scatter", "k_compact(scan+scatter)")):
+        if k.startswith(pre):
+            return nm
+    return k.split("<")[0]
+
+
+per = collections.defaultdict(float)
+sym = {}
+for k, v in agg.items():
+    m = {c: sum(x) / len(x) for c, x in v.items()}
+    hbm = 2 * m.get("FETCH_SIZE", 0.0) * 1024 + m.get("WRITE_SIZE", 0.0) * 1024
+    per[bench_name(k)] += hbm
+    sym.setdefault(bench_name(k), []).append(k)
+json.dump({"workload_key": key, "reads_per_launch": reads,
+           "note": "HBM bytes per launch = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 (MI355X_MICROARCH.md: gfx950 tallies 128-byte reads as 64), separate --pmc passes",
+           "kernels": {k: {"hbm_bytes_per_launch": v, "hbm_bytes_per_read": v / reads, "symbols": sym[k]} for k, v in sorted(per.items())}},
+          open(out_json, "w"), indent=1)
 print(open(out_txt).read())

@@ -76,6 +76,58 @@ def write_genome(fa, G, n_contigs, seed, repeats=False):
     return offs
 
 
+def check_output(g, ix, p, orc, oix, op, B, Q, Ln, L, pick):
+    """gm_map_batch + gm_output_batch on the picked reads: SAM records, coverage bins and (-b / -d) per-nucleotide bins against the
+    oracle's gmo_read_output; the device tracks are read through zero-copy views at the touched bins only"""
+    import torch
+    from gnumap_amd import dist as gd
+    pick = np.asarray(sorted(set(int(x) for x in pick)))
+    Bs, Qs, Ls = np.ascontiguousarray(B[pick]), np.ascontiguousarray(Q[pick]), np.ascontiguousarray(Ln[pick])
+    bs = 1 if p.mode else p.bin_size
+    ix.coverage_reset(bs)
+    if p.mode:
+        ix.coverage_enable_nuc()
+    bt = g.Batch(ix, len(pick), Bs.shape[1])
+    res = bt.map(p, Bs, Qs, Ls)
+    recs, cigars = bt.output(p, res)
+    want_recs = []; cov = {}; nuc = {}
+    for k, i in enumerate(pick):
+        seq = B[i, :L].tobytes(); qual = Q[i, :L].tobytes()
+        st, orecs, deps = orc.read_output(oix, op, orc.pwm(seq, qual), seq)
+        for r in orecs:
+            want_recs.append((k, int(r["pos"]), int(r["strand"]), int(r["chr_pos"]), int(r["mapq"]), r["cigar"], np.float32(r["a_score"]).view(np.uint32),
+                              np.float32(r["post_prob"]).view(np.uint32), int(r["sim_matches"])))
+        for pos, span, w, codes in deps:
+            for t in range(span):
+                b_ = (pos + t) // bs
+                cov[b_] = np.float32(cov.get(b_, np.float32(0)) + np.float32(w))
+                if codes is not None and codes[t] < 5:
+                    nuc[(codes[t], b_)] = np.float32(nuc.get((codes[t], b_), np.float32(0)) + np.float32(w))
+    got_recs = [(int(r["read"]), int(r["pos"]), int(r["strand"]), int(r["chr_pos"]), int(r["mapq"]), c, np.float32(r["a_score"]).view(np.uint32),
+                 np.float32(r["post_prob"]).view(np.uint32), int(r["sim_matches"])) for r, c in zip(recs, cigars)]
+    bad_recs = int(got_recs != want_recs)
+    dev = torch.device("cuda", 0)
+    bins = ix.coverage_bins()
+    track = gd.DeviceTrack(ix.coverage_device_ptr(), bins).tensor(dev)
+    keys = np.fromiter(cov.keys(), np.int64, len(cov))
+    got = track[torch.from_numpy(keys).to(dev)].cpu().numpy()
+    want = np.array([cov[k] for k in keys], np.float32)
+    bad_cov = int((np.abs(got - want) > 1e-5 * np.maximum(1.0, np.abs(want))).sum())
+    total_ok = abs(float(track.sum().item()) - float(want.astype(np.float64).sum())) <= 1e-3 * max(1.0, float(want.sum()))
+    bad_nuc = 0
+    if p.mode:
+        nt = gd.DeviceTrack(ix.coverage_nuc_device_ptr(), 5 * bins).tensor(dev)
+        nk = list(nuc.keys())
+        idx = torch.tensor([c * bins + b_ for c, b_ in nk], dtype=torch.int64, device=dev)
+        gotn = nt[idx].cpu().numpy()
+        wantn = np.array([nuc[k] for k in nk], np.float32)
+        bad_nuc = int((np.abs(gotn - wantn) > 1e-5 * np.maximum(1.0, np.abs(wantn))).sum())
+        total_ok = total_ok and abs(float(nt.sum().item()) - float(wantn.astype(np.float64).sum())) <= 1e-3 * max(1.0, float(wantn.sum()))
+    bt.destroy()
+    return dict(output_reads=len(pick), output_records=len(want_recs), output_record_mismatch=bad_recs, coverage_bins_checked=len(cov),
+                coverage_bin_mismatches=bad_cov, nuc_bins_checked=len(nuc), nuc_bin_mismatches=bad_nuc, track_totals_ok=bool(total_ok))
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--mbp", type=float, default=2200.0)
@@ -91,21 +143,30 @@ def main(argv=None):
     ap.add_argument("--repeats", action="store_true", help="overlay SINE-/LINE-/satellite-like repeat families (28 %% of the genome)")
     ap.add_argument("--no-nw", action="store_true")
     ap.add_argument("--keep", action="store_true", help="keep the FASTA and the index files in --workdir")
+    ap.add_argument("--jump", type=int, default=0)
+    ap.add_argument("--mode", type=int, default=0, help="0 normal, 1 -b, 2 --b2, 3 -d")
+    ap.add_argument("--check-output", type=int, default=0, help="reads whose gm_output_batch records and coverage / per-nucleotide deposits are compared with the oracle")
     a = ap.parse_args(argv)
 
     import gnumap_amd as g
     G = int(a.mbp * 1e6)
     L = a.read_len
     os.makedirs(a.workdir, exist_ok=True)
-    fa = os.path.join(a.workdir, f"g{a.mbp:g}{'r' if a.repeats else ''}.fa")
-    t = time.time()
-    offs = write_genome(fa, G, a.contigs, 11, a.repeats)
-    t_gen = time.time() - t
-    log(f"[scale] {G} bp FASTA written in {t_gen:.0f} s")
-    t = time.time()
-    g.index_build(fa)
-    t_build = time.time() - t
-    log(f"[scale] index built in {t_build:.0f} s")
+    fa = os.path.join(a.workdir, f"g{a.mbp:g}{'r' if a.repeats else ''}_c{a.contigs}.fa")
+    t_gen = t_build = 0.0
+    if a.keep and os.path.exists(fa + ".offs.npy") and os.path.exists(fa + ".gnumap.sa"):
+        offs = [int(x) for x in np.load(fa + ".offs.npy")]               # kept by an earlier call in the same session
+    else:
+        t = time.time()
+        offs = write_genome(fa, G, a.contigs, 11, a.repeats)
+        t_gen = time.time() - t
+        log(f"[scale] {G} bp FASTA written in {t_gen:.0f} s")
+        t = time.time()
+        g.index_build(fa)
+        t_build = time.time() - t
+        log(f"[scale] index built in {t_build:.0f} s")
+        if a.keep:
+            np.save(fa + ".offs.npy", np.asarray(offs, np.int64))
     out = dict(genome_bp=G, contigs=a.contigs, repeats=bool(a.repeats), fasta_write_s=round(t_gen, 1), index_build_s=round(t_build, 1))
     if a.build_only:
         print(json.dumps(out)); return out
@@ -141,7 +202,7 @@ def main(argv=None):
         Q[sl, :L] = (33 + rng.integers(20, 41, (k, L))).astype(np.uint8)
     Ln = np.full(n, L, np.uint16)
 
-    kw = dict(mer=a.mer, max_kmer_hits=a.max_kmer_hits, nw=0 if a.no_nw else 1)
+    kw = dict(mer=a.mer, jump=a.jump, max_kmer_hits=a.max_kmer_hits, nw=0 if a.no_nw else 1, mode=a.mode)
     p = g.Params(**kw)
     batch = g.Batch(ix, n, stride)
     res = batch.map(p, B, Q, Ln)                       # full host result (hit lists) for the checks
@@ -182,6 +243,9 @@ def main(argv=None):
     out.update(oracle_sample=int(a.sample), oracle_mismatches=int(bad), oracle_reads_per_s=round(a.sample / max(1e-9, time.time() - t_or), 1),
                oracle_tail_reads=int((pos[pick] >= (1 << 31)).sum()))
 
+    if a.check_output:
+        out.update(check_output(g, ix, p, orc, oix, op, B, Q, Ln, L, pick[:a.check_output]))
+
     # rate with the reads resident in HBM
     batch.upload(p, B, Q, Ln)
     batch.map_device(p)
@@ -198,7 +262,7 @@ def main(argv=None):
     print(json.dumps(out), flush=True)
     batch.destroy(); ix.close()
     if not a.keep:
-        for ext in ("", ".gnumap.pac", ".gnumap.ann", ".gnumap.amb", ".gnumap.bwt", ".gnumap.sa"):
+        for ext in ("", ".gnumap.pac", ".gnumap.ann", ".gnumap.amb", ".gnumap.bwt", ".gnumap.sa", ".offs.npy"):
             if os.path.exists(fa + ext):
                 os.remove(fa + ext)
     return out
