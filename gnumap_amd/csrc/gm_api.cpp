@@ -100,9 +100,11 @@ struct gm_batch {
         rs_overflow, retry_list, retry_off, gtab_keys, gtab_vals, cands, hit_count, hit_begin, hit_cursor, raw_hits, counters, small, shards, big_list,
         tb_items, tb_ops, tb_len, dep_pos, dep_span, dep_w, dep_codes, dep_coff,
         // grouping (process_hits' unique map) and output stage, gm_output.hip
-        g_sorted, g_ord, g_lead, g_krank, g_khash, g_nmatch, g_mbegin, g_multi, g_matches, g_positions, scan_tmp,
+        g_sorted, g_ord, g_lead, g_krank, g_khash, g_nmatch, g_mbegin, g_multi, g_matches, g_mhit, g_positions, scan_tmp,
         o_small, o_posmatch, o_post, o_mapq, o_emit, o_reccnt, o_cigcnt, o_recoff, o_cigoff, o_recs, o_pool, o_codes;
-    PinBuf h_raw, h_top, h_hbegin, h_ord, h_post, h_mapq, h_emit;
+    PinBuf h_raw, h_top, h_hbegin, h_ord, h_post, h_mapq, h_emit, h_mhit;
+    std::vector<double> h_exp;          // exp(score) of every accepted hit of the last gm_map_batch (reused by gm_output_batch)
+    uint64_t cache_hits = 0, cache_matches = 0;
     uint32_t cand_cap = 0;
     uint64_t raw_cap = 0;
     uint32_t n_cands = 0;
@@ -449,11 +451,11 @@ extern "C" void gm_batch_destroy(gm_batch* b) {
                       &b->n_entries, &b->entry_off, &b->coords, &b->rs_overflow, &b->retry_list, &b->retry_off, &b->gtab_keys, &b->gtab_vals,
                       &b->cands, &b->hit_count, &b->hit_begin, &b->hit_cursor, &b->raw_hits, &b->counters, &b->small, &b->shards, &b->big_list, &b->tb_items, &b->tb_ops,
                       &b->tb_len, &b->dep_pos, &b->dep_span, &b->dep_w, &b->dep_codes, &b->dep_coff,
-                      &b->g_sorted, &b->g_ord, &b->g_lead, &b->g_krank, &b->g_khash, &b->g_nmatch, &b->g_mbegin, &b->g_multi, &b->g_matches, &b->g_positions,
+                      &b->g_sorted, &b->g_ord, &b->g_lead, &b->g_krank, &b->g_khash, &b->g_nmatch, &b->g_mbegin, &b->g_multi, &b->g_matches, &b->g_mhit, &b->g_positions,
                       &b->scan_tmp, &b->o_small, &b->o_posmatch, &b->o_post, &b->o_mapq, &b->o_emit, &b->o_reccnt, &b->o_cigcnt, &b->o_recoff, &b->o_cigoff,
                       &b->o_recs, &b->o_pool, &b->o_codes };
     for (DevBuf* d : all) d->release();
-    PinBuf* pins[] = { &b->h_raw, &b->h_top, &b->h_hbegin, &b->h_ord, &b->h_post, &b->h_mapq, &b->h_emit };
+    PinBuf* pins[] = { &b->h_raw, &b->h_top, &b->h_hbegin, &b->h_ord, &b->h_post, &b->h_mapq, &b->h_emit, &b->h_mhit };
     for (PinBuf* d : pins) d->release();
     for (int i = 0; i < gm_batch::NS; ++i) { if (b->sub_streams[i]) (void)hipStreamDestroy(b->sub_streams[i]); b->sub_gk[i].release(); b->sub_gv[i].release(); }
     if (b->sub_ready) (void)hipEventDestroy(b->sub_ready);
@@ -502,7 +504,7 @@ extern "C" int gm_batch_upload(gm_batch* b, const gm_params* p, const gm_reads* 
     if (r->stride % 8 != 0) { gm_set_error("gm_reads.stride must be a multiple of 8"); return GM_E_ARG; }
     HIPCHK(hipSetDevice(b->ix->device));
     hipStream_t st = S_(stream);
-    b->n = r->n; b->stride = r->stride; b->mapped = false;
+    b->n = r->n; b->stride = r->stride; b->mapped = false; b->cache_hits = b->cache_matches = 0;
     size_t bytes = (size_t)r->n * r->stride;
     if (b->bases.ensure(bytes + 16) || b->quals.ensure(bytes + 16) || b->len.ensure((size_t)r->n * 2 + 16)) return GM_E_NOMEM;
     b->len_host.assign(r->len, r->len + r->n);
@@ -968,14 +970,15 @@ extern "C" int gm_map_batch(gm_index* ix, const gm_params* p, gm_batch* b, const
     b->n_raw = n_hits;
     const size_t nh = (size_t)n_hits + 16;
     if (b->g_sorted.ensure(nh * sizeof(GmRawHit)) || b->g_ord.ensure(nh * 4) || b->g_lead.ensure(nh * 4) || b->g_krank.ensure(nh * 4) ||
-        b->g_khash.ensure(nh * 8) || b->g_positions.ensure(nh * sizeof(GmDevPos)) || b->g_matches.ensure(nh * sizeof(GmDevMatch)) ||
+        b->g_khash.ensure(nh * 8) || b->g_positions.ensure(nh * sizeof(GmDevPos)) || b->g_matches.ensure(nh * sizeof(GmDevMatch)) || b->g_mhit.ensure(nh * 4) ||
         b->g_nmatch.ensure((size_t)n * 4) || b->g_mbegin.ensure(((size_t)n + 1) * 8) || b->g_multi.ensure((size_t)n * 4 + 64) ||
         b->scan_tmp.ensure(((size_t)n / 1024 + 8) * 8) || b->o_small.ensure(64)) return GM_E_NOMEM;
     GmDevGroup g;
     g.sorted = b->g_sorted.as<GmRawHit>(); g.ord_score = b->g_ord.as<float>(); g.lead = b->g_lead.as<uint32_t>(); g.krank = b->g_krank.as<uint32_t>();
     g.khash = b->g_khash.as<unsigned long long>(); g.n_match = b->g_nmatch.as<uint32_t>(); g.match_begin = b->g_mbegin.as<uint64_t>();
     g.multi_list = b->g_multi.as<uint32_t>(); g.n_multi = b->o_small.as<uint32_t>();
-    g.matches = b->g_matches.as<GmDevMatch>(); g.positions = b->g_positions.as<GmDevPos>();
+    g.matches = b->g_matches.as<GmDevMatch>(); g.match_hit = b->g_mhit.as<uint32_t>(); g.positions = b->g_positions.as<GmDevPos>();
+    b->cache_hits = b->cache_matches = 0;
     HIPCHK(hipMemsetAsync(b->o_small.p, 0, 64, st));
     if (p->unique_only && !p->nw) HIPCHK(hipMemsetAsync(b->g_positions.p, 0, nh * sizeof(GmDevPos), st));      // dropped hits leave holes
     KCHK(gmk_group_count(ix->dev, b->dev, g, p->nw, p->unique_only, p->max_matches, st));
@@ -1000,14 +1003,23 @@ extern "C" int gm_map_batch(gm_index* ix, const gm_params* p, gm_batch* b, const
     }
     if (n_m) HIPCHK(hipMemcpyAsync(out->matches, g.matches, (size_t)n_m * sizeof(gm_match), hipMemcpyDeviceToHost, st));
     if (n_hits) HIPCHK(hipMemcpyAsync(out->positions, g.positions, (size_t)n_hits * sizeof(gm_pos), hipMemcpyDeviceToHost, st));
+    if (b->h_mhit.ensure((size_t)n_m * 4 + 16)) return GM_E_NOMEM;
+    if (n_m) HIPCHK(hipMemcpyAsync(b->h_mhit.p, g.match_hit, (size_t)n_m * 4, hipMemcpyDeviceToHost, st));
     // the fp64 pass (process_hits :134-165: denominator += exp(align_score) for every new key and every new place of an old key, in
     // processing order) runs while the records are still in flight
     const float* top = b->h_top.as<float>(); const uint64_t* hb = b->h_hbegin.as<uint64_t>(); const float* ord = b->h_ord.as<float>();
+    b->h_exp.resize((size_t)n_hits + 1);
+    double* hexp = b->h_exp.data();
     for (uint32_t i = 0; i < n; ++i) {
         const int8_t s = out->status[i];
         double den = 0.0, tp = 0.0;
         if (s == GM_READ_OK) {
-            for (uint64_t h = hb[i]; h < hb[i + 1]; ++h) { const float sc = ord[h]; if (sc != -INFINITY) den += exp((double)sc); }
+            for (uint64_t h = hb[i]; h < hb[i + 1]; ++h) {
+                const float sc = ord[h];
+                const double e = sc != -INFINITY ? exp((double)sc) : 0.0;
+                hexp[h] = e;
+                if (sc != -INFINITY) den += e;
+            }
             tp = (double)top[i];
         } else if (s == GM_READ_TOO_SHORT) tp = -2.0;
         else if (s == GM_READ_TOO_POOR) tp = -3.0;
@@ -1016,6 +1028,7 @@ extern "C" int gm_map_batch(gm_index* ix, const gm_params* p, gm_batch* b, const
     }
     pc.lap("exp");
     HIPCHK(hipStreamSynchronize(st));
+    b->cache_hits = n_hits; b->cache_matches = n_m;          // h_exp / h_ord / h_mhit describe this result
     pc.lap("records");
     return GM_OK;
 }
@@ -1052,6 +1065,8 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
         return q > 30 ? 30 : q;
     };
     const int all = p->print_all_sam;
+    const uint64_t cached_m = b->cache_matches, cached_h = b->cache_hits;
+    const uint32_t* mhit = b->h_mhit.as<uint32_t>(); const float* ord = b->h_ord.as<float>(); const double* hexp = b->h_exp.data();
     for (uint32_t i = 0; i < n; ++i) {
         const uint64_t m0 = hits->match_begin[i], m1 = hits->match_begin[i + 1];
         if (m0 == m1) continue;
@@ -1063,7 +1078,11 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
             const gm_match& mm = hits->matches[m];
             if (mm.read != i || mm.pos_end < mm.pos_begin) { gm_set_error("gm_hits: match does not belong to its read"); return GM_E_ARG; }
             n_p = std::max<uint64_t>(n_p, mm.pos_end);
-            const double lg = exp((double)mm.score);
+            // exp(align_score): the value gm_map_batch already computed for the hit that gave this match its score, when the caller has
+            // left the match as it was (exp is a function of the score alone, so equal score bits are all that has to hold)
+            double lg;
+            if (m < cached_m && mhit[m] < cached_h && memcmp(&ord[mhit[m]], &mm.score, 4) == 0) lg = hexp[mhit[m]];
+            else lg = exp((double)mm.score);
             const double total = lg / den;                             // ScoredSeq.h:300
             post[m] = (float)total;                                    // AddScore(const float& amt), NormalScoredSeq.cpp:70
             emit[m] = (uint8_t)all;

@@ -118,6 +118,7 @@ struct GmDevGroup {
     uint32_t* multi_list;           // reads with >= 2 accepted hits
     uint32_t* n_multi;
     GmDevMatch* matches;
+    uint32_t* match_hit;            // per match: index (in the hit CSR, processing order) of the hit that gave the match its score
     GmDevPos* positions;            // same CSR as the hits (a read's positions live in [hit_begin[r], hit_begin[r+1]))
 };
 

@@ -2356,6 +2356,165 @@ __global__ void __launch_bounds__(256) k_traceback(GmDevIndex ix, GmDevParams p,
 }
 
 // ------------------------------------------------------------------------------------------------
+// traceback, lane form (reads up to 511 bases): ONE lane per kept sequence runs the forward banded DP with the 7-cell band row in
+// registers (the scheme of k_nw_lane) and keeps the 14 move bits of every row in LDS as [row][lane] 16-bit words (conflict-free: a
+// wave's row is 128 consecutive bytes); the same lane then walks the moves back from (L, L) and emits the packed operations, the
+// CIGAR text length and the aligned length exactly like k_traceback (which stays for longer reads).  Same arithmetic, same
+// tie-breaks (max_flt(char&,...) src/bin_seq.cpp:989-1011), so the operations are identical.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(NT) k_traceback_lane(GmDevIndex ix, GmDevParams p, GmDevBatch b, const GmCand* items, uint32_t n,
+                                                       unsigned long long* ops, uint32_t ops_words, uint16_t* ops_len, uint32_t Lp,
+                                                       const uint8_t* emit, uint32_t* cig_cnt, uint32_t* max_span) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    uint16_t* s_mv = reinterpret_cast<uint16_t*>(s_dyn);                 // (Lp + 1) rows x NT lanes
+    __shared__ float2 s_lut[512];
+    __shared__ uint32_t s_coff[GM_NW_NCOFF];
+    for (int q = threadIdx.x; q < 512; q += NT) s_lut[q] = p.lut[q];
+    const bool lds_coff = ix.n_seqs + 1 <= GM_NW_NCOFF;
+    if (lds_coff) for (uint32_t q = threadIdx.x; q <= ix.n_seqs; q += NT) s_coff[q] = ix.contig_off[q];
+    const uint32_t* coff = lds_coff ? s_coff : ix.contig_off;
+    __syncthreads();
+    float sg[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sg[g][k] = p.S256[(size_t)("acgt"[g]) * 4 + k];
+    const float gap = p.gap, gap4 = __fmul_rn(p.gap, 4.0f);
+    const uint32_t* pac32 = reinterpret_cast<const uint32_t*>(ix.pac);
+    const int lane = gm_lane();
+    uint16_t* mv = s_mv + threadIdx.x;
+    for (uint32_t base = blockIdx.x * NT; base < n; base += gridDim.x * NT) {
+        const uint32_t ci = base + threadIdx.x;
+        const bool have = ci < n;
+        GmCand c; c.rs = 0; c.b = 0;
+        if (have) c = items[ci];
+        const uint32_t r = c.rs >> 1, strand = c.rs & 1;
+        const uint32_t L = have ? b.len[r] : 0;
+        const bool ok = have && L > 0 && L <= Lp && gm_window_ok(ix, coff, c.b, L) && 2 * L <= 32 * ops_words;
+        uint16_t outlen = 0;
+        uint32_t ctext = 1;                                              // "*" when there is no path
+        if (ok) {
+            const float2* lut = s_lut + ((r < b.illumina_until) ? 256 : 0);
+            const uint8_t* rb = b.bases + (size_t)r * b.stride;
+            const uint8_t* rq = b.quals + (size_t)r * b.stride;
+            const int Li = (int)L;
+            uint32_t wword_lo = 0, wword_hi = 0; int wbase = -1;
+            auto wcode = [&](int j) -> uint32_t {                        // 2-bit code of the reference at window offset j
+                uint32_t g = c.b + (uint32_t)j;
+                int wi16 = (int)(g >> 4);
+                if (wi16 != wbase && wi16 != wbase + 1) { wbase = wi16; wword_lo = pac32[wi16]; wword_hi = pac32[wi16 + 1]; }
+                uint32_t word = wi16 == wbase ? wword_lo : wword_hi;
+                return (word >> ((((g >> 2) & 3u) << 3) + ((~g & 3u) << 1))) & 3u;
+            };
+            // row 0: nm[0][j] = gGAP * j for the band's columns (bin_seq.cpp:503-511)
+            float P[7], C[7];
+#pragma unroll
+            for (int d = 0; d < 7; ++d) P[d] = d >= 3 ? __fmul_rn(gap, (float)(d - 3)) : GM_NEG_INF;
+            // window codes of the band columns of row i: W[d] = w[i + d - 4] (column j - 1 of cell (i, j = i + d - 3)); start at row 1
+            uint32_t W[7];
+#pragma unroll
+            for (int d = 0; d < 7; ++d) { int j = 1 + d - 4; W[d] = (j >= 0 && j < Li) ? wcode(j) : 0u; }
+            // the read streams through 8-byte words, the next word requested one chunk ahead
+            const int src0 = strand ? Li - 1 : 0, cstep = strand ? -1 : 1, nchunk = (Li + 7) >> 3;
+            int chunk = src0 >> 3;
+            uint2 bw = *reinterpret_cast<const uint2*>(rb + (chunk << 3)), qw = *reinterpret_cast<const uint2*>(rq + (chunk << 3));
+            uint2 bn = bw, qn = qw;
+            { int nc = chunk + cstep; if (nc >= 0 && nc < nchunk) { bn = *reinterpret_cast<const uint2*>(rb + (nc << 3)); qn = *reinterpret_cast<const uint2*>(rq + (nc << 3)); } }
+            for (int i = 1; i <= Li; ++i) {
+                const int src = strand ? Li - i : i - 1;                 // PWM row i-1 in strand orientation (reverse_comp_cpy)
+                if ((src >> 3) != chunk) {
+                    chunk = src >> 3;
+                    bw = bn; qw = qn;
+                    int nc = chunk + cstep;
+                    if (nc >= 0 && nc < nchunk) { bn = *reinterpret_cast<const uint2*>(rb + (nc << 3)); qn = *reinterpret_cast<const uint2*>(rq + (nc << 3)); }
+                }
+                const uint32_t sh = (uint32_t)(src & 3) << 3;
+                const uint32_t ch = (((src & 4) ? bw.y : bw.x) >> sh) & 255u;
+                const uint32_t qc = (((src & 4) ? qw.y : qw.x) >> sh) & 255u;
+                uint32_t code = gm_nt4(ch);
+                if (strand && code < 4) code = 3 - code;
+                const float2 pq = lut[qc];
+                float v4[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) v4[g] = gm_get_val(code, pq.x, pq.y, sg[g]);
+                uint32_t mrow = 0;
+#pragma unroll
+                for (int d = 0; d < 7; ++d) {
+                    const int j = i + d - 3;
+                    if (j <= 0 || j > Li) { C[d] = j == 0 ? __fmul_rn(gap, (float)i) : GM_NEG_INF; continue; }     // first column: gGAP * i
+                    const uint32_t wc = W[d];
+                    const float val = (wc & 2u) ? ((wc & 1u) ? v4[3] : v4[2]) : ((wc & 1u) ? v4[1] : v4[0]);
+                    const float up = d < 6 ? P[d + 1] : (i - 1 == 0 ? gap4 : GM_NEG_INF);        // nm[i-1][j]
+                    const float left = d > 0 ? C[d - 1] : (j - 1 == 0 ? gap4 : GM_NEG_INF);       // nm[i][j-1]
+                    const float dd = __fadd_rn(P[d], val);
+                    const float u = __fadd_rn(up, gap);
+                    const float l = __fadd_rn(left, gap);
+                    uint32_t m; float best;                              // max_flt(char&,...) src/bin_seq.cpp:989-1011
+                    if (dd >= u) { if (dd >= l) { m = 0; best = dd; } else { m = 2; best = l; } }
+                    else         { if (u >= l)  { m = 1; best = u; }  else { m = 2; best = l; } }
+                    C[d] = best;
+                    mrow |= m << (2 * d);
+                }
+#pragma unroll
+                for (int d = 0; d < 7; ++d) P[d] = C[d];
+                mv[(size_t)i * NT] = (uint16_t)mrow;
+                // slide the window codes to row i + 1: column offsets (i + 1) + d - 4
+#pragma unroll
+                for (int d = 0; d < 6; ++d) W[d] = W[d + 1];
+                { const int j = i + 3; W[6] = j < Li ? wcode(j) : 0u; }
+            }
+            // walk back from (L, L)
+            unsigned long long* out = ops + (size_t)ci * ops_words;
+            int i = Li, j = Li, nops = 0; bool bad = false;
+            while (i != 0 && j != 0) {
+                const int dl = j - i;
+                if (dl < -3 || dl > 3) { bad = true; break; }
+                const uint32_t m = ((uint32_t)mv[(size_t)i * NT] >> (2 * (dl + 3))) & 3u;
+                if (m == 0) { --i; --j; } else if (m == 1) { --i; } else { --j; }
+                ++nops;
+            }
+            if (!bad) {
+                nops += i + j;
+                int k = nops - 1;
+                unsigned long long cur = 0;
+                uint32_t run_code = 3, run_len = 0, text = 0; bool first_run = true;
+                auto push = [&](uint32_t code) {
+                    cur |= (unsigned long long)code << (2 * (k & 31));
+                    if ((k & 31) == 0) { out[k >> 5] = cur; cur = 0; }
+                    --k;
+                    if (code == run_code) { ++run_len; return; }
+                    if (run_len) { if (!(first_run && run_code == 2)) text += gm_digits(run_len) + 1; first_run = false; }
+                    run_code = code; run_len = 1;
+                };
+                i = Li; j = Li;
+                while (i != 0 && j != 0) {
+                    const int dl = j - i;
+                    const uint32_t m = ((uint32_t)mv[(size_t)i * NT] >> (2 * (dl + 3))) & 3u;
+                    push(m);
+                    if (m == 0) { --i; --j; } else if (m == 1) { --i; } else { --j; }
+                }
+                while (i > 0) { push(1); --i; }
+                while (j > 0) { push(2); --j; }
+                if (run_len && !(first_run && run_code == 2)) text += gm_digits(run_len) + 1;
+                outlen = (uint16_t)nops;
+                if (nops) ctext = text;
+            }
+        }
+        if (have) {
+            ops_len[ci] = outlen;
+            if (cig_cnt) cig_cnt[ci] = emit[ci] ? (p.nw ? ctext : gm_digits(L) + 1u) + 1u : 0u;
+        }
+        if (max_span) {
+            uint32_t my_span = outlen;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(my_span, off); my_span = o > my_span ? o : my_span; }
+            if (lane == 0 && my_span) atomicMax(max_span, my_span);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // coverage: one thread per deposited base
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_coverage_add(float* cov, uint64_t bins, uint32_t bin_size, const uint64_t* pos,
@@ -2607,6 +2766,19 @@ int gmk_traceback(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& 
                   unsigned long long* ops, uint32_t ops_words, uint16_t* ops_len, const uint8_t* emit, uint32_t* cig_cnt, uint32_t* max_span, void* stream) {
     if (n == 0) return 0;
     uint32_t Lp = lp_of(b.stride);
+    static const bool group_form = [] { const char* e = getenv("GM_TRACEBACK"); return e && !strcmp(e, "group"); }();   // GM_TRACEBACK=group: the 8-lane form for every length (tests)
+    if (!group_form && Lp <= 511) {              // lane form: one lane per item, move rows in LDS
+        if (Lp <= 255) {
+            const size_t lds = (size_t)(Lp + 1) * 128 * 2;
+            uint32_t grid = cdiv(n, 128); if (grid > 16384) grid = 16384;
+            hipLaunchKernelGGL((k_traceback_lane<128>), dim3(grid), dim3(128), lds, S_(stream), ix, p, b, items, n, ops, ops_words, ops_len, Lp, emit, cig_cnt, max_span);
+        } else {
+            const size_t lds = (size_t)(Lp + 1) * 64 * 2;
+            uint32_t grid = cdiv(n, 64); if (grid > 16384) grid = 16384;
+            hipLaunchKernelGGL((k_traceback_lane<64>), dim3(grid), dim3(64), lds, S_(stream), ix, p, b, items, n, ops, ops_words, ops_len, Lp, emit, cig_cnt, max_span);
+        }
+        return (int)hipGetLastError();
+    }
     uint32_t mvw = (Lp + 1 + 15) / 16 + 1;
     uint32_t threads = 256;
     if (GM_NW_HDR + (size_t)32 * Lp * 3 + (size_t)32 * 7 * mvw * 4 > 60 * 1024) threads = 64;

@@ -215,6 +215,7 @@ __global__ void __launch_bounds__(256) k_group_write_single(GmDevBatch b, GmDevG
     m.read = b.read_base + r; m.score = h.score; m.first_pos = h.pos; m.first_strand = h.strand; m.pad[0] = m.pad[1] = m.pad[2] = 0;
     m.pos_begin = (uint32_t)hb; m.pos_end = (uint32_t)hb + 1u;
     g.matches[g.match_begin[r]] = m;
+    g.match_hit[g.match_begin[r]] = (uint32_t)hb;
     GmDevPos p; p.pos = h.pos; p.strand = h.strand; for (int q = 0; q < 7; ++q) p.pad[q] = 0;
     g.positions[hb] = p;
 }
@@ -250,6 +251,7 @@ __global__ void __launch_bounds__(64) k_group_write_multi(GmDevBatch b, GmDevGro
                 m.read = b.read_base + r; m.score = h.score; m.first_pos = h.pos; m.first_strand = h.strand; m.pad[0] = m.pad[1] = m.pad[2] = 0;
                 m.pos_begin = (uint32_t)(hb + goff); m.pos_end = (uint32_t)(hb + goff + gsize);
                 g.matches[mb + grp] = m;
+                g.match_hit[mb + grp] = (uint32_t)(hb + s);
             }
         }
     }

@@ -62,3 +62,17 @@ def test_cli_equals_reference_program(mode, extra, tmp_path):
     else:
         assert not os.path.exists(out + ".sgr")
         compare_tracks(open(out + ".gmp").read(), ref_text(mode, "gmp"), 8)
+
+
+@pytest.mark.parametrize("mode", ["default", "bs_all", "k1_all", "no_nw"])
+def test_cli_with_the_group_traceback_form(mode, tmp_path):
+    """reads up to 511 bases take the lane-per-sequence traceback kernel; GM_TRACEBACK=group forces the 8-lane form (the one long
+    reads use) on the same inputs: CIGARs, aligned lengths (coverage) and gapped read strings (.gmp) must not change"""
+    m = MANIFEST[mode]
+    out = str(tmp_path / "mine")
+    r = subprocess.run([EXE, "-g", os.path.join(GOLDEN, "syn.fa"), "-o", out, "-a", "0.9"] + m["argv"] + [os.path.join(GOLDEN, m["fastq"])],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, GM_TRACEBACK="group"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "".join(l for l in open(out + ".sam") if not l.startswith("@PG")) == ref_text(mode, "sam")
+    ext = "sgr" if "sgr" in m["tracks"] else "gmp"
+    compare_tracks(open(out + "." + ext).read(), ref_text(mode, ext), 3 if ext == "sgr" else 8)

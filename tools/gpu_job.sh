@@ -1,14 +1,7 @@
 set -e
-export TMPDIR=/tmp
-R=$(pwd)
-cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r02_j2_stats -- python3 $R/bench.py --genome-mbp 100 --contigs 6 --mer 10 --reads 2000000 --abi-reads 2097152 --cpu-seconds 0 > $R/gpurun_out/r02_j2_bench.json 2> $R/gpurun_out/r02_j2_bench.log || { tail -30 $R/gpurun_out/r02_j2_bench.log; exit 1; }
-cd $R
-python3 - <<'PY'
-import csv,glob
-f=glob.glob("gpurun_out/r02_j2_stats/*/*_kernel_stats.csv")[0]
-for r in csv.DictReader(open(f)):
-    print(r["Name"][:70], r["Calls"], r["TotalDurationNs"], r["AverageNs"])
-PY
+python -m pytest tests/test_gpu_driver_golden.py tests/test_gpu_parity.py tests/test_gpu_scale.py -x -q -k "not every_kernel_variant" > gpurun_out/r02_j5_tests.log 2>&1 || { tail -40 gpurun_out/r02_j5_tests.log; exit 1; }
+tail -3 gpurun_out/r02_j5_tests.log
+GM_TIMING=1 python3 bench.py --cpu-seconds 0 > gpurun_out/r02_j5_bench_human.json 2> gpurun_out/r02_j5_bench_human.log || { tail -30 gpurun_out/r02_j5_bench_human.log; exit 1; }
 python3 -c "
-import json;j=json.loads(open('gpurun_out/r02_j2_bench.json').read().strip().splitlines()[-1]);print(j['value'],j['abi'])"
+import json;j=json.loads(open('gpurun_out/r02_j5_bench_human.json').read().strip().splitlines()[-1]);print(j['value'],j['abi'])"
+grep -E "gm_timing" gpurun_out/r02_j5_bench_human.log | tail -6
