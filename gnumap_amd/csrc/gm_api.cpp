@@ -97,7 +97,7 @@ struct gm_batch {
     uint32_t max_reads = 0, max_len = 0;
     uint32_t n = 0, stride = 0, max_seeds = 0, illumina_until = 0;
     DevBuf bases, quals, len, status, self_score, min_score, top_score, seeds, n_seeds, n_entries, entry_off, coords,
-        rs_overflow, retry_list, retry_off, gtab_keys, gtab_vals, cands, hit_count, hit_begin, hit_cursor, raw_hits, counters, small, shards, big_list,
+        rs_overflow, retry_list, retry_off, gtab_keys, gtab_vals, cands, fixed_cands, fixed_cnt, hit_count, hit_begin, hit_cursor, raw_hits, counters, small, shards, big_list,
         tb_items, tb_ops, tb_len, dep_pos, dep_span, dep_w, dep_codes, dep_coff,
         // grouping (process_hits' unique map) and output stage, gm_output.hip
         g_sorted, g_ord, g_lead, g_krank, g_khash, g_nmatch, g_mbegin, g_multi, g_matches, g_mhit, g_positions, scan_tmp,
@@ -106,6 +106,7 @@ struct gm_batch {
     std::vector<double> h_exp;          // exp(score) of every accepted hit of the last gm_map_batch (reused by gm_output_batch)
     uint64_t cache_hits = 0, cache_matches = 0;
     uint32_t cand_cap = 0;
+    bool use_fixed = false;             // k_vote_tiny* leave their candidates in per read x strand slots (gathered by k_cand_gather)
     uint64_t raw_cap = 0;
     uint32_t n_cands = 0;
     uint64_t n_raw = 0;
@@ -449,7 +450,7 @@ extern "C" void gm_batch_destroy(gm_batch* b) {
     (void)hipSetDevice(b->ix->device);
     DevBuf* all[] = { &b->bases, &b->quals, &b->len, &b->status, &b->self_score, &b->min_score, &b->top_score, &b->seeds, &b->n_seeds,
                       &b->n_entries, &b->entry_off, &b->coords, &b->rs_overflow, &b->retry_list, &b->retry_off, &b->gtab_keys, &b->gtab_vals,
-                      &b->cands, &b->hit_count, &b->hit_begin, &b->hit_cursor, &b->raw_hits, &b->counters, &b->small, &b->shards, &b->big_list, &b->tb_items, &b->tb_ops,
+                      &b->cands, &b->fixed_cands, &b->fixed_cnt, &b->hit_count, &b->hit_begin, &b->hit_cursor, &b->raw_hits, &b->counters, &b->small, &b->shards, &b->big_list, &b->tb_items, &b->tb_ops,
                       &b->tb_len, &b->dep_pos, &b->dep_span, &b->dep_w, &b->dep_codes, &b->dep_coff,
                       &b->g_sorted, &b->g_ord, &b->g_lead, &b->g_krank, &b->g_khash, &b->g_nmatch, &b->g_mbegin, &b->g_multi, &b->g_matches, &b->g_mhit, &b->g_positions,
                       &b->scan_tmp, &b->o_small, &b->o_posmatch, &b->o_post, &b->o_mapq, &b->o_emit, &b->o_reccnt, &b->o_cigcnt, &b->o_recoff, &b->o_cigoff,
@@ -492,6 +493,7 @@ static void fill_dev_batch(gm_batch* b) {
     d.gtab_keys = b->gtab_keys.as<uint32_t>(); d.gtab_vals = b->gtab_vals.as<uint32_t>();
     d.cands = b->cands.as<GmCand>(); d.cand_cap = b->cand_cap; d.cand_region = b->cand_cap / GM_NSHARD;
     d.shard_cnt = b->shards.as<uint32_t>();
+    d.fixed_cands = b->use_fixed ? b->fixed_cands.as<GmCand>() : nullptr; d.fixed_cnt = b->fixed_cnt.as<uint8_t>();
     d.hit_count = b->hit_count.as<uint32_t>(); d.hit_begin = b->hit_begin.as<uint64_t>(); d.hit_cursor = b->hit_cursor.as<uint32_t>();
     d.raw_hits = b->raw_hits.as<GmRawHit>(); d.raw_cap = b->raw_cap;
     d.counters = b->counters.as<unsigned long long>();
@@ -554,7 +556,7 @@ static int map_pipelined(gm_index* ix, const gm_params* p, const GmDevParams& dp
     auto make_view = [&](uint32_t i) {
         GmDevBatch v = b->dev;
         const uint32_t lo = i * sub_n, cnt = std::min(sub_n, n - lo);
-        v.n = cnt; v.read_base = lo;
+        v.n = cnt; v.read_base = lo; v.fixed_cands = nullptr;
         v.illumina_until = b->illumina_until > lo ? std::min(b->illumina_until - lo, cnt) : 0;
         v.bases += (size_t)lo * b->stride; v.quals += (size_t)lo * b->stride; v.len += lo;
         v.status += lo; v.self_score += lo; v.min_score += lo; v.top_score += lo;
@@ -679,6 +681,12 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
             if (prc <= 0) return prc;                    // done, or a real error
         }
     }
+    // the one-wave vote kernels leave their candidates in per read x strand slots (no bump counter on the wave's critical path)
+    {
+        static const bool fixed_ok = [] { const char* e = getenv("GM_VOTE_FIXED"); return !(e && !strcmp(e, "0")); }();
+        b->use_fixed = fixed_ok && dense == 1 && slots_hint <= 0;
+        if (b->use_fixed && (b->fixed_cands.ensure(2 * (size_t)b->n * GM_FIXED_C * sizeof(GmCand)) || b->fixed_cnt.ensure(2 * (size_t)b->n + 64))) return GM_E_NOMEM;
+    }
     fill_dev_batch(b);
     HIPCHK(hipMemsetAsync(b->counters.p, 0, GMK_N * 8, st));
     { KTimer t(b, GM_K_PREP, st); KCHK(gmk_prep(ix->dev, dp, b->dev, st)); }
@@ -707,7 +715,8 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         HIPCHK(hipMemsetAsync(b->rs_overflow.p, 0, 2 * (size_t)b->n, st));
         HIPCHK(hipMemsetAsync(b->counters.as<unsigned long long>() + GMK_HEAVY_SLOTS, 0, 8, st));
         HIPCHK(hipMemsetAsync(b->counters.as<unsigned long long>() + GMK_OVERFLOW_RS, 0, 8, st));
-        { KTimer t(b, GM_K_VOTE, st); KCHK(gmk_vote(ix->dev, dp, b->dev, use_full, dense, slots_hint, st)); }
+        if (b->use_fixed) HIPCHK(hipMemsetAsync(b->fixed_cnt.p, 0, 2 * (size_t)b->n, st));
+        { KTimer t(b, GM_K_VOTE, st); KCHK(gmk_vote(ix->dev, dp, b->dev, use_full, dense, slots_hint, st)); KCHK(gmk_cand_gather(b->dev, st)); }
         uint32_t small[2];
         HIPCHK(hipMemcpyAsync(small, b->small.p, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(ctr, b->counters.p, sizeof ctr, hipMemcpyDeviceToHost, st));

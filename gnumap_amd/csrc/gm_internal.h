@@ -42,6 +42,7 @@ struct GmDevParams {
 
 struct GmSeed { uint32_t k, l, pos; };
 
+#define GM_FIXED_C 4
 #define GM_NSHARD 1024
 #define GM_SHARD_STRIDE 32
 
@@ -89,6 +90,11 @@ struct GmDevBatch {
     // shard s owns cands[s * cand_region, (s+1) * cand_region)
     GmCand* cands;  uint32_t cand_cap, cand_region;
     uint32_t* shard_cnt;            // GM_NSHARD counters, GM_SHARD_STRIDE words apart
+    // the one-wave vote kernels (k_vote_tiny*) do not wait for a bump counter: a read x strand with at most GM_FIXED_C candidates
+    // stores them into its own slots (plain stores, the wave retires) and k_cand_gather moves them into the shards afterwards with
+    // ONE atomic per 64 read x strands; null = not in use
+    GmCand* fixed_cands;            // 2n x GM_FIXED_C
+    uint8_t* fixed_cnt;             // 2n, zeroed before the vote kernel
     uint32_t* hit_count;            // n
     uint64_t* hit_begin;            // n+1
     uint32_t* hit_cursor;           // n
@@ -135,6 +141,7 @@ int gmk_seed(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, vo
 int gmk_scan_entries(const GmDevBatch& b, void* stream);
 int gmk_locate_sampled(const GmDevIndex& ix, const GmDevBatch& b, void* stream);
 int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, int dense, int slots_hint, void* stream);
+int gmk_cand_gather(const GmDevBatch& b, void* stream);
 int gmk_vote_retry(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, uint32_t j0, uint32_t n_retry, void* stream);
 int gmk_nw(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint32_t n_cands, void* stream);
 int gmk_compact(const GmDevBatch& b, void* stream);

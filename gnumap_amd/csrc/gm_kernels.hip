@@ -271,11 +271,40 @@ __global__ void __launch_bounds__(256) k_build_kmer_compact(const uint2* tab, ui
 // prep: one thread per read
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_prep(GmDevIndex ix, GmDevParams p, GmDevBatch b, uint32_t tile_reads) {
-    // the quality -> (p, q) table and the 256-row score table are read once per base: keep them in LDS, not behind 5 loads per base
-    __shared__ float2 s_lut[512];
-    __shared__ float4 s_S[256];
-    for (int q = threadIdx.x; q < 512; q += 256) s_lut[q] = p.lut[q];
-    s_S[threadIdx.x] = reinterpret_cast<const float4*>(p.S256)[threadIdx.x];
+    // the term a base adds to the self score depends only on (its character's row of the score table, its quality character): one
+    // table per workgroup, computed ONCE with the reference's expression (get_val, bin_seq.cpp:975-987), turns ~25 instructions per
+    // base into one LDS read + one add - bit-identical, the same function value is only looked up instead of recomputed.
+    // Rows: the 8 ACGT/acgt characters keep their own rows (the -b / -d edits touch the lowercase rows only), every other
+    // character shares the row of its first occurrence class: codes 8.. are built on demand below (class 8 = any other char).
+    __shared__ float s_term[2][10][128];                   // [phred table][char class][quality character & 127]
+    __shared__ uint8_t s_cls[256];
+    const float4* const S4 = reinterpret_cast<const float4*>(p.S256);
+    {
+        const int ch = threadIdx.x;
+        int cl = 8;
+        switch (ch) { case 'A': cl = 0; break; case 'C': cl = 1; break; case 'G': cl = 2; break; case 'T': cl = 3; break;
+                      case 'a': cl = 4; break; case 'c': cl = 5; break; case 'g': cl = 6; break; case 't': cl = 7; break; default: cl = 8; }
+        s_cls[ch] = (uint8_t)cl;
+    }
+    __syncthreads();
+    // all characters outside ACGTacgt have the same row in the reference's table (transversion score for every base, a_matrices.c:55-83)
+    // unless a caller edited gm_params.S by hand: then class 9 marks "not uniform" and those bases take the direct path
+    __shared__ int s_other_uniform;
+    if (threadIdx.x == 0) {
+        int uni = 1;
+        const float4 r0 = S4[(int)'N'];
+        for (int ch = 0; ch < 256 && uni; ++ch)
+            if (s_cls[ch] == 8) { const float4 r = S4[ch]; if (r.x != r0.x || r.y != r0.y || r.z != r0.z || r.w != r0.w) uni = 0; }
+        s_other_uniform = uni;
+    }
+    for (int e = threadIdx.x; e < 2 * 9 * 128; e += 256) {
+        const int tab = e / (9 * 128), cl = (e / 128) % 9, qc = e & 127;
+        const int ch = cl < 8 ? "ACGTacgt"[cl] : 'N';
+        const float2 pq = p.lut[tab * 256 + qc];
+        const float4 sv = S4[ch];
+        const float sarr[4] = { sv.x, sv.y, sv.z, sv.w };
+        s_term[tab][cl][qc] = gm_get_val(gm_nt4((uint32_t)ch), pq.x, pq.y, sarr);
+    }
     // a lane walking its own row with 8-byte loads pulls a whole 128-byte line per load and finds it evicted by the next one
     // (measured: 13 x the useful HBM traffic).  So the 256 reads of a tile are staged into LDS with coalesced 16-byte loads.
     // tile_reads = reads per tile that fit the LDS budget (256 at 100 bp); 0 = rows too long to stage, lanes read HBM directly
@@ -309,7 +338,10 @@ __global__ void __launch_bounds__(256) k_prep(GmDevIndex ix, GmDevParams p, GmDe
         uint32_t L = b.len[r];
         const uint8_t* rb = staged ? s_b + (size_t)threadIdx.x * b.stride : b.bases + (size_t)r * b.stride;
         const uint8_t* rq = staged ? s_q + (size_t)threadIdx.x * b.stride : b.quals + (size_t)r * b.stride;
-        const float2* lut = s_lut + ((r < b.illumina_until) ? 256 : 0);
+        const int tab = (r < b.illumina_until) ? 1 : 0;
+        const float2* lut = p.lut + tab * 256;
+        const float (*term)[128] = s_term[tab];
+        const bool uni = s_other_uniform != 0;
         int8_t st = 0;
         float self = 0.0f;
         double mn;
@@ -322,11 +354,18 @@ __global__ void __launch_bounds__(256) k_prep(GmDevIndex ix, GmDevParams p, GmDe
                 if (i0 + t < L) {
                     uint32_t ch = ((t < 4 ? bw.x : bw.y) >> ((t & 3) * 8)) & 255u;
                     uint32_t qc = ((t < 4 ? qw.x : qw.y) >> ((t & 3) * 8)) & 255u;
-                    float2 pq = lut[qc];
-                    if (pq.x != pq.x) bad = 1;               // negative probability (SeqReader.cpp:1171-1189)
-                    const float4 sv = s_S[ch];
-                    const float s[4] = { sv.x, sv.y, sv.z, sv.w };
-                    score = __fadd_rn(score, gm_get_val(gm_nt4(ch), pq.x, pq.y, s));
+                    const uint32_t cl = s_cls[ch];
+                    float v;
+                    if (qc < 128u && (cl < 8u || uni)) {
+                        v = term[cl][qc];                    // NaN when the probability is negative, like the direct form
+                    } else {
+                        float2 pq = lut[qc];
+                        const float4 sv = S4[ch];
+                        const float s4[4] = { sv.x, sv.y, sv.z, sv.w };
+                        v = gm_get_val(gm_nt4(ch), pq.x, pq.y, s4);
+                    }
+                    if (v != v) bad = 1;                     // negative probability (SeqReader.cpp:1171-1189)
+                    score = __fadd_rn(score, v);
                 }
             }
         }
@@ -1670,7 +1709,18 @@ __global__ void __launch_bounds__(64, 8) k_vote_tiny(GmDevIndex ix, GmDevParams 
         }
         const unsigned long long m0 = __builtin_amdgcn_ballot_w64(em[0]), m1 = __builtin_amdgcn_ballot_w64(em[1]);
         const uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1);
-        if (n0 + n1 != 0u) {                         // wave-uniform
+        if (n0 + n1 != 0u && b.fixed_cands && n0 + n1 <= GM_FIXED_C) {       // wave-uniform: own slots, no counter to wait for
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (em[q]) {
+                    const unsigned long long mq = q ? m1 : m0;
+                    const uint32_t idx = (q ? n0 : 0u) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
+                    GmCand c;
+                    c.rs = rs; c.b = ky[q]; c.step = (uint16_t)st[q]; c.flags = 4; c.pad = 0; c.score = 0.0f;
+                    b.fixed_cands[(size_t)rs * GM_FIXED_C + idx] = c;
+                }
+            if (lane == 0) b.fixed_cnt[rs] = (uint8_t)(n0 + n1);
+        } else if (n0 + n1 != 0u) {                  // wave-uniform
             const uint32_t shard = blockIdx.x & (GM_NSHARD - 1);
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&b.shard_cnt[shard * GM_SHARD_STRIDE], n0 + n1);
@@ -1827,7 +1877,17 @@ __global__ void __launch_bounds__(64, 6) k_vote_tiny2(GmDevIndex ix, GmDevParams
             nb[q] = total;
             total += (uint32_t)__popcll(mk[q]);
         }
-        if (total != 0u) {                           // wave-uniform
+        if (total != 0u && b.fixed_cands && total <= GM_FIXED_C) {            // wave-uniform: own slots, no counter to wait for
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (em[q]) {
+                    const uint32_t idx = nb[q] + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk[q] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk[q], 0u));
+                    GmCand c;
+                    c.rs = rs; c.b = ky[q]; c.step = (uint16_t)st[q]; c.flags = 4; c.pad = 0; c.score = 0.0f;
+                    b.fixed_cands[(size_t)rs * GM_FIXED_C + idx] = c;
+                }
+            if (lane == 0) b.fixed_cnt[rs] = (uint8_t)total;
+        } else if (total != 0u) {                    // wave-uniform
             const uint32_t shard = blockIdx.x & (GM_NSHARD - 1);
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&b.shard_cnt[shard * GM_SHARD_STRIDE], total);
@@ -2070,7 +2130,11 @@ __global__ void __launch_bounds__(256) k_nw(GmDevIndex ix, GmDevParams p, GmDevB
 #ifndef GM_NW_OCC
 #define GM_NW_OCC 5       // measured: 4 -> 3.09 ms, 5 -> 2.97, 6 -> 3.03, 8 -> 3.16 (2 M reads)
 #endif
-__global__ void __launch_bounds__(256, GM_NW_OCC) k_nw_lane(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
+// NCH > 0: the candidate's read row (bases and qualities, NCH 8-byte words each) is loaded into registers up front - every load of
+// a lane goes out back to back and each 128-byte line is fetched once - instead of streaming one word per 8 DP rows (which re-fetched
+// the lines ~9 times: 3.9 KB of HBM traffic per candidate for 208 bytes of read).  NCH = 0 keeps the streaming form (long reads).
+template <int NCH>
+__global__ void __launch_bounds__(256, NCH > 0 ? 3 : GM_NW_OCC) k_nw_lane(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
     __shared__ float2 s_lut[512];
     __shared__ uint32_t s_coff[GM_NW_NCOFF];
     __shared__ uint32_t s_pre[GM_NSHARD + 4];
@@ -2122,9 +2186,30 @@ __global__ void __launch_bounds__(256, GM_NW_OCC) k_nw_lane(GmDevIndex ix, GmDev
             // the read streams through 8-byte words; the NEXT word is requested one chunk ahead so its latency hides under 8 rows
             const int src0 = strand ? 0 : Li - 1, cstep = strand ? 1 : -1, nchunk = (Li + 7) >> 3;
             int chunk = src0 >> 3;
-            uint2 bw = *reinterpret_cast<const uint2*>(rb + (chunk << 3)), qw = *reinterpret_cast<const uint2*>(rq + (chunk << 3));
-            uint2 bn = bw, qn = qw;
-            { int nc = chunk + cstep; if (nc >= 0 && nc < nchunk) { bn = *reinterpret_cast<const uint2*>(rb + (nc << 3)); qn = *reinterpret_cast<const uint2*>(rq + (nc << 3)); } }
+            uint2 RB[NCH > 0 ? NCH : 1], RQ[NCH > 0 ? NCH : 1];
+            auto pick = [&](int cch, uint2& bo, uint2& qo) {           // mask-and-or: keeps the rows in registers (a select chain became a scratch array)
+                uint32_t bx = 0, by = 0, qx = 0, qy = 0;
+#pragma unroll
+                for (int k = 0; k < (NCH > 0 ? NCH : 1); ++k) {
+                    const uint32_t mk = cch == k ? 0xFFFFFFFFu : 0u;
+                    bx |= RB[k].x & mk; by |= RB[k].y & mk; qx |= RQ[k].x & mk; qy |= RQ[k].y & mk;
+                }
+                bo = make_uint2(bx, by); qo = make_uint2(qx, qy);
+            };
+            uint2 bw, qw, bn, qn;
+            if constexpr (NCH > 0) {
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    RB[k] = make_uint2(0u, 0u); RQ[k] = make_uint2(0u, 0u);
+                    if (k < nchunk) { RB[k] = *reinterpret_cast<const uint2*>(rb + (k << 3)); RQ[k] = *reinterpret_cast<const uint2*>(rq + (k << 3)); }
+                }
+                pick(chunk, bw, qw);
+                bn = bw; qn = qw;
+            } else {
+                bw = *reinterpret_cast<const uint2*>(rb + (chunk << 3)); qw = *reinterpret_cast<const uint2*>(rq + (chunk << 3));
+                bn = bw; qn = qw;
+                int nc = chunk + cstep; if (nc >= 0 && nc < nchunk) { bn = *reinterpret_cast<const uint2*>(rb + (nc << 3)); qn = *reinterpret_cast<const uint2*>(rq + (nc << 3)); }
+            }
             // one DP row.  EDGE = the row touches column L, row L or column -1 (the first 4 and the last 3 rows); the rows in
             // between - nearly all of them - need none of those tests
             auto dp_row = [&](const int i, auto edge_tag) {
@@ -2133,9 +2218,12 @@ __global__ void __launch_bounds__(256, GM_NW_OCC) k_nw_lane(GmDevIndex ix, GmDev
                 const int src = strand ? Li - 1 - i : i;
                 if ((src >> 3) != chunk) {
                     chunk = src >> 3;
-                    bw = bn; qw = qn;
-                    int nc = chunk + cstep;
-                    if (nc >= 0 && nc < nchunk) { bn = *reinterpret_cast<const uint2*>(rb + (nc << 3)); qn = *reinterpret_cast<const uint2*>(rq + (nc << 3)); }
+                    if constexpr (NCH > 0) pick(chunk, bw, qw);
+                    else {
+                        bw = bn; qw = qn;
+                        int nc = chunk + cstep;
+                        if (nc >= 0 && nc < nchunk) { bn = *reinterpret_cast<const uint2*>(rb + (nc << 3)); qn = *reinterpret_cast<const uint2*>(rq + (nc << 3)); }
+                    }
                 }
                 const uint32_t sh = (uint32_t)(src & 3) << 3;
                 const uint32_t ch = (((src & 4) ? bw.y : bw.x) >> sh) & 255u;
@@ -2200,6 +2288,25 @@ __global__ void __launch_bounds__(256, GM_NW_OCC) k_nw_lane(GmDevIndex ix, GmDev
     }
     gm_count(b, GMK_NW_CELLS, cells);
     gm_count(b, GMK_ACCEPTED, accepted);
+}
+
+// candidates the one-wave vote kernels left in their own slots -> the shards the DP kernel reads: one thread per read x strand, the
+// wave's candidates are counted by a scan and reserved with ONE atomic (64 read x strands per atomic instead of one each, and no
+// vote wave waits for it).  A wave's candidates stay together: 64 consecutive candidates belong to ~60 consecutive reads, so the
+// DP kernel's lanes and the hit scatter touch neighbouring rows.
+__global__ void __launch_bounds__(256) k_cand_gather(GmDevBatch b) {
+    const uint32_t rs = blockIdx.x * 256 + threadIdx.x;
+    const int lane = gm_lane();
+    uint32_t c = rs < 2 * b.n ? b.fixed_cnt[rs] : 0u;
+    const uint32_t incl = gm_wave_scan_incl(c);
+    const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+    if (total == 0u) return;                             // wave-uniform
+    const uint32_t shard = (rs >> 6) & (GM_NSHARD - 1);
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&b.shard_cnt[shard * GM_SHARD_STRIDE], total);
+    base = __builtin_amdgcn_readfirstlane(base) + incl - c;
+    for (uint32_t k = 0; k < c; ++k)
+        if (base + k < b.cand_region) b.cands[(size_t)shard * b.cand_region + base + k] = b.fixed_cands[(size_t)rs * GM_FIXED_C + k];
 }
 
 __global__ void __launch_bounds__(256) k_scatter_hits(GmDevBatch b) {
@@ -2706,6 +2813,12 @@ int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, in
     return (int)hipGetLastError();
 }
 
+int gmk_cand_gather(const GmDevBatch& b, void* stream) {
+    if (b.n == 0 || !b.fixed_cands) return 0;
+    hipLaunchKernelGGL(k_cand_gather, dim3(cdiv(2ull * b.n, 256)), dim3(256), 0, S_(stream), b);
+    return (int)hipGetLastError();
+}
+
 int gmk_vote_retry(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, uint32_t j0, uint32_t n_retry, void* stream) {
     if (n_retry == 0) return 0;
     hipLaunchKernelGGL(k_vote_retry, dim3(n_retry), dim3(256), 0, S_(stream), ix, p, b, use_full_sa, j0, n_retry);
@@ -2722,7 +2835,13 @@ int gmk_nw(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint
         // 16384 5.6 ms), more, smaller ones pay their set-up (LDS tables, shard prefix) too often (2 M candidates: 0.77 against 1.02 ms)
         static const uint32_t nw_fixed = [] { const char* e = getenv("GM_NW_GRID"); return e ? (uint32_t)atoi(e) : 0u; }();
         uint32_t nw_grid = nw_fixed ? nw_fixed : std::min<uint32_t>(16384u, std::max<uint32_t>(2048u, n_cands / 1024u));
-        hipLaunchKernelGGL(k_nw_lane, dim3(nw_grid), dim3(256), 0, S_(stream), ix, p, b);
+        // rows in registers while the candidates are sparse (about one per read: every candidate touches its own lines); with several
+        // candidates per read (dense seeds) neighbouring lanes share the lines and the streaming form with its 5 waves per SIMD wins
+        // (measured at configs[1], 4.3 candidates per read: 2.8 against 3.2 ms).  GM_NW_ROWS=0: streaming form always
+        static const int rows_in_regs = [] { const char* e = getenv("GM_NW_ROWS"); return e ? atoi(e) : 1; }();
+        if (rows_in_regs && n_cands < 2.5 * b.n && b.stride <= 104) hipLaunchKernelGGL(k_nw_lane<13>, dim3(nw_grid), dim3(256), 0, S_(stream), ix, p, b);
+        else if (rows_in_regs && n_cands < 2.5 * b.n && b.stride <= 152) hipLaunchKernelGGL(k_nw_lane<19>, dim3(nw_grid), dim3(256), 0, S_(stream), ix, p, b);
+        else hipLaunchKernelGGL(k_nw_lane<0>, dim3(nw_grid), dim3(256), 0, S_(stream), ix, p, b);
         return (int)hipGetLastError();
     }
     uint32_t Lp = lp_of(b.stride);
