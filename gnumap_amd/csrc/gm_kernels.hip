@@ -279,23 +279,21 @@ __global__ void __launch_bounds__(256) k_prep(GmDevIndex ix, GmDevParams p, GmDe
     __shared__ float s_term[2][10][128];                   // [phred table][char class][quality character & 127]
     __shared__ uint8_t s_cls[256];
     const float4* const S4 = reinterpret_cast<const float4*>(p.S256);
+    __shared__ int s_other_uniform;
+    if (threadIdx.x == 0) s_other_uniform = 1;
+    __syncthreads();
     {
+        // all characters outside ACGTacgt have the same row in the reference's table (transversion score for every base,
+        // a_matrices.c:55-83) unless a caller edited gm_params.S by hand (-S file): then those bases take the direct path
         const int ch = threadIdx.x;
         int cl = 8;
         switch (ch) { case 'A': cl = 0; break; case 'C': cl = 1; break; case 'G': cl = 2; break; case 'T': cl = 3; break;
                       case 'a': cl = 4; break; case 'c': cl = 5; break; case 'g': cl = 6; break; case 't': cl = 7; break; default: cl = 8; }
         s_cls[ch] = (uint8_t)cl;
-    }
-    __syncthreads();
-    // all characters outside ACGTacgt have the same row in the reference's table (transversion score for every base, a_matrices.c:55-83)
-    // unless a caller edited gm_params.S by hand: then class 9 marks "not uniform" and those bases take the direct path
-    __shared__ int s_other_uniform;
-    if (threadIdx.x == 0) {
-        int uni = 1;
-        const float4 r0 = S4[(int)'N'];
-        for (int ch = 0; ch < 256 && uni; ++ch)
-            if (s_cls[ch] == 8) { const float4 r = S4[ch]; if (r.x != r0.x || r.y != r0.y || r.z != r0.z || r.w != r0.w) uni = 0; }
-        s_other_uniform = uni;
+        if (cl == 8) {
+            const float4 r0 = S4[(int)'N'], r = S4[ch];
+            if (r.x != r0.x || r.y != r0.y || r.z != r0.z || r.w != r0.w) atomicAnd(&s_other_uniform, 0);
+        }
     }
     for (int e = threadIdx.x; e < 2 * 9 * 128; e += 256) {
         const int tab = e / (9 * 128), cl = (e / 128) % 9, qc = e & 127;
