@@ -97,7 +97,7 @@ struct gm_batch {
     uint32_t max_reads = 0, max_len = 0;
     uint32_t n = 0, stride = 0, max_seeds = 0, illumina_until = 0;
     DevBuf bases, quals, len, status, self_score, min_score, top_score, seeds, n_seeds, n_entries, entry_off, coords,
-        rs_overflow, retry_list, retry_off, gtab_keys, gtab_vals, cands, fixed_cands, fixed_cnt, hit_count, hit_begin, hit_cursor, raw_hits, counters, small, shards, big_list,
+        rs_overflow, retry_list, retry_off, gtab_keys, gtab_vals, cands, fixed_cands, fixed_cnt, heavy_list, heavy_off, heavy_k0, heavy_k1, heavy_tmp, hit_count, hit_begin, hit_cursor, raw_hits, counters, small, shards, big_list,
         tb_items, tb_ops, tb_len, dep_pos, dep_span, dep_w, dep_codes, dep_coff,
         // grouping (process_hits' unique map) and output stage, gm_output.hip
         g_sorted, g_ord, g_lead, g_krank, g_khash, g_nmatch, g_mbegin, g_multi, g_matches, g_mhit, g_positions, scan_tmp,
@@ -450,7 +450,7 @@ extern "C" void gm_batch_destroy(gm_batch* b) {
     (void)hipSetDevice(b->ix->device);
     DevBuf* all[] = { &b->bases, &b->quals, &b->len, &b->status, &b->self_score, &b->min_score, &b->top_score, &b->seeds, &b->n_seeds,
                       &b->n_entries, &b->entry_off, &b->coords, &b->rs_overflow, &b->retry_list, &b->retry_off, &b->gtab_keys, &b->gtab_vals,
-                      &b->cands, &b->fixed_cands, &b->fixed_cnt, &b->hit_count, &b->hit_begin, &b->hit_cursor, &b->raw_hits, &b->counters, &b->small, &b->shards, &b->big_list, &b->tb_items, &b->tb_ops,
+                      &b->cands, &b->fixed_cands, &b->fixed_cnt, &b->heavy_list, &b->heavy_off, &b->heavy_k0, &b->heavy_k1, &b->heavy_tmp, &b->hit_count, &b->hit_begin, &b->hit_cursor, &b->raw_hits, &b->counters, &b->small, &b->shards, &b->big_list, &b->tb_items, &b->tb_ops,
                       &b->tb_len, &b->dep_pos, &b->dep_span, &b->dep_w, &b->dep_codes, &b->dep_coff,
                       &b->g_sorted, &b->g_ord, &b->g_lead, &b->g_krank, &b->g_khash, &b->g_nmatch, &b->g_mbegin, &b->g_multi, &b->g_matches, &b->g_mhit, &b->g_positions,
                       &b->scan_tmp, &b->o_small, &b->o_posmatch, &b->o_post, &b->o_mapq, &b->o_emit, &b->o_reccnt, &b->o_cigcnt, &b->o_recoff, &b->o_cigoff,
@@ -701,6 +701,48 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         KCHK(gmk_scan_entries(b->dev, st));
         { KTimer t(b, GM_K_LOCATE, st); KCHK(gmk_locate_sampled(ix->dev, b->dev, st)); }
     }
+    // read x strands with very many SA hits (repeat seeds without -h) leave the ordinary vote kernels before they start: sorted-key
+    // path of gm_heavy.hip, routed by k_seed's own hit count.  GM_HEAVY_MIN / GM_HEAVY_BUDGET (keys per chunk) are test switches.
+    static const uint32_t heavy_min = [] { const char* e = getenv("GM_HEAVY_MIN"); return e ? (uint32_t)atoll(e) : 16384u; }();
+    static const uint64_t heavy_budget = [] { const char* e = getenv("GM_HEAVY_BUDGET"); return e ? (uint64_t)atoll(e) : (uint64_t)1 << 27; }();
+    std::vector<uint32_t> heavy;                     // {rs, n_seeds, SA hits} triples
+    {
+        if (b->heavy_list.ensure(3 * 2 * (size_t)b->n * 4 + 64)) return GM_E_NOMEM;
+        HIPCHK(hipMemsetAsync(b->small.as<uint32_t>() + 3, 0, 4, st));
+        KCHK(gmk_heavy_collect(b->dev, heavy_min, b->small.as<uint32_t>() + 3, b->heavy_list.as<uint32_t>(), st));
+        uint32_t nh = 0;
+        HIPCHK(hipMemcpyAsync(&nh, b->small.as<uint32_t>() + 3, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (nh) {
+            heavy.resize(3 * (size_t)nh);
+            HIPCHK(hipMemcpy(heavy.data(), b->heavy_list.p, heavy.size() * 4, hipMemcpyDeviceToHost));
+        }
+    }
+    auto run_heavy = [&]() -> int {                  // expand + sort + run-length vote, chunk by chunk under the key budget
+        const uint32_t nh = (uint32_t)(heavy.size() / 3);
+        std::vector<unsigned long long> off;
+        for (uint32_t j = 0; j < nh;) {
+            const uint32_t j0 = j;
+            unsigned long long acc = 0;
+            off.clear();
+            while (j < nh && j - j0 < 65536u) {
+                const unsigned long long e = heavy[3 * (size_t)j + 2];
+                if (e == 0xFFFFFFFFull || e > heavy_budget) { gm_set_error("a read x strand with more SA hits than one heavy-path chunk holds; use -h"); return GM_E_CAPACITY; }
+                if (acc + e > heavy_budget) break;
+                off.push_back(acc); acc += e; ++j;
+            }
+            const uint32_t nj = j - j0;
+            unsigned item_bits = 1; while ((1u << item_bits) < nj) ++item_bits;
+            const size_t tmp_bytes = gmk_heavy_sort_temp_bytes((size_t)acc);
+            if (b->heavy_k0.ensure((size_t)acc * 8 + 64) || b->heavy_k1.ensure((size_t)acc * 8 + 64) || b->heavy_tmp.ensure(tmp_bytes + 64) ||
+                b->heavy_off.ensure((size_t)nj * 8 + 64)) return GM_E_NOMEM;
+            HIPCHK(hipMemcpyAsync(b->heavy_off.p, off.data(), (size_t)nj * 8, hipMemcpyHostToDevice, st));
+            KCHK(gmk_heavy_chunk(ix->dev, dp, b->dev, use_full, b->heavy_list.as<uint32_t>(), j0, nj, b->heavy_off.as<unsigned long long>(),
+                                 b->heavy_k0.as<unsigned long long>(), b->heavy_k1.as<unsigned long long>(), acc, b->heavy_tmp.p, tmp_bytes, item_bits, st));
+            HIPCHK(hipStreamSynchronize(st));        // off[] and the key buffers are reused by the next chunk
+        }
+        return GM_OK;
+    };
     std::vector<uint32_t> shard_host((size_t)GM_NSHARD * GM_SHARD_STRIDE);
     auto read_shards = [&](uint64_t& total, uint32_t& mx) -> int {
         HIPCHK(hipMemcpyAsync(shard_host.data(), b->shards.p, shard_host.size() * 4, hipMemcpyDeviceToHost, st));
@@ -768,6 +810,13 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
                     HIPCHK(hipStreamSynchronize(st));        // off[] is reused by the next group
                 }
             }
+            rc = read_shards(total, mx);
+            if (rc) return rc;
+        }
+        if (!heavy.empty() && mx <= b->dev.cand_region) {
+            KTimer t(b, GM_K_VOTE_RETRY, st);
+            rc = run_heavy();
+            if (rc) return rc;
             rc = read_shards(total, mx);
             if (rc) return rc;
         }

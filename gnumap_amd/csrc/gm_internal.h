@@ -142,6 +142,12 @@ int gmk_scan_entries(const GmDevBatch& b, void* stream);
 int gmk_locate_sampled(const GmDevIndex& ix, const GmDevBatch& b, void* stream);
 int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, int dense, int slots_hint, void* stream);
 int gmk_cand_gather(const GmDevBatch& b, void* stream);
+// gm_heavy.hip: read x strands with more than heavy_min SA hits (sorted-key vote path)
+int gmk_heavy_collect(const GmDevBatch& b, uint32_t heavy_min, uint32_t* n_heavy, uint32_t* heavy_list /* {rs, n_seeds, SA hits} triples */, void* stream);
+size_t gmk_heavy_sort_temp_bytes(size_t n_keys);
+int gmk_heavy_chunk(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, const uint32_t* heavy_list, uint32_t j0, uint32_t nj,
+                    const unsigned long long* key_off, unsigned long long* keys0, unsigned long long* keys1, unsigned long long n_keys, void* tmp,
+                    size_t tmp_bytes, unsigned item_bits, void* stream);
 int gmk_vote_retry(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, uint32_t j0, uint32_t n_retry, void* stream);
 int gmk_nw(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint32_t n_cands, void* stream);
 int gmk_compact(const GmDevBatch& b, void* stream);
