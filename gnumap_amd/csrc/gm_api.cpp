@@ -15,6 +15,9 @@
 #include <thread>
 
 static thread_local std::string g_err;
+// GM_TRACE=1: one line per phase of the batch calls on stderr (what a long run is doing, with the sizes that explain it)
+static bool gm_trace_on() { static const bool on = [] { const char* e = getenv("GM_TRACE"); return e && atoi(e); }(); return on; }
+#define GM_TRACE(...) do { if (gm_trace_on()) { fprintf(stderr, "[gm_trace] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 void gm_set_error(const std::string& s) { g_err = s; }
 extern "C" const char* gm_last_error(void) { return g_err.c_str(); }
 extern "C" const char* gm_version(void) { return "gnumap-mi355x 0.1 (gfx950)"; }
@@ -713,6 +716,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         uint32_t nh = 0;
         HIPCHK(hipMemcpyAsync(&nh, b->small.as<uint32_t>() + 3, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        GM_TRACE("map_device: %u reads, seeds done, %u read x strands on the heavy path (> %u SA hits)", b->n, nh, heavy_min);
         if (nh) {
             heavy.resize(3 * (size_t)nh);
             HIPCHK(hipMemcpy(heavy.data(), b->heavy_list.p, heavy.size() * 4, hipMemcpyDeviceToHost));
@@ -740,6 +744,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
             KCHK(gmk_heavy_chunk(ix->dev, dp, b->dev, use_full, b->heavy_list.as<uint32_t>(), j0, nj, b->heavy_off.as<unsigned long long>(),
                                  b->heavy_k0.as<unsigned long long>(), b->heavy_k1.as<unsigned long long>(), acc, b->heavy_tmp.p, tmp_bytes, item_bits, st));
             HIPCHK(hipStreamSynchronize(st));        // off[] and the key buffers are reused by the next chunk
+            GM_TRACE("heavy chunk: items %u..%u of %u, %llu keys sorted", j0, j, nh, acc);
         }
         return GM_OK;
     };
@@ -830,6 +835,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
             continue;
         }
         b->n_cands = (uint32_t)total;
+        GM_TRACE("vote done: %llu candidates (attempt %d)", (unsigned long long)total, attempt);
         break;
     }
     if (b->raw_cap < b->n_cands + 16ull) b->raw_cap = b->n_cands + 16ull;
@@ -837,6 +843,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
     fill_dev_batch(b);
     { KTimer t(b, GM_K_NW, st); KCHK(gmk_nw(ix->dev, dp, b->dev, b->n_cands, st)); }
     { KTimer t(b, GM_K_COMPACT, st); KCHK(gmk_compact(b->dev, st)); }
+    if (gm_trace_on()) { HIPCHK(hipStreamSynchronize(st)); GM_TRACE("NW + compaction done"); }
     b->mapped = true;
     return GM_OK;
 }
@@ -1054,6 +1061,7 @@ extern "C" int gm_map_batch(gm_index* ix, const gm_params* p, gm_batch* b, const
     HIPCHK(hipMemcpyAsync(out->match_begin, g.match_begin, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     pc.lap("group");
+    GM_TRACE("grouping done: %llu accepted hits -> %llu matches", (unsigned long long)n_hits, (unsigned long long)n_m);
     if (n_m > out->matches_cap || n_hits > out->positions_cap) {
         out->matches_cap = n_m; out->positions_cap = n_hits;
         gm_set_error("output buffers too small");

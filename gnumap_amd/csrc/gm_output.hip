@@ -180,21 +180,33 @@ __global__ void __launch_bounds__(64) k_group_multi(GmDevIndex ix, GmDevBatch b,
             }
             __syncthreads();
         }
-        // 4. rank of every key among the read's keys (std::map<string> order)
+        // 4. number of keys first: a read beyond -T is READ_TOO_MANY whatever the order of its keys is (the map only grows, so the
+        //    check after the last seed decides, align_seq2_raw.cpp:299-306) - and ranking thousands of repeat copies would be the
+        //    one quadratic step with full key compares
         uint32_t my_leaders = 0;
-        for (uint32_t s = lane; s < k; s += 64) {
-            if (g.lead[hb + s] != s) continue;
-            ++my_leaders;
-            const GmRawHit h = srt[s];
-            uint32_t rank = 0;
-            for (uint32_t t = 0; t < k; ++t)
-                if (t != s && g.lead[hb + t] == t && go_key_cmp(ix.pac, L, srt[t].pos, srt[t].strand, h.pos, h.strand) < 0) ++rank;
-            g.krank[hb + s] = rank;
-        }
+        for (uint32_t s = lane; s < k; s += 64) my_leaders += g.lead[hb + s] == s ? 1u : 0u;
         if (my_leaders) atomicAdd(&s_cnt[0], my_leaders);
         __syncthreads();
         const uint32_t u = s_cnt[0];
-        if (nw && u > max_matches) too_many = true;                       // the map only grows, so the check after the last seed decides
+        if (nw && u > max_matches) too_many = true;
+        // 5. rank of every key among the read's keys (std::map<string> order): first words first, the whole key only on a tie
+        if (!too_many) {
+            for (uint32_t s = lane; s < k; s += 64)
+                if (g.lead[hb + s] == s) g.khash[hb + s] = go_key_word(ix.pac, srt[s].pos, L, srt[s].strand, 0);      // the hash has done its work
+            __syncthreads();
+            for (uint32_t s = lane; s < k; s += 64) {
+                if (g.lead[hb + s] != s) continue;
+                const GmRawHit h = srt[s];
+                const unsigned long long w0 = g.khash[hb + s];
+                uint32_t rank = 0;
+                for (uint32_t t = 0; t < k; ++t) {
+                    if (t == s || g.lead[hb + t] != t) continue;
+                    const unsigned long long wt = g.khash[hb + t];
+                    if (wt < w0 || (wt == w0 && go_key_cmp(ix.pac, L, srt[t].pos, srt[t].strand, h.pos, h.strand) < 0)) ++rank;
+                }
+                g.krank[hb + s] = rank;
+            }
+        }
         if (lane == 0) {
             if (too_many) { b.status[r] = 1; g.n_match[r] = 0; }
             else if (u == 0) { b.status[r] = 2; g.n_match[r] = 0; }
