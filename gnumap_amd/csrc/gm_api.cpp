@@ -17,7 +17,8 @@
 static thread_local std::string g_err;
 // GM_TRACE=1: one line per phase of the batch calls on stderr (what a long run is doing, with the sizes that explain it)
 static bool gm_trace_on() { static const bool on = [] { const char* e = getenv("GM_TRACE"); return e && atoi(e); }(); return on; }
-#define GM_TRACE(...) do { if (gm_trace_on()) { fprintf(stderr, "[gm_trace] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
+static double gm_trace_ms() { static const auto t0 = std::chrono::steady_clock::now(); return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+#define GM_TRACE(...) do { if (gm_trace_on()) { fprintf(stderr, "[gm_trace %9.1f ms] ", gm_trace_ms()); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 void gm_set_error(const std::string& s) { g_err = s; }
 extern "C" const char* gm_last_error(void) { return g_err.c_str(); }
 extern "C" const char* gm_version(void) { return "gnumap-mi355x 0.1 (gfx950)"; }
@@ -103,7 +104,7 @@ struct gm_batch {
         rs_overflow, retry_list, retry_off, gtab_keys, gtab_vals, cands, fixed_cands, fixed_cnt, heavy_list, heavy_off, heavy_k0, heavy_k1, heavy_tmp, hit_count, hit_begin, hit_cursor, raw_hits, counters, small, shards, big_list,
         tb_items, tb_ops, tb_len, dep_pos, dep_span, dep_w, dep_codes, dep_coff,
         // grouping (process_hits' unique map) and output stage, gm_output.hip
-        g_sorted, g_ord, g_lead, g_krank, g_khash, g_nmatch, g_mbegin, g_multi, g_matches, g_mhit, g_positions, scan_tmp,
+        g_sorted, g_ord, g_lead, g_krank, g_khash, g_nmatch, g_mbegin, g_multi, g_big, g_bigdone, g_sk0, g_sk1, g_si0, g_si1, g_matches, g_mhit, g_positions, scan_tmp,
         o_small, o_posmatch, o_post, o_mapq, o_emit, o_reccnt, o_cigcnt, o_recoff, o_cigoff, o_recs, o_pool, o_codes;
     PinBuf h_raw, h_top, h_hbegin, h_ord, h_post, h_mapq, h_emit, h_mhit;
     std::vector<double> h_exp;          // exp(score) of every accepted hit of the last gm_map_batch (reused by gm_output_batch)
@@ -455,7 +456,7 @@ extern "C" void gm_batch_destroy(gm_batch* b) {
                       &b->n_entries, &b->entry_off, &b->coords, &b->rs_overflow, &b->retry_list, &b->retry_off, &b->gtab_keys, &b->gtab_vals,
                       &b->cands, &b->fixed_cands, &b->fixed_cnt, &b->heavy_list, &b->heavy_off, &b->heavy_k0, &b->heavy_k1, &b->heavy_tmp, &b->hit_count, &b->hit_begin, &b->hit_cursor, &b->raw_hits, &b->counters, &b->small, &b->shards, &b->big_list, &b->tb_items, &b->tb_ops,
                       &b->tb_len, &b->dep_pos, &b->dep_span, &b->dep_w, &b->dep_codes, &b->dep_coff,
-                      &b->g_sorted, &b->g_ord, &b->g_lead, &b->g_krank, &b->g_khash, &b->g_nmatch, &b->g_mbegin, &b->g_multi, &b->g_matches, &b->g_mhit, &b->g_positions,
+                      &b->g_sorted, &b->g_ord, &b->g_lead, &b->g_krank, &b->g_khash, &b->g_nmatch, &b->g_mbegin, &b->g_multi, &b->g_big, &b->g_bigdone, &b->g_sk0, &b->g_sk1, &b->g_si0, &b->g_si1, &b->g_matches, &b->g_mhit, &b->g_positions,
                       &b->scan_tmp, &b->o_small, &b->o_posmatch, &b->o_post, &b->o_mapq, &b->o_emit, &b->o_reccnt, &b->o_cigcnt, &b->o_recoff, &b->o_cigoff,
                       &b->o_recs, &b->o_pool, &b->o_codes };
     for (DevBuf* d : all) d->release();
@@ -1037,11 +1038,14 @@ extern "C" int gm_map_batch(gm_index* ix, const gm_params* p, gm_batch* b, const
     if (b->g_sorted.ensure(nh * sizeof(GmRawHit)) || b->g_ord.ensure(nh * 4) || b->g_lead.ensure(nh * 4) || b->g_krank.ensure(nh * 4) ||
         b->g_khash.ensure(nh * 8) || b->g_positions.ensure(nh * sizeof(GmDevPos)) || b->g_matches.ensure(nh * sizeof(GmDevMatch)) || b->g_mhit.ensure(nh * 4) ||
         b->g_nmatch.ensure((size_t)n * 4) || b->g_mbegin.ensure(((size_t)n + 1) * 8) || b->g_multi.ensure((size_t)n * 4 + 64) ||
+        b->g_big.ensure((size_t)n * 4 + 64) || b->g_bigdone.ensure((size_t)n + 64) || b->g_sk0.ensure(nh * 8) || b->g_sk1.ensure(nh * 8) || b->g_si0.ensure(nh * 4) || b->g_si1.ensure(nh * 4) ||
         b->scan_tmp.ensure(((size_t)n / 1024 + 8) * 8) || b->o_small.ensure(64)) return GM_E_NOMEM;
     GmDevGroup g;
     g.sorted = b->g_sorted.as<GmRawHit>(); g.ord_score = b->g_ord.as<float>(); g.lead = b->g_lead.as<uint32_t>(); g.krank = b->g_krank.as<uint32_t>();
     g.khash = b->g_khash.as<unsigned long long>(); g.n_match = b->g_nmatch.as<uint32_t>(); g.match_begin = b->g_mbegin.as<uint64_t>();
     g.multi_list = b->g_multi.as<uint32_t>(); g.n_multi = b->o_small.as<uint32_t>();
+    g.big_list = b->g_big.as<uint32_t>(); g.n_big = b->o_small.as<uint32_t>() + 1; g.big_done = b->g_bigdone.as<uint8_t>();
+    g.sk0 = b->g_sk0.as<unsigned long long>(); g.sk1 = b->g_sk1.as<unsigned long long>(); g.si0 = b->g_si0.as<uint32_t>(); g.si1 = b->g_si1.as<uint32_t>();
     g.matches = b->g_matches.as<GmDevMatch>(); g.match_hit = b->g_mhit.as<uint32_t>(); g.positions = b->g_positions.as<GmDevPos>();
     b->cache_hits = b->cache_matches = 0;
     HIPCHK(hipMemsetAsync(b->o_small.p, 0, 64, st));

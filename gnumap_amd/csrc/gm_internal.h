@@ -43,6 +43,7 @@ struct GmDevParams {
 struct GmSeed { uint32_t k, l, pos; };
 
 #define GM_FIXED_C 4
+#define GM_GROUP_BIG 64          // accepted hits per read above which grouping takes the hash-set + sort path
 #define GM_NSHARD 1024
 #define GM_SHARD_STRIDE 32
 
@@ -121,8 +122,12 @@ struct GmDevGroup {
     unsigned long long* khash;
     uint32_t* n_match;              // n: matches of a read (0 unless its status stays OK)
     uint64_t* match_begin;          // n+1: exclusive scan of n_match
-    uint32_t* multi_list;           // reads with >= 2 accepted hits
+    uint32_t* multi_list;           // reads with 2 .. GM_GROUP_BIG accepted hits (and the ones the big path hands back)
     uint32_t* n_multi;
+    uint32_t* big_list;             // reads with more accepted hits: hash-set + sort path (k_group_big), linear in the hits
+    uint32_t* n_big;
+    uint8_t* big_done;              // per big_list entry: 1 = grouped by the big path (k_group_write_big finishes it)
+    unsigned long long* sk0; unsigned long long* sk1; uint32_t* si0; uint32_t* si1;     // sort scratch, per hit
     GmDevMatch* matches;
     uint32_t* match_hit;            // per match: index (in the hit CSR, processing order) of the hit that gave the match its score
     GmDevPos* positions;            // same CSR as the hits (a read's positions live in [hit_begin[r], hit_begin[r+1]))

@@ -14,6 +14,7 @@
 // denominator += exp(score) in processing order, posterior = exp(score) / denominator, MAPQ = round(-10 log10(1 - p)).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include "gm_internal.h"
 
 namespace {
@@ -100,7 +101,7 @@ __device__ __forceinline__ bool go_hit_less(const GmRawHit& a, const GmRawHit& b
 // ------------------------------------------------------------------------------------------------
 // grouping, pass 1: reads with 0 or 1 accepted hits are finished by one thread; the others go to a list
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_group_single(GmDevBatch b, GmDevGroup g, int nw, uint32_t max_matches) {
+__global__ void __launch_bounds__(256) k_group_single(GmDevBatch b, GmDevGroup g, int nw, uint32_t max_matches, uint32_t big_min) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= b.n) return;
     const uint64_t hb = b.hit_begin[r];
@@ -114,8 +115,9 @@ __global__ void __launch_bounds__(256) k_group_single(GmDevBatch b, GmDevGroup g
             if (nw && 1u > max_matches) b.status[r] = 1;                  // unique.size() > gMAX_MATCHES (align_seq2_raw.cpp:299-306)
             else nm = 1;
         } else {
-            g.multi_list[atomicAdd(g.n_multi, 1u)] = r;
-            return;                                                      // n_match is written by k_group_multi
+            if (k > big_min) { const uint32_t at = atomicAdd(g.n_big, 1u); g.big_list[at] = r; g.big_done[at] = 0; }
+            else g.multi_list[atomicAdd(g.n_multi, 1u)] = r;
+            return;                                                      // n_match is written by k_group_multi / k_group_big
         }
     }
     g.n_match[r] = nm;
@@ -211,6 +213,203 @@ __global__ void __launch_bounds__(64) k_group_multi(GmDevIndex ix, GmDevBatch b,
             if (too_many) { b.status[r] = 1; g.n_match[r] = 0; }
             else if (u == 0) { b.status[r] = 2; g.n_match[r] = 0; }
             else g.n_match[r] = u;
+        }
+        __syncthreads();
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// grouping of reads with MANY accepted hits (repeat copies: up to 10^5 .. 10^6 per read), linear in the hits instead of the
+// all-pairs steps of k_group_multi:
+//   * distinct keys are counted in an LDS hash set keyed by the 64-bit key hash, value = the smallest processing-order key among
+//     the hits with that hash.  More distinct hashes than -T means more distinct keys than -T: READ_TOO_MANY as soon as the count
+//     passes -T, after a few thousand insertions (what the reference finds out seed by seed, align_seq2_raw.cpp:299-306)
+//   * otherwise the hits are put in processing order by a wave-level LSD radix sort in HBM, the leader of a hit is found through the
+//     set (and verified on the 2-bit windows: a hash collision hands the read back to the all-pairs kernel), the few keys are ranked
+//     all-pairs, and a second sort by (key rank, position, strand) lays out the matches' position sets (k_group_write_big)
+// ------------------------------------------------------------------------------------------------
+#define GO_SET_SLOTS 4096u
+#define GO_SET_LIMIT 3000u
+
+// stable LSD radix sort (4-bit digits) of (key, value) pairs by one wavefront, ping-pong between (k0, v0) and (k1, v1); returns 0 / 1 =
+// which pair of buffers holds the result.  Needs blockDim.x == 64 (uses __syncthreads between passes).
+__device__ int go_wave_sort(unsigned long long* k0, uint32_t* v0, unsigned long long* k1, uint32_t* v1, uint32_t n, int nbits, int lane) {
+    unsigned long long* kin = k0; uint32_t* vin = v0; unsigned long long* kout = k1; uint32_t* vout = v1;
+    int cur = 0;
+    for (int shift = 0; shift < nbits; shift += 4) {
+        // histogram: lane d (< 16) ends up with the number of keys whose digit is d
+        uint32_t total = 0;
+        for (uint32_t base = 0; base < n; base += 64) {
+            const uint32_t i = base + lane;
+            const uint32_t dig = i < n ? (uint32_t)(kin[i] >> shift) & 15u : 16u;
+#pragma unroll
+            for (uint32_t d = 0; d < 16; ++d) {
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(dig == d);
+                if ((uint32_t)lane == d) total += (uint32_t)__popcll(m);
+            }
+        }
+        // exclusive prefix over the 16 digits (lanes 0..15)
+        uint32_t incl = (uint32_t)lane < 16u ? total : 0u;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+        uint32_t run = incl - ((uint32_t)lane < 16u ? total : 0u);       // lane d: where the next key with digit d goes
+        for (uint32_t base = 0; base < n; base += 64) {
+            const uint32_t i = base + lane;
+            unsigned long long key = 0; uint32_t val = 0;
+            uint32_t dig = 16u;
+            if (i < n) { key = kin[i]; val = vin[i]; dig = (uint32_t)(key >> shift) & 15u; }
+            uint32_t my_rank = 0;
+#pragma unroll
+            for (uint32_t d = 0; d < 16; ++d) {
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(dig == d);
+                const uint32_t start = __shfl(run, (int)d);
+                if (dig == d) my_rank = start + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if ((uint32_t)lane == d) run += (uint32_t)__popcll(m);
+            }
+            if (i < n) { kout[my_rank] = key; vout[my_rank] = val; }
+        }
+        __syncthreads();
+        unsigned long long* tk = kin; kin = kout; kout = tk;
+        uint32_t* tv = vin; vin = vout; vout = tv;
+        cur ^= 1;
+    }
+    return cur;
+}
+
+__global__ void __launch_bounds__(64) k_group_big(GmDevIndex ix, GmDevBatch b, GmDevGroup g, int nw, int unique_only, uint32_t max_matches) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_big[];
+    unsigned long long* s_keys = reinterpret_cast<unsigned long long*>(s_big);           // GO_SET_SLOTS hashes (0 = empty)
+    unsigned long long* s_vals = s_keys + GO_SET_SLOTS;                                  // smallest order key of the hash
+    uint32_t* s_lead = reinterpret_cast<uint32_t*>(s_vals + GO_SET_SLOTS);               // up to GO_SET_LIMIT leaders (sorted index)
+    __shared__ uint32_t s_n[4];                                                          // distinct hashes, leaders, flags
+    const int lane = threadIdx.x;
+    const uint32_t n_big = *g.n_big;
+    for (uint32_t li = blockIdx.x; li < n_big; li += gridDim.x) {
+        const uint32_t r = g.big_list[li];
+        const uint64_t hb = b.hit_begin[r];
+        const uint32_t k = (uint32_t)(b.hit_begin[r + 1] - hb);
+        const uint32_t L = b.len[r];
+        const GmRawHit* raw = b.raw_hits + hb;
+        GmRawHit* srt = g.sorted + hb;
+        auto hand_back = [&]() { if (lane == 0) g.multi_list[atomicAdd(g.n_multi, 1u)] = r; };    // the all-pairs kernel runs after this one
+        if (unique_only && !nw) { hand_back(); continue; }                // per-strand drop rule of --no_nw -u: rare, all-pairs kernel
+        for (uint32_t q = lane; q < GO_SET_SLOTS; q += 64) { s_keys[q] = 0ull; s_vals[q] = ~0ull; }
+        if (lane < 4) s_n[lane] = 0;
+        __syncthreads();
+        const uint32_t limit = nw && max_matches < GO_SET_LIMIT ? max_matches : GO_SET_LIMIT;
+        // 1. hash + processing-order key of every hit; distinct hashes into the set (stops as soon as the count passes the limit)
+        for (uint32_t base = 0; base < k; base += 64) {
+            const uint32_t a = base + lane;
+            if (a < k) {
+                const GmRawHit h = raw[a];
+                const unsigned long long hs = go_key_hash(ix.pac, h.pos, L, h.strand) | 1ull;
+                const unsigned long long ok = nw ? ((unsigned long long)h.strand << 48) | ((unsigned long long)h.step << 32) | h.pos
+                                                 : ((unsigned long long)h.strand << 48) | h.pos;
+                g.khash[hb + a] = hs; g.sk0[hb + a] = ok; g.si0[hb + a] = a;
+                uint32_t slot = (uint32_t)(hs >> 17) & (GO_SET_SLOTS - 1u);
+                for (uint32_t probe = 0; probe < GO_SET_SLOTS; ++probe) {
+                    const unsigned long long old = atomicCAS(&s_keys[slot], 0ull, hs);
+                    if (old == 0ull) atomicAdd(&s_n[0], 1u);
+                    if (old == 0ull || old == hs) { atomicMin(&s_vals[slot], ok); break; }
+                    slot = (slot + 1u) & (GO_SET_SLOTS - 1u);
+                }
+            }
+            __syncthreads();
+            if (s_n[0] > limit) break;                                    // uniform: read after the barrier
+        }
+        __syncthreads();
+        const uint32_t distinct = s_n[0];
+        if (distinct > limit) {
+            if (nw && limit == max_matches) {                             // more distinct keys than -T: READ_TOO_MANY (Driver.cpp:512-525)
+                if (lane == 0) { b.status[r] = 1; g.n_match[r] = 0; g.big_done[li] = 1; }
+            } else hand_back();                                           // more keys than the set holds and no -T to stop at: all-pairs kernel
+            continue;
+        }
+        // 2. processing order
+        const int where = go_wave_sort(g.sk0 + hb, g.si0 + hb, g.sk1 + hb, g.si1 + hb, k, 52, lane);
+        const unsigned long long* sk = (where ? g.sk1 : g.sk0) + hb;
+        const uint32_t* si = (where ? g.si1 : g.si0) + hb;
+        unsigned long long* spare_k = (where ? g.sk0 : g.sk1) + hb;
+        for (uint32_t i = lane; i < k; i += 64) { const GmRawHit h = raw[si[i]]; srt[i] = h; g.ord_score[hb + i] = h.score; }
+        __syncthreads();
+        // 3. leader of every hit = the hit with the smallest order key among those with its hash (verified on the windows)
+        bool dup = false, collide = false;
+        for (uint32_t i = lane; i < k; i += 64) {
+            const unsigned long long hs = g.khash[hb + si[i]];
+            uint32_t slot = (uint32_t)(hs >> 17) & (GO_SET_SLOTS - 1u);
+            while (s_keys[slot] != hs) slot = (slot + 1u) & (GO_SET_SLOTS - 1u);
+            const unsigned long long lk = s_vals[slot];
+            uint32_t lo = 0, hi = k - 1;                                  // order keys are unique: binary search for the leader's place
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sk[mid] < lk) lo = mid + 1; else hi = mid; }
+            const GmRawHit h = srt[i], hl = srt[lo];
+            if (lo != i && go_key_cmp(ix.pac, L, hl.pos, hl.strand, h.pos, h.strand) != 0) collide = true;
+            g.lead[hb + i] = lo;
+            if (lo != i) dup = true;
+            else { const uint32_t at = atomicAdd(&s_n[1], 1u); if (at < GO_SET_LIMIT) s_lead[at] = i; }
+        }
+        __syncthreads();
+        if (__builtin_amdgcn_ballot_w64(collide) != 0ull || s_n[1] != distinct) { hand_back(); continue; }     // two keys under one hash: all-pairs kernel
+        if (unique_only && nw && __builtin_amdgcn_ballot_w64(dup) != 0ull) {     // -u: an existing key -> READ_TOO_MANY (align_seq2_raw.cpp:146-152)
+            if (lane == 0) { b.status[r] = 1; g.n_match[r] = 0; g.big_done[li] = 1; }
+            continue;
+        }
+        // 4. rank of the (few) keys in std::map<string> order: first words first, the whole key on a tie
+        for (uint32_t q = lane; q < distinct; q += 64) { const GmRawHit h = srt[s_lead[q]]; spare_k[q] = go_key_word(ix.pac, h.pos, L, h.strand, 0); }
+        __syncthreads();
+        for (uint32_t q = lane; q < distinct; q += 64) {
+            const uint32_t i = s_lead[q];
+            const GmRawHit h = srt[i];
+            const unsigned long long w0 = spare_k[q];
+            uint32_t rank = 0;
+            for (uint32_t t = 0; t < distinct; ++t) {
+                if (t == q) continue;
+                const unsigned long long wt = spare_k[t];
+                if (wt < w0) ++rank;
+                else if (wt == w0) { const GmRawHit ht = srt[s_lead[t]]; if (go_key_cmp(ix.pac, L, ht.pos, ht.strand, h.pos, h.strand) < 0) ++rank; }
+            }
+            g.krank[hb + i] = rank;
+        }
+        if (lane == 0) { g.n_match[r] = distinct; g.big_done[li] = 1; }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(64) k_group_write_big(GmDevBatch b, GmDevGroup g) {
+    const int lane = threadIdx.x;
+    const uint32_t n_big = *g.n_big;
+    for (uint32_t li = blockIdx.x; li < n_big; li += gridDim.x) {
+        const uint32_t r = g.big_list[li];
+        if (!g.big_done[li] || g.n_match[r] == 0) continue;
+        const uint64_t hb = b.hit_begin[r], mb = g.match_begin[r];
+        const uint32_t k = (uint32_t)(b.hit_begin[r + 1] - hb);
+        const GmRawHit* srt = g.sorted + hb;
+        // second sort: (key rank, position, strand) = the matches in std::map order, each with its set<(pos,strand)> in order
+        for (uint32_t i = lane; i < k; i += 64) {
+            const GmRawHit h = srt[i];
+            g.sk0[hb + i] = ((unsigned long long)g.krank[hb + g.lead[hb + i]] << 33) | ((unsigned long long)h.pos << 1) | h.strand;
+            g.si0[hb + i] = i;
+        }
+        __syncthreads();
+        const int where = go_wave_sort(g.sk0 + hb, g.si0 + hb, g.sk1 + hb, g.si1 + hb, k, 48, lane);
+        const unsigned long long* sk = (where ? g.sk1 : g.sk0) + hb;
+        const uint32_t* si = (where ? g.si1 : g.si0) + hb;
+        for (uint32_t j = lane; j < k; j += 64) {
+            const uint32_t i = si[j];
+            const GmRawHit h = srt[i];
+            const uint32_t grp = (uint32_t)(sk[j] >> 33);
+            GmDevPos p; p.pos = h.pos; p.strand = h.strand; for (int q = 0; q < 7; ++q) p.pad[q] = 0;
+            g.positions[hb + j] = p;
+            GmDevMatch* m = g.matches + mb + grp;
+            if (j == 0 || (uint32_t)(sk[j - 1] >> 33) != grp) {
+                const uint32_t l = g.lead[hb + i];
+                const GmRawHit hl = srt[l];                               // the FIRST hit of a key gives the ScoredSeq its sequence, score and strand
+                m->read = b.read_base + r; m->score = hl.score; m->first_pos = hl.pos; m->first_strand = hl.strand;
+                m->pad[0] = m->pad[1] = m->pad[2] = 0; m->tail = 0;
+                m->pos_begin = (uint32_t)(hb + j);
+                g.match_hit[mb + grp] = (uint32_t)(hb + l);
+            }
+            if (j + 1 == k || (uint32_t)(sk[j + 1] >> 33) != grp) m->pos_end = (uint32_t)(hb + j + 1);
         }
         __syncthreads();
     }
@@ -435,7 +634,13 @@ static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b -
 
 int gmk_group_count(const GmDevIndex& ix, const GmDevBatch& b, const GmDevGroup& g, int nw, int unique_only, uint32_t max_matches, void* stream) {
     if (b.n == 0) return 0;
-    hipLaunchKernelGGL(k_group_single, dim3(cdiv(b.n, 256)), dim3(256), 0, S_(stream), b, g, nw, max_matches);
+    static const uint32_t big_min = [] { const char* e = getenv("GM_GROUP_BIG_MIN"); return e ? (uint32_t)atoi(e) : (uint32_t)GM_GROUP_BIG; }();     // test switch
+    hipLaunchKernelGGL(k_group_single, dim3(cdiv(b.n, 256)), dim3(256), 0, S_(stream), b, g, nw, max_matches, big_min);
+    {   // reads with many accepted hits first: what this kernel cannot finish goes to the all-pairs kernel's list
+        const size_t lds = (size_t)GO_SET_SLOTS * 16 + (size_t)GO_SET_LIMIT * 4 + 64;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_big), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipLaunchKernelGGL(k_group_big, dim3(std::min<uint32_t>(b.n, 4096u)), dim3(64), lds, S_(stream), ix, b, g, nw, unique_only, max_matches);
+    }
     hipLaunchKernelGGL(k_group_multi, dim3(std::min<uint32_t>(b.n, 16384u)), dim3(64), 0, S_(stream), ix, b, g, nw, unique_only, max_matches);
     return (int)hipGetLastError();
 }
@@ -444,6 +649,7 @@ int gmk_group_write(const GmDevBatch& b, const GmDevGroup& g, void* stream) {
     if (b.n == 0) return 0;
     hipLaunchKernelGGL(k_group_write_single, dim3(cdiv(b.n, 256)), dim3(256), 0, S_(stream), b, g);
     hipLaunchKernelGGL(k_group_write_multi, dim3(std::min<uint32_t>(b.n, 16384u)), dim3(64), 0, S_(stream), b, g);
+    hipLaunchKernelGGL(k_group_write_big, dim3(std::min<uint32_t>(b.n, 4096u)), dim3(64), 0, S_(stream), b, g);
     return (int)hipGetLastError();
 }
 

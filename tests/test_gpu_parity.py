@@ -420,9 +420,10 @@ _VARIANT_ORACLE = {}
                                  dict(GM_VOTE="block", GM_VOTE_SLOTS="0", GM_VOTE_FIXED="0"), dict(GM_VOTE="block", GM_VOTE_SLOTS="-1", GM_VOTE_FIXED="0"),   # candidates through the bump counters instead of own slots + k_cand_gather
                                  dict(GM_NW_ROWS="0"),
                                  dict(GM_HEAVY_MIN="64"), dict(GM_HEAVY_MIN="8", GM_HEAVY_BUDGET="200000"),      # sorted-key path for read x strands with many SA hits (several chunks)
-                                 dict(GM_HEAVY_MIN="64", GM_TEST_SAMPLED="1")],                                              # streaming DP rows instead of rows in registers
+                                 dict(GM_HEAVY_MIN="64", GM_TEST_SAMPLED="1"),
+                                 dict(GM_GROUP_BIG_MIN="1")],                                         # every read with >= 2 accepted hits through the hash-set + sort grouping                                              # streaming DP rows instead of rows in registers
                          ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()))
-@pytest.mark.parametrize("cfg", ["default", "no_nw", "k3", "h30", "m6_j2", "m20_j2", "k1"])
+@pytest.mark.parametrize("cfg", ["default", "no_nw", "k3", "h30", "m6_j2", "m20_j2", "k1", "T2", "unique", "unique_no_nw"])
 def test_every_kernel_variant_matches_oracle(env, cfg, syn_fa, oracle, oix, syn_reads, packed, tmp_path):
     """the dispatch heuristics pick kernels by seed density; force each variant on the same inputs and compare the result of
     gm_map_batch (status, self / top score, denominator, matches in key order, position sets) with the ORACLE, read by read"""
