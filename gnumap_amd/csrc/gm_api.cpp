@@ -1065,7 +1065,12 @@ extern "C" int gm_map_batch(gm_index* ix, const gm_params* p, gm_batch* b, const
     HIPCHK(hipMemcpyAsync(out->match_begin, g.match_begin, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     pc.lap("group");
-    GM_TRACE("grouping done: %llu accepted hits -> %llu matches", (unsigned long long)n_hits, (unsigned long long)n_m);
+    if (gm_trace_on()) {
+        uint32_t cnt[16] = { 0 };
+        HIPCHK(hipMemcpy(cnt, b->o_small.p, sizeof cnt, hipMemcpyDeviceToHost));
+        GM_TRACE("grouping done: %llu accepted hits -> %llu matches; reads: %u all-pairs list (incl. handed back), %u big path; handed back: %u (-u --no_nw), %u (> set limit), %u (hash collision)",
+                 (unsigned long long)n_hits, (unsigned long long)n_m, cnt[0], cnt[1], cnt[2], cnt[3], cnt[4]);
+    }
     if (n_m > out->matches_cap || n_hits > out->positions_cap) {
         out->matches_cap = n_m; out->positions_cap = n_hits;
         gm_set_error("output buffers too small");

@@ -66,13 +66,18 @@ __device__ __forceinline__ unsigned long long go_key_word(const uint8_t* pac, ui
     return k;
 }
 
+// 64-bit hash of a key.  Every word goes through a full-avalanche mixer (the murmur3 finaliser): repeat copies differ from each other
+// in a handful of bases, and with a multiply-only step a difference in the top bits of one word stays in the top bits and is cancelled
+// by a difference at the same place in the next word - near-identical windows then collide by the dozen (seen on a repeat-rich
+// reference: 53 reads of 2424 handed back for "collisions").
+__device__ __forceinline__ unsigned long long go_mix64(unsigned long long x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return x;
+}
 __device__ __forceinline__ unsigned long long go_key_hash(const uint8_t* pac, uint32_t pos, uint32_t L, uint32_t strand) {
     unsigned long long h = 0x243F6A8885A308D3ull;
     const uint32_t nw = (L + 31u) >> 5;
-    for (uint32_t j = 0; j < nw; ++j) {
-        h = (h ^ go_key_word(pac, pos, L, strand, j)) * 0x9E3779B97F4A7C15ull;
-        h ^= h >> 29;
-    }
+    for (uint32_t j = 0; j < nw; ++j) h = go_mix64(h ^ go_key_word(pac, pos, L, strand, j)) + 0x9E3779B97F4A7C15ull;
     return h;
 }
 
@@ -292,8 +297,8 @@ __global__ void __launch_bounds__(64) k_group_big(GmDevIndex ix, GmDevBatch b, G
         const uint32_t L = b.len[r];
         const GmRawHit* raw = b.raw_hits + hb;
         GmRawHit* srt = g.sorted + hb;
-        auto hand_back = [&]() { if (lane == 0) g.multi_list[atomicAdd(g.n_multi, 1u)] = r; };    // the all-pairs kernel runs after this one
-        if (unique_only && !nw) { hand_back(); continue; }                // per-strand drop rule of --no_nw -u: rare, all-pairs kernel
+        auto hand_back = [&](int why) { if (lane == 0) { g.multi_list[atomicAdd(g.n_multi, 1u)] = r; atomicAdd(g.n_big + 1 + why, 1u); } };    // the all-pairs kernel runs after this one; n_big[1..3] count the reasons
+        if (unique_only && !nw) { hand_back(0); continue; }                // per-strand drop rule of --no_nw -u: rare, all-pairs kernel
         for (uint32_t q = lane; q < GO_SET_SLOTS; q += 64) { s_keys[q] = 0ull; s_vals[q] = ~0ull; }
         if (lane < 4) s_n[lane] = 0;
         __syncthreads();
@@ -323,7 +328,7 @@ __global__ void __launch_bounds__(64) k_group_big(GmDevIndex ix, GmDevBatch b, G
         if (distinct > limit) {
             if (nw && limit == max_matches) {                             // more distinct keys than -T: READ_TOO_MANY (Driver.cpp:512-525)
                 if (lane == 0) { b.status[r] = 1; g.n_match[r] = 0; g.big_done[li] = 1; }
-            } else hand_back();                                           // more keys than the set holds and no -T to stop at: all-pairs kernel
+            } else hand_back(1);                                          // more keys than the set holds and no -T to stop at: all-pairs kernel
             continue;
         }
         // 2. processing order
@@ -349,7 +354,7 @@ __global__ void __launch_bounds__(64) k_group_big(GmDevIndex ix, GmDevBatch b, G
             else { const uint32_t at = atomicAdd(&s_n[1], 1u); if (at < GO_SET_LIMIT) s_lead[at] = i; }
         }
         __syncthreads();
-        if (__builtin_amdgcn_ballot_w64(collide) != 0ull || s_n[1] != distinct) { hand_back(); continue; }     // two keys under one hash: all-pairs kernel
+        if (__builtin_amdgcn_ballot_w64(collide) != 0ull || s_n[1] != distinct) { hand_back(2); continue; }    // two keys under one hash: all-pairs kernel
         if (unique_only && nw && __builtin_amdgcn_ballot_w64(dup) != 0ull) {     // -u: an existing key -> READ_TOO_MANY (align_seq2_raw.cpp:146-152)
             if (lane == 0) { b.status[r] = 1; g.n_match[r] = 0; g.big_done[li] = 1; }
             continue;
