@@ -10,6 +10,7 @@ _LIB = None
 GM_INDEX_FULL_SA, GM_INDEX_BUILD, GM_INDEX_HOST_ONLY = 1, 2, 4
 GM_READ_OK, GM_READ_TOO_MANY, GM_READ_NONE, GM_READ_TOO_SHORT, GM_READ_TOO_POOR = 0, 1, 2, -2, -3
 GM_E_CAPACITY = -5
+GM_E_BATCH_TOO_LARGE = -9
 
 u8p = C.POINTER(C.c_uint8)
 u64 = C.c_uint64

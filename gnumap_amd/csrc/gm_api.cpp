@@ -109,6 +109,7 @@ struct gm_batch {
     PinBuf h_raw, h_top, h_hbegin, h_ord, h_post, h_mapq, h_emit, h_mhit;
     std::vector<double> h_exp;          // exp(score) of every accepted hit of the last gm_map_batch (reused by gm_output_batch)
     uint64_t cache_hits = 0, cache_matches = 0;
+    const void* resume_ptr = nullptr;   // set when gm_map_batch returned GM_E_CAPACITY: the next call with the same reads resumes at the copies
     uint32_t cand_cap = 0;
     bool use_fixed = false;             // k_vote_tiny* leave their candidates in per read x strand slots (gathered by k_cand_gather)
     uint64_t raw_cap = 0;
@@ -510,7 +511,7 @@ extern "C" int gm_batch_upload(gm_batch* b, const gm_params* p, const gm_reads* 
     if (r->stride % 8 != 0) { gm_set_error("gm_reads.stride must be a multiple of 8"); return GM_E_ARG; }
     HIPCHK(hipSetDevice(b->ix->device));
     hipStream_t st = S_(stream);
-    b->n = r->n; b->stride = r->stride; b->mapped = false; b->cache_hits = b->cache_matches = 0;
+    b->n = r->n; b->stride = r->stride; b->mapped = false; b->cache_hits = b->cache_matches = 0; b->resume_ptr = nullptr;
     size_t bytes = (size_t)r->n * r->stride;
     if (b->bases.ensure(bytes + 16) || b->quals.ensure(bytes + 16) || b->len.ensure((size_t)r->n * 2 + 16)) return GM_E_NOMEM;
     b->len_host.assign(r->len, r->len + r->n);
@@ -732,7 +733,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
             off.clear();
             while (j < nh && j - j0 < 65536u) {
                 const unsigned long long e = heavy[3 * (size_t)j + 2];
-                if (e == 0xFFFFFFFFull || e > heavy_budget) { gm_set_error("a read x strand with more SA hits than one heavy-path chunk holds; use -h"); return GM_E_CAPACITY; }
+                if (e == 0xFFFFFFFFull || e > heavy_budget) { gm_set_error("a read x strand with more SA hits than one heavy-path chunk holds; use -h"); return GM_E_BATCH_TOO_LARGE; }
                 if (acc + e > heavy_budget) break;
                 off.push_back(acc); acc += e; ++j;
             }
@@ -805,7 +806,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
                     while (j < n_retry) {
                         size_t need = 2 * (size_t)nent[list[j]], sz = 1024;
                         while (sz < need && sz < 0x80000000u) sz <<= 1;
-                        if (sz > budget) { gm_set_error("a read x strand with more SA hits than the retry table budget; use -h"); return GM_E_CAPACITY; }
+                        if (sz > budget) { gm_set_error("a read x strand with more SA hits than the retry table budget; use -h"); return GM_E_BATCH_TOO_LARGE; }
                         if (acc + sz > budget) break;
                         off[j] = acc; acc += sz; ++j;
                     }
@@ -829,7 +830,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         if (mx > b->dev.cand_region) {                  // a candidate shard overflowed: grow the list and vote again
             if (attempt > 8) { gm_set_error("candidate list keeps overflowing"); return GM_E_NOMEM; }
             size_t want = ((size_t)mx + mx / 4 + 64) * GM_NSHARD;
-            if (want > 0x7FFFFFFFu) { gm_set_error("too many candidates in one batch; use smaller batches"); return GM_E_CAPACITY; }
+            if (want > 0x7FFFFFFFu) { gm_set_error("more than 2^31 candidates in one batch; map the block in smaller pieces (or use -h)"); return GM_E_BATCH_TOO_LARGE; }
             b->cand_cap = (uint32_t)want;
             if (b->cands.ensure((size_t)b->cand_cap * sizeof(GmCand))) return GM_E_NOMEM;
             fill_dev_batch(b);
@@ -1018,12 +1019,19 @@ static_assert(sizeof(gm_sam_rec) == sizeof(GmDevSamRec) && offsetof(gm_sam_rec, 
 extern "C" int gm_map_batch(gm_index* ix, const gm_params* p, gm_batch* b, const gm_reads* reads, gm_hits* out, void* stream) {
     if (!ix || !p || !b || !reads || !out) return GM_E_ARG;
     PhaseClock pc("gm_map_batch");
-    int rc = gm_batch_upload(b, p, reads, stream);
-    if (rc) return rc;
-    pc.lap("upload");
-    rc = gm_map_batch_device(ix, p, b, stream);
-    if (rc) return rc;
     hipStream_t st = S_(stream);
+    int rc;
+    // a call repeated with larger output buffers after GM_E_CAPACITY picks up where the first one stopped: the block is still mapped
+    // and grouped in HBM (same reads pointer, same count), only the copies to the host are left to do
+    const bool resume = b->resume_ptr != nullptr && b->resume_ptr == (const void*)reads->bases && b->n == reads->n;
+    b->resume_ptr = nullptr;
+    if (!resume) {
+        rc = gm_batch_upload(b, p, reads, stream);
+        if (rc) return rc;
+        pc.lap("upload");
+        rc = gm_map_batch_device(ix, p, b, stream);
+        if (rc) return rc;
+    } else HIPCHK(hipSetDevice(ix->device));
     const uint32_t n = b->n;
     out->n = n;
     if (n == 0) { out->match_begin[0] = 0; return GM_OK; }
@@ -1032,7 +1040,7 @@ extern "C" int gm_map_batch(gm_index* ix, const gm_params* p, gm_batch* b, const
     HIPCHK(hipStreamSynchronize(st));
     pc.lap("device");
     if (n_hits > b->raw_cap) { gm_set_error("internal: raw hit buffer too small"); return GM_E_CAPACITY; }
-    if (n_hits > 0xFFFFFFF0ull) { gm_set_error("more than 2^32 accepted hits in one batch; use smaller batches"); return GM_E_CAPACITY; }
+    if (n_hits > 0xFFFFFFF0ull) { gm_set_error("more than 2^32 accepted hits in one batch; map the block in smaller pieces"); return GM_E_BATCH_TOO_LARGE; }
     b->n_raw = n_hits;
     const size_t nh = (size_t)n_hits + 16;
     if (b->g_sorted.ensure(nh * sizeof(GmRawHit)) || b->g_ord.ensure(nh * 4) || b->g_lead.ensure(nh * 4) || b->g_krank.ensure(nh * 4) ||
@@ -1048,11 +1056,13 @@ extern "C" int gm_map_batch(gm_index* ix, const gm_params* p, gm_batch* b, const
     g.sk0 = b->g_sk0.as<unsigned long long>(); g.sk1 = b->g_sk1.as<unsigned long long>(); g.si0 = b->g_si0.as<uint32_t>(); g.si1 = b->g_si1.as<uint32_t>();
     g.matches = b->g_matches.as<GmDevMatch>(); g.match_hit = b->g_mhit.as<uint32_t>(); g.positions = b->g_positions.as<GmDevPos>();
     b->cache_hits = b->cache_matches = 0;
-    HIPCHK(hipMemsetAsync(b->o_small.p, 0, 64, st));
-    if (p->unique_only && !p->nw) HIPCHK(hipMemsetAsync(b->g_positions.p, 0, nh * sizeof(GmDevPos), st));      // dropped hits leave holes
-    KCHK(gmk_group_count(ix->dev, b->dev, g, p->nw, p->unique_only, p->max_matches, st));
-    KCHK(gmk_scan_u32(g.n_match, n, g.match_begin, b->scan_tmp.as<unsigned long long>(), st));
-    KCHK(gmk_group_write(b->dev, g, st));
+    if (!resume) {
+        HIPCHK(hipMemsetAsync(b->o_small.p, 0, 64, st));
+        if (p->unique_only && !p->nw) HIPCHK(hipMemsetAsync(b->g_positions.p, 0, nh * sizeof(GmDevPos), st));      // dropped hits leave holes
+        KCHK(gmk_group_count(ix->dev, b->dev, g, p->nw, p->unique_only, p->max_matches, st));
+        KCHK(gmk_scan_u32(g.n_match, n, g.match_begin, b->scan_tmp.as<unsigned long long>(), st));
+        KCHK(gmk_group_write(b->dev, g, st));
+    }
     // what the host pass needs: per-read status / top score, the CSR of the hits and their scores in processing order
     if (b->h_top.ensure((size_t)n * 4) || b->h_hbegin.ensure(((size_t)n + 1) * 8) || b->h_ord.ensure(nh * 4)) return GM_E_NOMEM;
     uint64_t n_m = 0;
@@ -1074,6 +1084,7 @@ extern "C" int gm_map_batch(gm_index* ix, const gm_params* p, gm_batch* b, const
     if (n_m > out->matches_cap || n_hits > out->positions_cap) {
         out->matches_cap = n_m; out->positions_cap = n_hits;
         gm_set_error("output buffers too small");
+        b->resume_ptr = (const void*)reads->bases;               // the repeated call only copies
         return GM_E_CAPACITY;
     }
     if (n_m) HIPCHK(hipMemcpyAsync(out->matches, g.matches, (size_t)n_m * sizeof(gm_match), hipMemcpyDeviceToHost, st));
@@ -1127,7 +1138,7 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
     const uint64_t n_m64 = n ? hits->match_begin[n] : 0;
     out->n_recs = 0; out->cigar_len = 0;
     if (n_m64 == 0) return GM_OK;
-    if (n_m64 > 0x7FFFFFFFull) { gm_set_error("too many matches in one batch"); return GM_E_CAPACITY; }
+    if (n_m64 > 0x7FFFFFFFull) { gm_set_error("too many matches in one batch; map the block in smaller pieces"); return GM_E_BATCH_TOO_LARGE; }
     const uint32_t n_m = (uint32_t)n_m64;
     // ---- host pass: ScoredSeq::get_SAM :300-309, is_greater :223-228, Driver.cpp:672-701 ----
     if (b->h_post.ensure((size_t)n_m * 4) || b->h_mapq.ensure((size_t)n_m * 4) || b->h_emit.ensure(n_m)) return GM_E_NOMEM;
@@ -1209,7 +1220,7 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
         gm_set_error("output buffers too small");
         return GM_E_CAPACITY;
     }
-    if (cig_len > 0xFFFFFFFFull) { gm_set_error("CIGAR pool beyond 4 GB in one batch; use smaller batches"); return GM_E_CAPACITY; }
+    if (cig_len > 0xFFFFFFFFull) { gm_set_error("CIGAR pool beyond 4 GB in one batch; map the block in smaller pieces"); return GM_E_BATCH_TOO_LARGE; }
     if (b->o_recs.ensure((size_t)(n_recs + 1) * sizeof(GmDevSamRec)) || b->o_pool.ensure((size_t)cig_len + 16)) return GM_E_NOMEM;
     if (n_recs) {
         KCHK(gmk_out_write(ix->dev, b->dev, d_m, d_p, n_m, b->o_emit.as<uint8_t>(), b->o_mapq.as<int32_t>(), b->o_post.as<float>(), b->tb_ops.as<unsigned long long>(),

@@ -394,6 +394,7 @@ static int process_block(Worker& w, const Options& o, Block& b) {
         hits.positions = w.positions.data(); hits.positions_cap = w.positions.size();
         int rc = gm_map_batch(w.ix, &bp, w.batch, &reads, &hits, w.stream);
         if (rc == GM_E_CAPACITY) { w.matches.ensure(hits.matches_cap + 64); w.positions.ensure(hits.positions_cap + 64); continue; }
+        if (rc == GM_E_BATCH_TOO_LARGE) { fprintf(stderr, "note: block of %u reads is mapped in halves (%s)\n", n, gm_last_error()); return rc; }
         if (rc != GM_OK) { fprintf(stderr, "ERROR: gm_map_batch: %s\n", gm_last_error()); return rc; }
         break;
     }
@@ -405,6 +406,7 @@ static int process_block(Worker& w, const Options& o, Block& b) {
         so.recs = b.recs.data(); so.recs_cap = b.recs.size(); so.cigar_pool = b.pool.data(); so.cigar_cap = b.pool.size();
         int rc = gm_output_batch(w.ix, &bp, w.batch, &reads, &hits, &so, w.stream);
         if (rc == GM_E_CAPACITY) { b.recs.ensure(so.recs_cap + 64); b.pool.ensure(so.cigar_cap + 64); continue; }
+        if (rc == GM_E_BATCH_TOO_LARGE) { fprintf(stderr, "note: block of %u reads is written in halves (%s)\n", n, gm_last_error()); return rc; }
         if (rc != GM_OK) { fprintf(stderr, "ERROR: gm_output_batch: %s\n", gm_last_error()); return rc; }
         break;
     }
@@ -412,6 +414,40 @@ static int process_block(Worker& w, const Options& o, Block& b) {
     w.t_pack += std::chrono::duration<double>(c1 - c0).count(); w.t_map += std::chrono::duration<double>(c2 - c1).count(); w.t_out += secs_since(c2);
     w.n_reads += n; w.n_records += so.n_recs;
     for (uint32_t i = 0; i < n; ++i) w.n_matched += (w.status[i] == GM_READ_OK || w.status[i] == GM_READ_TOO_MANY);
+    return GM_OK;
+}
+
+// a block whose intermediate lists outgrow one launch (GM_E_BATCH_TOO_LARGE: e.g. > 2^31 candidates on a repeat-rich reference
+// without -h) is mapped as two halves, recursively; the halves' records are put back together in read order
+static int process_block_split(Worker& w, const Options& o, Block& b, int depth) {
+    int rc = process_block(w, o, b);
+    if (rc != GM_E_BATCH_TOO_LARGE || b.n < 2 || depth > 20) return rc;
+    const uint32_t half = b.n / 2;
+    uint64_t total = 0; size_t pool_len = 0;
+    std::vector<gm_sam_rec> recs; std::vector<char> pool;
+    for (int part = 0; part < 2; ++part) {
+        const uint32_t lo = part ? half : 0, hi = part ? b.n : half;
+        Block c;
+        c.index = b.index; c.n = hi - lo; c.maxlen = b.maxlen; c.stride = b.stride; c.illumina = b.illumina;
+        c.name.assign(b.name.begin() + lo, b.name.begin() + hi); c.seq.assign(b.seq.begin() + lo, b.seq.begin() + hi);
+        c.qual.assign(b.qual.begin() + lo, b.qual.begin() + hi); c.name_len.assign(b.name_len.begin() + lo, b.name_len.begin() + hi);
+        c.qual_len.assign(b.qual_len.begin() + lo, b.qual_len.begin() + hi); c.len.assign(b.len.begin() + lo, b.len.begin() + hi);
+        if (part && b.illumina) {                           // the fallback may have happened inside the first half
+            for (uint32_t i = 0; i < half && c.illumina; ++i)
+                for (uint32_t t = 0; t < b.len[i]; ++t) if ((unsigned char)b.qual[i][t] < 64) { c.illumina = 0; break; }
+        }
+        rc = process_block_split(w, o, c, depth + 1);
+        if (rc != GM_OK) return rc;
+        for (uint64_t k = 0; k < c.n_recs; ++k) { gm_sam_rec r = c.recs[k]; r.read += lo; r.cigar_off += (uint32_t)pool_len; recs.push_back(r); }
+        size_t used = 0;
+        for (uint64_t k = 0; k < c.n_recs; ++k) used = std::max<size_t>(used, c.recs[k].cigar_off + strlen(c.pool.data() + c.recs[k].cigar_off) + 1);
+        pool.insert(pool.end(), c.pool.data(), c.pool.data() + used);
+        pool_len += used; total += c.n_recs;
+    }
+    b.recs.ensure(recs.size() + 1); b.pool.ensure(pool.size() + 1);
+    if (!recs.empty()) memcpy(b.recs.data(), recs.data(), recs.size() * sizeof(gm_sam_rec));
+    if (!pool.empty()) memcpy(b.pool.data(), pool.data(), pool.size());
+    b.n_recs = total; b.gpu = w.gpu;
     return GM_OK;
 }
 
@@ -496,7 +532,7 @@ int main(int argc, char** argv) {
             Worker& w = workers[k];
             Block* b;
             while (map_q.pop(b)) {
-                if (!failed && process_block(w, o, *b) != GM_OK) { failed = 1; }
+                if (!failed && process_block_split(w, o, *b, 0) != GM_OK) { failed = 1; }
                 if (failed) { b->failed = true; b->n_recs = 0; }
                 fmt_q.push(b);
             }

@@ -45,7 +45,9 @@ typedef enum {
     GM_E_UNSUPPORTED = -6,  /* e.g. reference longer than 2^32-2 bases (the reference's own `unsigned int vit`
                                loop, inc/align_seq2_raw.cpp:262, has the same limit) */
     GM_E_NOMEM = -7,
-    GM_E_BAD_QUAL = -8      /* negative base probability: reference throws "Invalid Fastq Character", SeqReader.cpp:1181-1189 */
+    GM_E_BAD_QUAL = -8,     /* negative base probability: reference throws "Invalid Fastq Character", SeqReader.cpp:1181-1189 */
+    GM_E_BATCH_TOO_LARGE = -9   /* the block's intermediate lists (candidates, SA hits of one read) exceed what one launch addresses:
+                                   map the block in smaller pieces (a repeat-rich reference without -h can yield > 2^31 candidates) */
 } gm_status;
 
 /* per-read status, the reference's sentinel values (inc/const_include.h:183-186) */

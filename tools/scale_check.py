@@ -146,6 +146,7 @@ def main(argv=None):
     ap.add_argument("--repeats", action="store_true", help="overlay SINE-/LINE-/satellite-like repeat families (28 %% of the genome)")
     ap.add_argument("--no-nw", action="store_true")
     ap.add_argument("--keep", action="store_true", help="keep the FASTA and the index files in --workdir")
+    ap.add_argument("--batch", type=int, default=0, help="map the reads in blocks of this many (0 = one block); repeat-rich references without -h need it")
     ap.add_argument("--jump", type=int, default=0)
     ap.add_argument("--mode", type=int, default=0, help="0 normal, 1 -b, 2 --b2, 3 -d")
     ap.add_argument("--check-output", type=int, default=0, help="reads whose gm_output_batch records and coverage / per-nucleotide deposits are compared with the oracle")
@@ -207,70 +208,88 @@ def main(argv=None):
 
     kw = dict(mer=a.mer, jump=a.jump, max_kmer_hits=a.max_kmer_hits, nw=0 if a.no_nw else 1, mode=a.mode)
     p = g.Params(**kw)
-    batch = g.Batch(ix, n, stride)
-    log("[scale] reads made; gm_map_batch ...")
-    res = batch.map(p, B, Q, Ln)                       # full host result (hit lists) for the checks
-    log("[scale] gm_map_batch done")
-    c = batch.counters()
-    mb = res["match_begin"]
-    # property: a read whose substitutions left it exact must have its origin among the reported positions (reads that ended as
-    # "too many" report nothing, like on the reference, and are not counted)
-    found = 0; checked = 0
-    P = res["positions"]
-    for i in np.flatnonzero(is_exact)[:2000]:
-        if res["status"][i] != 0:
-            continue
-        checked += 1
-        ms = res["matches"][int(mb[i]):int(mb[i + 1])]
-        ok = False
-        if len(ms):
-            lo, hi = int(ms["pos_begin"].min()), int(ms["pos_end"].max())
-            seg = P[lo:hi]
-            ok = bool(np.any((seg["pos"] == np.uint64(pos[i])) & (seg["strand"] == strand[i])))
-        found += ok
-    log("[scale] origin check done")
-    out.update(exact_reads_checked=checked, exact_reads_origin_found=found, mapped=int((res["status"] == 0).sum()) if "status" in res else None,
-               max_reported_pos=int(res["positions"]["pos"].max()) if len(res["positions"]) else 0)
-
-    # oracle sample
     from reflib import OracleLib
     orc = OracleLib()
-    t = time.time()
     oix = orc.index_load(fa)
     op = orc.params(**kw)
-    bad = 0
-    t_or = time.time()
     pick = rng.integers(0, n, a.sample)
-    for i in pick:
-        seq = B[i, :L].tobytes(); qual = Q[i, :L].tobytes()
-        o = orc.map_read(oix, op, orc.pwm(seq, qual), seq)
-        ms = res["matches"][int(mb[i]):int(mb[i + 1])]
-        same = res["status"][i] == o["status"] and res["denominator"][i] == o["denominator"] and res["top_score"][i] == o["top_score"] and len(ms) == len(o["hits"])
-        if same:
-            for m, hh in zip(ms, o["hits"]):
-                same &= np.float32(m["score"]).view(np.uint32) == np.float32(hh["score"]).view(np.uint32)
-                same &= [(int(q["pos"]), int(q["strand"])) for q in res["positions"][m["pos_begin"]:m["pos_end"]]] == [(int(x), int(y)) for x, y in hh["pos"]]
-        bad += not same
-    log("[scale] oracle sample done")
-    out.update(oracle_sample=int(a.sample), oracle_mismatches=int(bad), oracle_reads_per_s=round(a.sample / max(1e-9, time.time() - t_or), 1),
+    blk = a.batch if a.batch > 0 else n
+    found = checked = bad = mapped = 0
+    max_pos = 0
+    t_or = 0.0
+    batch = g.Batch(ix, min(blk, n), stride)
+    for s0 in range(0, n, blk):
+        s1 = min(n, s0 + blk)
+        log(f"[scale] gm_map_batch reads {s0}..{s1} ...")
+        res = batch.map(p, B[s0:s1], Q[s0:s1], Ln[s0:s1])          # full host result (hit lists) for the checks
+        log("[scale] gm_map_batch done")
+        mb = res["match_begin"]
+        mapped += int((res["status"] == 0).sum())
+        # property: a read whose substitutions left it exact must have its origin among the reported positions (reads that ended as
+        # "too many" report nothing, like on the reference, and are not counted)
+        P = res["positions"]
+        M = res["matches"]
+        if len(M):
+            max_pos = max(max_pos, int(max(int(P[m["pos_begin"]:m["pos_end"]]["pos"].max()) for m in M[:: max(1, len(M) // 2000)])))
+        ex = np.flatnonzero(is_exact[s0:s1])[: max(1, 2000 * (s1 - s0) // n)]
+        for i in ex:
+            if res["status"][i] != 0:
+                continue
+            checked += 1
+            ms = M[int(mb[i]):int(mb[i + 1])]
+            ok = False
+            if len(ms):
+                lo, hi = int(ms["pos_begin"].min()), int(ms["pos_end"].max())
+                seg = P[lo:hi]
+                ok = bool(np.any((seg["pos"] == np.uint64(pos[s0 + i])) & (seg["strand"] == strand[s0 + i])))
+            found += ok
+        # oracle sample
+        t0_ = time.time()
+        for gi in pick[(pick >= s0) & (pick < s1)]:
+            i = int(gi) - s0
+            seq = B[gi, :L].tobytes(); qual = Q[gi, :L].tobytes()
+            o = orc.map_read(oix, op, orc.pwm(seq, qual), seq)
+            ms = M[int(mb[i]):int(mb[i + 1])]
+            same = res["status"][i] == o["status"] and res["denominator"][i] == o["denominator"] and res["top_score"][i] == o["top_score"] and len(ms) == len(o["hits"])
+            if same:
+                for m, hh in zip(ms, o["hits"]):
+                    same &= np.float32(m["score"]).view(np.uint32) == np.float32(hh["score"]).view(np.uint32)
+                    same &= [(int(q["pos"]), int(q["strand"])) for q in P[m["pos_begin"]:m["pos_end"]]] == [(int(x), int(y)) for x, y in hh["pos"]]
+            bad += not same
+        t_or += time.time() - t0_
+        log("[scale] checks of the block done")
+    c = batch.counters()
+    out.update(exact_reads_checked=checked, exact_reads_origin_found=found, mapped=mapped, max_reported_pos=max_pos)
+    out.update(oracle_sample=int(a.sample), oracle_mismatches=int(bad), oracle_reads_per_s=round(a.sample / max(1e-9, t_or), 1),
                oracle_tail_reads=int((pos[pick] >= (1 << 31)).sum()))
 
     if a.check_output:
         out.update(check_output(g, ix, p, orc, oix, op, B, Q, Ln, L, pick[:a.check_output]))
 
-    # rate with the reads resident in HBM
-    batch.upload(p, B, Q, Ln)
-    batch.map_device(p)
-    batch.counters()                                   # reads the device counters back: waits for the launch stream
-    batch.kernel_times(); batch.set_profiling(True)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
+    # rate with the reads resident in HBM (block by block when --batch is set)
+    batch.set_profiling(False)
+    dt = 0.0
+    ktot = {}
+    sa_hits = cands = retries = 0
+    for s0 in range(0, n, blk):
+        s1 = min(n, s0 + blk)
+        batch.upload(p, B[s0:s1], Q[s0:s1], Ln[s0:s1])
         batch.map_device(p)
-    batch.counters()
-    dt = (time.perf_counter() - t0) / a.steps
-    out.update(reads=n, mer=p.mer, max_kmer_hits=p.max_kmer_hits, ms_per_step=round(dt * 1e3, 2), reads_per_s=round(n / dt, 1),
-               kernels_ms={k: round(ms / max(1, cnt) * (cnt / a.steps), 3) for k, (ms, cnt) in batch.kernel_times().items() if cnt},
-               sa_hits_per_read=round(c["sa_hits"] / n, 1), candidates_per_read=round(c["candidates"] / n, 2), vote_retries=c.get("vote_retries"))
+        batch.counters()                               # reads the device counters back: waits for the launch stream
+        batch.kernel_times(); batch.set_profiling(True)
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            batch.map_device(p)
+        cc = batch.counters()
+        dt += (time.perf_counter() - t0) / a.steps
+        for k_, (ms_, cnt_) in batch.kernel_times().items():
+            if cnt_:
+                ktot[k_] = ktot.get(k_, 0.0) + ms_ / a.steps
+        batch.set_profiling(False)
+        sa_hits += cc["sa_hits"]; cands += cc["candidates"]; retries += cc.get("vote_retries", 0)
+    out.update(reads=n, batch=blk, mer=p.mer, max_kmer_hits=p.max_kmer_hits, ms_per_step=round(dt * 1e3, 2), reads_per_s=round(n / dt, 1),
+               kernels_ms={k_: round(v_, 3) for k_, v_ in ktot.items()},
+               sa_hits_per_read=round(sa_hits / n, 1), candidates_per_read=round(cands / n, 2), vote_retries=retries)
     print(json.dumps(out), flush=True)
     batch.destroy(); ix.close()
     if not a.keep:
