@@ -78,7 +78,7 @@ SAM_DTYPE = np.dtype([("read", "<u4"), ("pos", "<u8"), ("contig", "<u4"), ("chr_
 
 # every symbol include/gnumap_hip.h declares
 EXPORTS = ["gm_last_error", "gm_version", "gm_index_build", "gm_index_build_on", "gm_index_open", "gm_index_close", "gm_index_get_info", "gm_index_contig_name",
-           "gm_index_contig_offset", "gm_index_window", "gm_params_default", "gm_params_finalize", "gm_batch_create", "gm_batch_destroy",
+           "gm_index_contig_offset", "gm_index_window", "gm_params_default", "gm_params_finalize", "gm_params_load_subst", "gm_batch_create", "gm_batch_destroy",
            "gm_batch_upload", "gm_map_batch_device", "gm_batch_counters", "gm_batch_set_profiling", "gm_batch_kernel_times", "gm_kernel_name",
            "gm_batch_raw_hits", "gm_stream_create", "gm_stream_destroy", "gm_host_alloc", "gm_host_free", "gm_map_batch", "gm_output_batch",
            "gm_dev_sa_interval", "gm_dev_locate", "gm_dev_nw_score", "gm_dev_traceback", "gm_coverage_reset", "gm_coverage_bins",
@@ -111,6 +111,7 @@ def load_library():
     L.gm_index_window.argtypes = [C.c_void_p, u64, C.c_uint32, C.c_char_p]
     L.gm_params_default.argtypes = [C.POINTER(gm_params)]; L.gm_params_default.restype = None
     L.gm_params_finalize.argtypes = [C.POINTER(gm_params)]
+    L.gm_params_load_subst.argtypes = [C.POINTER(gm_params), C.c_char_p]
     L.gm_batch_create.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
     L.gm_batch_destroy.argtypes = [C.c_void_p]; L.gm_batch_destroy.restype = None
     L.gm_batch_upload.argtypes = [C.c_void_p, C.POINTER(gm_params), C.POINTER(gm_reads), C.c_void_p]
@@ -178,6 +179,11 @@ class Params:
                 raise AttributeError(k)
             setattr(self.c, k, v)
         _chk(lib().gm_params_finalize(C.byref(self.c)))
+
+    def load_subst(self, path):
+        """-S / --subst_file: overwrite the lowercase rows of the score table from a 5 x 4 file (readPWM, Driver.cpp:768-859)"""
+        _chk(lib().gm_params_load_subst(C.byref(self.c), os.fsencode(path)))
+        return self
 
     def __getattr__(self, k):
         return getattr(self.c, k)

@@ -191,6 +191,38 @@ extern "C" int gm_params_finalize(gm_params* p) {
     return GM_OK;
 }
 
+extern "C" int gm_params_load_subst(gm_params* p, const char* path) {
+    if (!p || !path || !p->finalized) { gm_set_error("gm_params_load_subst: finalize the parameters first"); return GM_E_ARG; }
+    FILE* f = fopen(path, "r");
+    if (!f) { gm_set_error(std::string("cannot open substitution file ") + path); return GM_E_IO; }
+    float t[5][4];
+    char line[100], l0[100], l1[100], l2[100], l3[100];
+    int count = 0; bool labels = false;
+    auto next_line = [&]() -> bool {                           // ifstream::getline(buf, 100): at most 99 characters of a line
+        if (!fgets(line, sizeof line, f)) return false;
+        size_t n = strlen(line);
+        if (n && line[n - 1] == '\n') line[n - 1] = 0;
+        return true;
+    };
+    while (count < 5 && next_line()) {
+        if (sscanf(line, "%99s %99s %99s %99s", l0, l1, l2, l3) == 4 && tolower((unsigned char)l0[0]) == 'a' && tolower((unsigned char)l1[0]) == 'c') {
+            if (!next_line()) break;                           // the label line: rows carry a label from here on
+            labels = true;
+        }
+        float a, c, g, tt;
+        const int got = labels ? sscanf(line, "%99s %f %f %f %f", l0, &a, &c, &g, &tt) - 1 : sscanf(line, "%f %f %f %f", &a, &c, &g, &tt);
+        if (got != 4) { fclose(f); gm_set_error(std::string("Error in Score File: ") + line); return GM_E_IO; }
+        t[count][0] = a; t[count][1] = c; t[count][2] = g; t[count][3] = tt;
+        ++count;
+    }
+    fclose(f);
+    if (count < 5) { gm_set_error("Error in Score File:  Not enough lines"); return GM_E_IO; }
+    static const char rows[5] = { 'a', 'c', 'g', 't', 'n' };
+    for (int r = 0; r < 5; ++r) for (int b = 0; b < 4; ++b) p->S[(int)rows[r]][b] = t[r][b];
+    p->adjust = 1.0f;                                          // gADJUST = 1: "don't adjust the scores" (XA:f: prints score * 1 / gADJUST)
+    return GM_OK;
+}
+
 // Q -> (p, (1-p)/3) in fp32 exactly as SeqReader::get_more_fastq computes them (fp64 libm, then one cast):
 // Q2Prb_std src/SeqReader.cpp:623-627, Q2Prb_ill :618-622.  Negative p is stored as NaN.
 static void build_lut(float* lut /* 512 x 2 */) {

@@ -35,7 +35,7 @@
 #define MAX_NAME_SZ 1024        // inc/const_include.h:46
 
 struct Options {
-    std::string genome, output = "gnumap_out", reads;
+    std::string genome, output = "gnumap_out", reads, subst;
     gm_params p;
     int gpus = 1, locate_sampled = 0, verbose = 1;
     uint32_t batch = 262144;
@@ -60,6 +60,7 @@ static void usage(int rc, const char* msg) {
             "  -T, --max_match=INT          Maximum number of matches per read (default: 1000)\n"
             "  -u X                         Only match sequences to one position (like the reference, -u swallows the next word)\n"
             "  -G, --gap_penalty=DOUBLE     Gap penalty (default: -4)\n"
+            "  -S, --subst_file=STRING      5 x 4 substitution matrix file (rows a c g t n; scores are then used unscaled)\n"
             "  -c, --num_proc=INT           accepted for compatibility (the GPU path ignores it)\n"
             "  -b, --bs_seq / --b2 / -d, --a_to_g   bisulfite / A-to-G scoring\n"
             "      --no_nw                  use k-mer hit counts instead of Needleman-Wunsch alignments\n"
@@ -91,6 +92,7 @@ static void parse_args(int argc, char** argv, Options& o) {
             else if (starts(s, "max_match=")) o.p.max_matches = (uint32_t)atoi(s + 10);
             else if (starts(s, "max_kmer=")) o.p.max_kmer_hits = (uint32_t)atoi(s + 9);
             else if (starts(s, "gap_penalty=")) o.p.gap = (float)atof(s + 12);
+            else if (starts(s, "subst_file=")) o.subst = s + 11;
             else if (starts(s, "max_gap=")) o.p.max_gap = atoi(s + 8);
             else if (!strcmp(s, "unique")) o.p.unique_only = 1;
             else if (!strcmp(s, "print_all_sam")) o.p.print_all_sam = 1;
@@ -140,7 +142,8 @@ static void parse_args(int argc, char** argv, Options& o) {
             case '0': break;
             case 'j': o.p.jump = atoi(v); break;
             case 'k': o.p.min_seed_hits = atoi(v); break;
-            case 'l': case 'B': case 's': case 'A': case 'S': fprintf(stderr, "option -%c is outside the hot path of this build\n", c); exit(1);
+            case 'S': o.subst = v; break;
+            case 'l': case 'B': case 's': case 'A': fprintf(stderr, "option -%c is outside the hot path of this build\n", c); exit(1);
             case '?': usage(0, "");
             default: fprintf(stderr, "Irregular Parameter in: %s\n", a); exit(1);
         }
@@ -151,6 +154,7 @@ static void parse_args(int argc, char** argv, Options& o) {
     if ((o.p.mode == GM_MODE_BS || o.p.mode == GM_MODE_BS2) && !o.p.pos_strand) o.p.mode = GM_MODE_BS2;    // Driver.cpp:1260-1281
     if (o.p.mode == GM_MODE_ATOG && !o.p.pos_strand) o.p.mode = GM_MODE_ATOG2;
     if (gm_params_finalize(&o.p) != GM_OK) { fprintf(stderr, "%s\n", gm_last_error()); exit(1); }
+    if (!o.subst.empty() && gm_params_load_subst(&o.p, o.subst.c_str()) != GM_OK) { fprintf(stderr, "ERROR: \n\t%s\n", gm_last_error()); exit(1); }
     if (o.gpus < 1) o.gpus = 1;
     if (o.batch < 1) o.batch = 1;
     if (o.workers < 1) o.workers = 1;

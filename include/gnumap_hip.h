@@ -177,6 +177,10 @@ int gm_index_window(const gm_index*, uint64_t begin, uint32_t L, char* out);
 /* ---- parameters ---- */
 void gm_params_default(gm_params*);
 int gm_params_finalize(gm_params*);
+/* -S / --subst_file (readPWM, src/Driver.cpp:768-859; call AFTER gm_params_finalize): 5 rows (genome a, c, g, t, n) x 4 read bases,
+ * with or without the label line / row labels; overwrites the LOWERCASE rows of S unscaled, sets adjust = 1 (XA is then printed
+ * unscaled) and leaves the gap penalty as finalize scaled it - exactly what the reference does. */
+int gm_params_load_subst(gm_params*, const char* path);
 
 /* ---- batches: device-resident reads + workspace + raw results ---- */
 int gm_batch_create(gm_index*, uint32_t max_reads /* <= 16 000 000 */, uint32_t max_len /* <= 2048 */, gm_batch** out);

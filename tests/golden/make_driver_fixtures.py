@@ -56,6 +56,10 @@ MODES = {
     "illumina_fallback_first": (["--illumina"], dict(illumina=1), "syn.fq"),   # first read already shows Q < '@': Phred+33 throughout
     "illumina":       (["--illumina"], dict(illumina=1), "syn_ill.fq"),        # Phred+64 reads, then a fallback in mid-file
     "illumina_all":   (["--illumina", "--print_all_sam"], dict(illumina=1, print_all_sam=1), "syn_ill.fq"),
+    # -S: 5 x 4 substitution file (readPWM Driver.cpp:768-859); "_subst" is not a parameter field: the tests apply the file to the
+    # finalized parameters (OracleLib.apply_subst / gm_params_load_subst)
+    "subst_all":      (["-S", "subst.txt", "--print_all_sam"], dict(print_all_sam=1, _subst="subst.txt"), "syn.fq"),
+    "subst_bs":       (["-S", "subst.txt", "-b"], dict(mode=1, _subst="subst.txt"), "syn.fq"),
 }
 
 
@@ -90,6 +94,7 @@ def main():
         if f.startswith("syn."):
             shutil.copy(os.path.join(HERE, f), work)
     shutil.copy(ill, work)
+    shutil.copy(os.path.join(HERE, "subst.txt"), work)
     manifest = {}
     for name, (args, kw, fq) in MODES.items():
         argv = ["-g", "syn.fa", "-o", name, "-a", "0.9"] + args + [fq]

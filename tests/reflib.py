@@ -210,6 +210,25 @@ class OracleLib:
         self.lib.gmo_params_finalize(C.byref(p))
         return p
 
+    @staticmethod
+    def apply_subst(p, path):
+        """-S file on finalized oracle parameters: readPWM (Driver.cpp:768-859) overwrites the lowercase rows a,c,g,t,n unscaled and
+        sets gADJUST = 1 (the gap keeps its scaled value)"""
+        rows = []
+        for line in open(path):
+            f = line.split()
+            if len(f) == 4 and f[0][0].lower() == "a" and f[1][0].lower() == "c":
+                continue
+            vals = [float(x) for x in (f[1:] if len(f) == 5 else f)]
+            assert len(vals) == 4, line
+            rows.append(vals)
+        assert len(rows) >= 5
+        for ch, vals in zip("acgtn", rows[:5]):
+            for b, v in enumerate(vals):
+                p.S[ord(ch)][b] = v
+        p.adjust = 1.0
+        return p
+
     def index_load(self, fa):
         ix = self.lib.gmo_index_load(fa.encode())
         assert ix, f"cannot load index {fa}"

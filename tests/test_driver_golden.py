@@ -30,7 +30,11 @@ def oix(oracle, syn_fa):
 def test_oracle_run_equals_reference_program(mode, oracle, oix, tmp_path):
     m = MANIFEST[mode]
     out = str(tmp_path / "o")
-    st = oracle.run(oix, oracle.params(**m["params"]), os.path.join(GOLDEN, m["fastq"]), out, threads=1)
+    kw = dict(m["params"]); subst = kw.pop("_subst", None)
+    p = oracle.params(**kw)
+    if subst:
+        oracle.apply_subst(p, os.path.join(GOLDEN, subst))
+    st = oracle.run(oix, p, os.path.join(GOLDEN, m["fastq"]), out, threads=1)
     sam = b"".join(l for l in open(out + ".sam", "rb") if not l.startswith(b"@PG"))
     assert sam == ref_text(mode, "sam"), mode
     assert sam.count(b"\n") == m["sam_lines"]

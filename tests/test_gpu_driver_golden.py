@@ -47,7 +47,8 @@ def test_cli_equals_reference_program(mode, extra, tmp_path):
     if extra and mode not in ("default", "no_nw", "bs_all", "T2", "u", "illumina", "k1_all", "m16_h150_all"):
         pytest.skip("index / batching variants run on a subset of the modes")
     out = str(tmp_path / "mine")
-    r = subprocess.run([EXE, "-g", os.path.join(GOLDEN, "syn.fa"), "-o", out, "-a", "0.9"] + m["argv"] + extra + [os.path.join(GOLDEN, m["fastq"])],
+    argv = [os.path.join(GOLDEN, a) if a == "subst.txt" else a for a in m["argv"]]
+    r = subprocess.run([EXE, "-g", os.path.join(GOLDEN, "syn.fa"), "-o", out, "-a", "0.9"] + argv + extra + [os.path.join(GOLDEN, m["fastq"])],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     sam = "".join(l for l in open(out + ".sam") if not l.startswith("@PG"))
