@@ -14,6 +14,7 @@ import bench
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mbp", type=float, default=100.0)
+    ap.add_argument("--contigs", type=int, default=6)
     ap.add_argument("--reads", type=int, default=2_000_000)
     ap.add_argument("--len", type=int, default=100)
     ap.add_argument("--args", default="-a 0.9")
@@ -21,7 +22,15 @@ def main():
     a = ap.parse_args()
     os.makedirs(a.dir, exist_ok=True)
     fa = os.path.join(a.dir, "g%g.fa" % a.mbp); fq = os.path.join(a.dir, "r%d.fq" % a.reads)
-    codes = bench.make_genome(fa, a.mbp, 42, 6)
+    bench.make_genome(fa, a.mbp, 42, a.contigs)
+    raw = np.fromfile(fa, np.uint8)                                # FASTA text -> 2-bit codes: drop the header lines and the newlines
+    keep = np.ones(len(raw), bool)
+    for h in np.flatnonzero(raw == ord(">")):
+        e = h + int(np.argmax(raw[h:h + 4096] == 10))
+        keep[h:e + 1] = False
+    keep &= raw != 10
+    codes = np.searchsorted(np.frombuffer(b"ACGT", np.uint8), raw[keep]).astype(np.uint8)
+    del raw, keep
     rng = np.random.default_rng(7)
     L, n = a.len, a.reads
     acgt = np.frombuffer(b"ACGT", np.uint8)
