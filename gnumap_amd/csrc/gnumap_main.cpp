@@ -39,6 +39,7 @@ struct Options {
     gm_params p;
     int gpus = 1, locate_sampled = 0, verbose = 1;
     uint32_t batch = 262144;
+    bool batch_set = false;     // --batch given: blocks of exactly that many reads (one sequential scanner); otherwise byte-range chunks parsed by the workers
     int workers = 3;            // host threads (and gm_batch objects) per GPU (measured: 2 -> 9.6, 3 -> 11.4, 4 -> 11.0 M reads/s)
     int fmt_threads = 0;        // SAM formatter threads per block (0 = min(8, cores))
     int threads = 1;            // -c: accepted for compatibility (the GPU replaces the pthread pool)
@@ -65,7 +66,7 @@ static void usage(int rc, const char* msg) {
             "  -b, --bs_seq / --b2 / -d, --a_to_g   bisulfite / A-to-G scoring\n"
             "      --no_nw                  use k-mer hit counts instead of Needleman-Wunsch alignments\n"
             "      --fast, --print_all_sam, --illumina, --up_strand, --down_strand, --bin_size=INT\n"
-            "  MI355X options: --gpus=N  --batch=N  --workers=N  --fmt_threads=N  --locate=sampled|full\n");
+            "  MI355X options: --gpus=N  --batch=N (blocks of exactly N reads)  --chunk_reads=N  --workers=N  --fmt_threads=N  --locate=sampled|full\n");
     exit(rc);
 }
 
@@ -107,7 +108,8 @@ static void parse_args(int argc, char** argv, Options& o) {
             else if (!strcmp(s, "up_strand")) { o.p.pos_strand = 1; o.p.neg_strand = 0; }
             else if (!strcmp(s, "down_strand")) { o.p.pos_strand = 0; o.p.neg_strand = 1; }
             else if (starts(s, "gpus=")) o.gpus = atoi(s + 5);
-            else if (starts(s, "batch=")) o.batch = (uint32_t)atoi(s + 6);
+            else if (starts(s, "batch=")) { o.batch = (uint32_t)atoi(s + 6); o.batch_set = true; }
+            else if (starts(s, "chunk_reads=")) o.batch = (uint32_t)atoi(s + 12);       // byte-range chunks of about this many records (default 262144)
             else if (starts(s, "workers=")) o.workers = atoi(s + 8);
             else if (starts(s, "fmt_threads=")) o.fmt_threads = atoi(s + 12);
             else if (starts(s, "locate=")) o.locate_sampled = !strcmp(s + 7, "sampled");
@@ -191,6 +193,8 @@ struct Block {
     // results of the two batch calls (page-locked)
     PinVec<gm_sam_rec> recs; PinVec<char> pool; uint64_t n_recs = 0;
     int gpu = 0;
+    size_t text_lo = 0, text_hi = 0; bool lazy = false;   // chunk mode: the byte range of the FASTQ text a worker still has to cut into records
+    bool malformed = false;                 // a malformed record ended this block: later blocks are dropped (the reference's parser stops there)
     int illumina = 0;                       // --illumina still in force when this block starts (the fallback is sticky, SeqReader.cpp:1171-1180)
     std::vector<std::string> text;          // SAM text, one piece per formatter thread
     bool failed = false;
@@ -239,25 +243,33 @@ struct FastqScanner {
         p = s; len = (size_t)(e - s); at = (size_t)(e - base) + 1;
         return true;
     }
-    bool next(Block& b, uint32_t max_reads) {
+    // cut base[cur, limit) into records until max_reads (thread-safe: no scanner state); `stop` = a malformed record ended the input
+    static bool parse_range(const char* base, size_t& cur, size_t limit, Block& b, uint32_t max_reads, bool* stop) {
         b.n = 0; b.maxlen = 0;
         b.name.clear(); b.seq.clear(); b.qual.clear(); b.name_len.clear(); b.qual_len.clear(); b.len.clear();
-        if (done) return false;
+        auto line = [&](const char*& p, size_t& len) -> bool {       // one line without its newline; false at the end of the range
+            if (cur >= limit) return false;
+            const char* s0 = base + cur;
+            const char* e = (const char*)memchr(s0, '\n', limit - cur);
+            if (!e) { p = s0; len = limit - cur; cur = limit; return true; }
+            p = s0; len = (size_t)(e - s0); cur = (size_t)(e - base) + 1;
+            return true;
+        };
         while (b.n < max_reads) {
             const char *nm, *sq = nullptr, *pl = nullptr, *ql = nullptr; size_t nl, sl = 0, pll = 0, qll = 0;
-            if (!line(nm, nl)) { done = true; break; }
+            if (!line(nm, nl)) break;
             bool eof = false;
             while (nl == 0) { if (!line(nm, nl)) { eof = true; break; } }
-            if (eof) { done = true; break; }
+            if (eof) break;
             if (!line(sq, sl)) { sq = ""; sl = 0; }
             if (!line(pl, pll)) { pl = ""; pll = 0; }
             if (!line(ql, qll)) { ql = ""; qll = 0; }
             if (nm[0] != '@' || pll == 0 || pl[0] != '+' || sl > qll) {
                 fprintf(stderr, "--ERROR at sequence %.*s (malformed FASTQ record); stopping here\n", (int)std::min<size_t>(nl, 200), nm);
-                done = true;
+                *stop = true;
                 break;
             }
-            if (sl > 2048) { fprintf(stderr, "read %.*s longer than 2048 bases\n", (int)std::min<size_t>(nl, 200), nm); done = true; break; }
+            if (sl > 2048) { fprintf(stderr, "read %.*s longer than 2048 bases\n", (int)std::min<size_t>(nl, 200), nm); *stop = true; break; }
             b.name.push_back(nm + 1); b.name_len.push_back((uint32_t)(nl - 1));
             b.seq.push_back(sq); b.len.push_back((uint16_t)sl);
             b.qual.push_back(ql); b.qual_len.push_back((uint32_t)qll);
@@ -266,6 +278,45 @@ struct FastqScanner {
         }
         b.stride = std::max<uint32_t>(8, (b.maxlen + 7u) & ~7u);
         return b.n > 0;
+    }
+    bool next(Block& b, uint32_t max_reads) {               // sequential mode: blocks of exactly max_reads reads
+        if (done) return false;
+        bool stop = false;
+        const bool got = parse_range(base, at, size, b, max_reads, &stop);
+        if (stop || at >= size || !got) done = true;
+        return got;
+    }
+    // chunk mode: the start of the first record at or after `off` (a line starting with '@' whose next-but-one line starts with
+    // '+': a quality line may start with '@' too, but then the line two below is a sequence, never '+')
+    size_t record_start(size_t off) const {
+        if (off == 0) return 0;
+        if (off >= size) return size;
+        const char* e = (const char*)memchr(base + off - 1, '\n', size - off + 1);      // the line containing off-1 ends here
+        size_t p = e ? (size_t)(e - base) + 1 : size;
+        while (p < size) {
+            const char* l1 = (const char*)memchr(base + p, '\n', size - p);
+            if (!l1) return size;
+            const char* l2 = (const char*)memchr(l1 + 1, '\n', size - (size_t)(l1 + 1 - base));
+            if (!l2) return size;
+            if (base[p] == '@' && (size_t)(l2 + 1 - base) < size && l2[1] == '+') return p;
+            p = (size_t)(l1 - base) + 1;
+        }
+        return size;
+    }
+    size_t chunk_bytes = 0;
+    bool next_chunk(Block& b, uint32_t target_reads) {       // a byte range of about target_reads records, cut at record starts
+        if (done || at >= size) { done = true; return false; }
+        if (!chunk_bytes) {                                  // record size from the first records of the file
+            size_t p = 0; uint32_t recs = 0;
+            while (recs < 4000 && p < size) { const char* e = (const char*)memchr(base + p, '\n', size - p); if (!e) break; p = (size_t)(e - base) + 1; ++recs; }
+            const double per_rec = recs >= 4 ? (double)p / (recs / 4) : 256.0;
+            chunk_bytes = (size_t)std::max(4096.0, per_rec * target_reads);
+        }
+        const size_t lo = at, hi = record_start(std::min(size, at + chunk_bytes));
+        b.text_lo = lo; b.text_hi = hi > lo ? hi : size; b.lazy = true; b.n = 0;
+        at = b.text_hi;
+        if (at >= size) done = true;
+        return true;
     }
 };
 
@@ -376,7 +427,7 @@ struct Worker {
     PinVec<int8_t> status; PinVec<float> self_score; PinVec<double> top, den; PinVec<uint64_t> mbegin;
     PinVec<gm_match> matches; PinVec<gm_pos> positions;
     uint64_t n_reads = 0, n_matched = 0, n_records = 0;
-    double t_pack = 0, t_map = 0, t_out = 0;
+    double t_pack = 0, t_map = 0, t_out = 0, t_scan = 0;
 };
 
 static double secs_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
@@ -475,7 +526,7 @@ int main(int argc, char** argv) {
         for (int k = 0; k < o.workers; ++k) {
             Worker& w = workers[(size_t)g * (size_t)o.workers + (size_t)k];
             w.gpu = g; w.ix = gpu_ix[(size_t)g];
-            if (gm_batch_create(w.ix, o.batch, 2048, &w.batch) != GM_OK || gm_stream_create(w.ix, &w.stream) != GM_OK) { fprintf(stderr, "ERROR: %s\n", gm_last_error()); return 1; }
+            if (gm_batch_create(w.ix, o.batch_set || o.p.illumina ? o.batch : 16000000u, 2048, &w.batch) != GM_OK || gm_stream_create(w.ix, &w.stream) != GM_OK) { fprintf(stderr, "ERROR: %s\n", gm_last_error()); return 1; }
         }
     }
     gm_index_info info;
@@ -508,6 +559,7 @@ int main(int argc, char** argv) {
     Queue<Block*> free_q, map_q, fmt_q;
     for (auto& b : blocks) free_q.push(&b);
     std::atomic<int> failed{ 0 };
+    std::atomic<uint64_t> stop_block{ ~0ull };         // chunk mode: first block that ended in a malformed record; later blocks are dropped
     double t_scan = 0, t_fmt = 0, t_write = 0;
     std::mutex fmt_mu;
 
@@ -517,7 +569,10 @@ int main(int argc, char** argv) {
         Block* b;
         while (!failed && free_q.pop(b)) {
             auto s0 = std::chrono::steady_clock::now();
-            bool more = fq.next(*b, o.batch);
+            b->lazy = false; b->malformed = false;
+            // --batch=N or --illumina (its fallback is a property of the reads in file order): blocks of N reads cut here;
+            // otherwise byte-range chunks of about that many records, cut into records by the workers in parallel
+            const bool more = (o.batch_set || o.p.illumina) ? fq.next(*b, o.batch) : fq.next_chunk(*b, o.batch);
             t_scan += secs_since(s0);
             if (!more) { free_q.push(b); break; }
             b->index = idx++; b->failed = false;
@@ -536,6 +591,14 @@ int main(int argc, char** argv) {
             Worker& w = workers[k];
             Block* b;
             while (map_q.pop(b)) {
+                if (b->lazy) {                              // chunk mode: this worker cuts its byte range into records
+                    auto s0 = std::chrono::steady_clock::now();
+                    size_t cur = b->text_lo; bool stop = false;
+                    FastqScanner::parse_range(fq.base, cur, b->text_hi, *b, 16000000u, &stop);
+                    if (stop) { b->malformed = true; uint64_t cur_min = stop_block.load(); while (b->index < cur_min && !stop_block.compare_exchange_weak(cur_min, b->index)) {} }
+                    w.t_scan += secs_since(s0);
+                }
+                if (b->n == 0) { b->n_recs = 0; fmt_q.push(b); continue; }
                 if (!failed && process_block_split(w, o, *b, 0) != GM_OK) { failed = 1; }
                 if (failed) { b->failed = true; b->n_recs = 0; }
                 fmt_q.push(b);
@@ -579,7 +642,7 @@ int main(int argc, char** argv) {
                 b = ready.begin()->second; ready.erase(ready.begin());
             }
             auto w0 = std::chrono::steady_clock::now();
-            if (!b->failed)
+            if (!b->failed && b->index <= stop_block.load())
                 for (auto& s : b->text) if (!s.empty() && !write_all(s.data(), s.size())) { fprintf(stderr, "ERROR: write failed\n"); failed = 1; }
             t_write += secs_since(w0);
             ++next;
@@ -612,7 +675,7 @@ int main(int argc, char** argv) {
     uint64_t n_reads = 0, n_matched = 0, n_records = 0;
     double t_pack = 0, t_map = 0, t_out = 0;
     for (auto& w : workers) {
-        n_reads += w.n_reads; n_matched += w.n_matched; n_records += w.n_records; t_pack += w.t_pack; t_map += w.t_map; t_out += w.t_out;
+        n_reads += w.n_reads; n_matched += w.n_matched; n_records += w.n_records; t_pack += w.t_pack; t_map += w.t_map; t_out += w.t_out; t_scan += w.t_scan;
         gm_batch_destroy(w.batch);
         gm_stream_destroy(w.ix, w.stream);
     }

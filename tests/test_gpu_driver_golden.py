@@ -40,7 +40,8 @@ def compare_tracks(mine, ref, ncol):
             assert abs(x - y) <= 1e-4 * max(1.0, abs(y)) + 2e-5, (k, x, y)
 
 
-@pytest.mark.parametrize("extra", [[], ["--locate=sampled"], ["--batch=64", "--workers=2"]], ids=["full_sa", "sampled_sa", "batch64"])
+@pytest.mark.parametrize("extra", [[], ["--locate=sampled"], ["--batch=64", "--workers=2"], ["--chunk_reads=37", "--workers=3"]],
+                         ids=["full_sa", "sampled_sa", "batch64", "chunks37"])
 @pytest.mark.parametrize("mode", sorted(MANIFEST))
 def test_cli_equals_reference_program(mode, extra, tmp_path):
     m = MANIFEST[mode]
