@@ -1569,50 +1569,21 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
 // More hits or groups than that -> b.big_list -> k_vote_fast_list; a table that fills up -> the retry kernel.
 #define GMT_Q 32                         // 16-rank groups per read x strand
 #define GMT_LCAP 256                     // hits per read x strand
-template <bool MASK64, bool FULL>
-__global__ void __launch_bounds__(64, 8) k_vote_tiny(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
-    constexpr int U = GMT_Q / 4, T2 = 128;
-    __shared__ uint4 s_r0v[192];                      // 3 KB: words [0,256) = 512 x 16-bit counters, [256,768) = 128 x key | votes | low mask | high mask
-    __shared__ uint32_t s_lbp[GMT_LCAP];
-    __shared__ uint8_t s_lt[GMT_LCAP];
-    __shared__ uint2 s_desc[GMT_Q];                   // {SA rank (flat entry index if !FULL) of the group's first hit, read offset | tag << 16 | hits << 24}
-    __shared__ uint32_t s_cnt0[64];
+// the part of k_vote_tiny after its descriptors are in LDS, unrolled for UU load steps (4 groups of 16 ranks each) and LQ list
+// chunks of 64 hits: the kernel is vector-issue bound, and a read x strand of 13 seeds x ~12 hits fills 4 of the 8 steps and 3 of
+// the 4 chunks - the step counts are wave-uniform, so the kernel picks the instantiation instead of walking empty steps
+template <bool MASK64, bool FULL, int UU, int LQ>
+__device__ __forceinline__ void gm_vote_tiny_body(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, const uint32_t rs, const int lane, const uint32_t E,
+                                                  uint4* s_r0v, uint32_t* s_lbp, uint8_t* s_lt, const uint2* s_desc, uint32_t* s_cnt0) {
+    constexpr int T2 = 128;
     uint32_t* const s_r0 = reinterpret_cast<uint32_t*>(s_r0v);
-    const uint32_t rs = blockIdx.x;                   // grid = 2n
-    const int lane = threadIdx.x;
-    GmSeed sd; sd.k = 0; sd.l = 0; sd.pos = 0;
-    if ((uint32_t)lane < b.max_seeds) sd = b.seeds[(size_t)rs * b.max_seeds + lane];
-    uint32_t ns = b.n_seeds[rs];
-    if (p.nw && p.fast && ns > 1) ns = 1;
-    const uint32_t cnt = (uint32_t)lane < ns ? sd.l - sd.k + 1 : 0u;
-    const uint32_t nq = (cnt + 15u) >> 4;
-    const uint32_t ie = gm_wave_scan_incl(cnt), iq = gm_wave_scan_incl(nq);
-    const uint32_t E = __builtin_amdgcn_readlane(ie, 63), Q = __builtin_amdgcn_readlane(iq, 63);
-    if (Q == 0) return;                               // wave-uniform: nothing to vote on
-    if (Q > GMT_Q || E > GMT_LCAP) {                  // wave-uniform: hand over to the list kernel
-        if (lane == 0) { const uint32_t at = atomicAdd(b.n_big, 1u); b.big_list[at] = rs; }
-        return;
-    }
-    if (lane < GMT_Q) s_desc[lane] = make_uint2(0u, 0u);
-    s_cnt0[lane] = 0;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) s_r0v[lane + 64 * k] = make_uint4(0u, 0u, 0u, 0u);
-    __syncthreads();
-    {
-        const uint32_t q0 = iq - nq, e0 = ie - cnt;
-        for (uint32_t j = 0; j < nq; ++j) {
-            const uint32_t left = cnt - 16u * j;
-            s_desc[q0 + j] = make_uint2((FULL ? sd.k : e0) + 16u * j, sd.pos | ((uint32_t)lane << 16) | ((left < 16u ? left : 16u) << 24));
-        }
-    }
-    __syncthreads();
     const uint32_t* const src = FULL ? ix.full_sa : b.coords + b.entry_off[rs];
     // ---- loads: step j holds groups 4j .. 4j+3, lane -> group 4j + lane / 16, rank = first rank + lane % 16
-    uint32_t bpv[U], tg[U];
+    uint32_t bpv[UU], tg[UU];
     unsigned long long zero_votes = 0;               // (step, lane) pairs that hold a b = 0 vote: rare
     const uint32_t sub = (uint32_t)lane & 15u;
 #pragma unroll
-    for (int j = 0; j < U; ++j) {
+    for (int j = 0; j < UU; ++j) {
         const uint2 d = s_desc[4 * j + (lane >> 4)];
         const bool valid = sub < (d.y >> 24);
         tg[j] = (d.y >> 16) & 63u;
@@ -1624,7 +1595,7 @@ __global__ void __launch_bounds__(64, 8) k_vote_tiny(GmDevIndex ix, GmDevParams 
     uint32_t wcount = 0;
     bool any0 = false;
 #pragma unroll
-    for (int j = 0; j < U; ++j) {
+    for (int j = 0; j < UU; ++j) {
         const bool hit = bpv[j] != 0xFFFFFFFFu;
         const bool z = hit && bpv[j] == 0u;
         if (z) atomicAdd(&s_cnt0[tg[j]], 1u);
@@ -1642,9 +1613,9 @@ __global__ void __launch_bounds__(64, 8) k_vote_tiny(GmDevIndex ix, GmDevParams 
     uint32_t* const keys = s_r0 + 256; uint32_t* const vals = keys + T2; uint32_t* const mlo = keys + 2 * T2; uint32_t* const mhi = keys + 3 * T2;
     const uint32_t n_l = wcount;
     const uint32_t thr = (uint32_t)(p.kmin < 1 ? 1 : p.kmin);
-    uint32_t bp4[4];
+    uint32_t bp4[LQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < LQ; ++q) {
         const uint32_t i = 64u * q + (uint32_t)lane;
         bp4[q] = i < n_l ? s_lbp[i] : 0u;
         if (bp4[q] != 0u) {
@@ -1656,7 +1627,7 @@ __global__ void __launch_bounds__(64, 8) k_vote_tiny(GmDevIndex ix, GmDevParams 
     bool full = false;
     uint32_t nkeys = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < LQ; ++q) {
         const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> 23;
         const uint32_t c = (s_r0[h2 & 255u] >> ((h2 >> 8) << 4)) & 0xFFFFu;
         bool fresh = false;
@@ -1743,6 +1714,51 @@ __global__ void __launch_bounds__(64, 8) k_vote_tiny(GmDevIndex ix, GmDevParams 
         const bool emit = lane == 0 && total >= (uint32_t)p.kmin;
         const uint32_t step = p.nw ? (uint32_t)(__ffsll((long long)reached) - 1) : (total > 65535u ? 65535u : total);
         gm_emit<GmLdsTable>(b, emit, rs, 0u, step, 4);
+    }
+}
+
+template <bool MASK64, bool FULL>
+__global__ void __launch_bounds__(64, 8) k_vote_tiny(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
+    __shared__ uint4 s_r0v[192];                      // 3 KB: words [0,256) = 512 x 16-bit counters, [256,768) = 128 x key | votes | low mask | high mask
+    __shared__ uint32_t s_lbp[GMT_LCAP];
+    __shared__ uint8_t s_lt[GMT_LCAP];
+    __shared__ uint2 s_desc[GMT_Q];                   // {SA rank (flat entry index if !FULL) of the group's first hit, read offset | tag << 16 | hits << 24}
+    __shared__ uint32_t s_cnt0[64];
+    uint32_t* const s_r0 = reinterpret_cast<uint32_t*>(s_r0v);
+    const uint32_t rs = blockIdx.x;                   // grid = 2n
+    const int lane = threadIdx.x;
+    GmSeed sd; sd.k = 0; sd.l = 0; sd.pos = 0;
+    if ((uint32_t)lane < b.max_seeds) sd = b.seeds[(size_t)rs * b.max_seeds + lane];
+    uint32_t ns = b.n_seeds[rs];
+    if (p.nw && p.fast && ns > 1) ns = 1;
+    const uint32_t cnt = (uint32_t)lane < ns ? sd.l - sd.k + 1 : 0u;
+    const uint32_t nq = (cnt + 15u) >> 4;
+    const uint32_t ie = gm_wave_scan_incl(cnt), iq = gm_wave_scan_incl(nq);
+    const uint32_t E = __builtin_amdgcn_readlane(ie, 63), Q = __builtin_amdgcn_readlane(iq, 63);
+    if (Q == 0) return;                               // wave-uniform: nothing to vote on
+    if (Q > GMT_Q || E > GMT_LCAP) {                  // wave-uniform: hand over to the list kernel
+        if (lane == 0) { const uint32_t at = atomicAdd(b.n_big, 1u); b.big_list[at] = rs; }
+        return;
+    }
+    if (lane < GMT_Q) s_desc[lane] = make_uint2(0u, 0u);
+    s_cnt0[lane] = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s_r0v[lane + 64 * k] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    {
+        const uint32_t q0 = iq - nq, e0 = ie - cnt;
+        for (uint32_t j = 0; j < nq; ++j) {
+            const uint32_t left = cnt - 16u * j;
+            s_desc[q0 + j] = make_uint2((FULL ? sd.k : e0) + 16u * j, sd.pos | ((uint32_t)lane << 16) | ((left < 16u ? left : 16u) << 24));
+        }
+    }
+    __syncthreads();
+    if (Q <= 16u) {
+        if (E <= 192u) gm_vote_tiny_body<MASK64, FULL, 4, 3>(ix, p, b, rs, lane, E, s_r0v, s_lbp, s_lt, s_desc, s_cnt0);
+        else gm_vote_tiny_body<MASK64, FULL, 4, 4>(ix, p, b, rs, lane, E, s_r0v, s_lbp, s_lt, s_desc, s_cnt0);
+    } else {
+        if (E <= 192u) gm_vote_tiny_body<MASK64, FULL, 8, 3>(ix, p, b, rs, lane, E, s_r0v, s_lbp, s_lt, s_desc, s_cnt0);
+        else gm_vote_tiny_body<MASK64, FULL, 8, 4>(ix, p, b, rs, lane, E, s_r0v, s_lbp, s_lt, s_desc, s_cnt0);
     }
 }
 

@@ -1,7 +1,5 @@
 set -e
-python -m pytest tests/test_gpu_driver_golden.py -x -q > gpurun_out/r02_j16_tests.log 2>&1 || { tail -40 gpurun_out/r02_j16_tests.log; exit 1; }
-tail -2 gpurun_out/r02_j16_tests.log
+python -m pytest tests -m gpu -x -q > gpurun_out/r02_j17_tests.log 2>&1 || { tail -40 gpurun_out/r02_j17_tests.log; exit 1; }
+tail -2 gpurun_out/r02_j17_tests.log
 python3 tools/cli_bench.py --mbp 100 --contigs 6 --reads 32000000 --args "-a 0.9" --dir /tmp/gm_cli > gpurun_out/r02_cli_bench_100.txt 2>&1 || { tail -30 gpurun_out/r02_cli_bench_100.txt; exit 1; }
 grep -E "^---|wall seconds|stage seconds|Finished|SAM bytes" gpurun_out/r02_cli_bench_100.txt
-python3 tools/cli_bench.py --mbp 100 --contigs 6 --reads 32000000 --args "-a 0.9 -m 16 -j 8 --workers=4" --dir /tmp/gm_cli > gpurun_out/r02_cli_bench_100_m16.txt 2>&1 || { tail -30 gpurun_out/r02_cli_bench_100_m16.txt; exit 1; }
-grep -E "^---|wall seconds|stage seconds|Finished" gpurun_out/r02_cli_bench_100_m16.txt
