@@ -105,7 +105,7 @@ struct gm_batch {
         tb_items, tb_ops, tb_len, dep_pos, dep_span, dep_w, dep_codes, dep_coff,
         // grouping (process_hits' unique map) and output stage, gm_output.hip
         g_sorted, g_ord, g_lead, g_krank, g_khash, g_nmatch, g_mbegin, g_multi, g_big, g_bigdone, g_sk0, g_sk1, g_si0, g_si1, g_matches, g_mhit, g_positions, scan_tmp,
-        o_small, o_posmatch, o_post, o_mapq, o_emit, o_reccnt, o_cigcnt, o_recoff, o_cigoff, o_recs, o_pool, o_codes;
+        o_small, o_posmatch, o_post, o_mapq, o_emit, o_reccnt, o_cigcnt, o_cigall, o_recoff, o_cigoff, o_recs, o_pool, o_codes;
     PinBuf h_raw, h_top, h_hbegin, h_ord, h_post, h_mapq, h_emit, h_mhit;
     std::vector<double> h_exp;          // exp(score) of every accepted hit of the last gm_map_batch (reused by gm_output_batch)
     uint64_t cache_hits = 0, cache_matches = 0;
@@ -490,7 +490,7 @@ extern "C" void gm_batch_destroy(gm_batch* b) {
                       &b->cands, &b->fixed_cands, &b->fixed_cnt, &b->heavy_list, &b->heavy_off, &b->heavy_k0, &b->heavy_k1, &b->heavy_tmp, &b->hit_count, &b->hit_begin, &b->hit_cursor, &b->raw_hits, &b->counters, &b->small, &b->shards, &b->big_list, &b->tb_items, &b->tb_ops,
                       &b->tb_len, &b->dep_pos, &b->dep_span, &b->dep_w, &b->dep_codes, &b->dep_coff,
                       &b->g_sorted, &b->g_ord, &b->g_lead, &b->g_krank, &b->g_khash, &b->g_nmatch, &b->g_mbegin, &b->g_multi, &b->g_big, &b->g_bigdone, &b->g_sk0, &b->g_sk1, &b->g_si0, &b->g_si1, &b->g_matches, &b->g_mhit, &b->g_positions,
-                      &b->scan_tmp, &b->o_small, &b->o_posmatch, &b->o_post, &b->o_mapq, &b->o_emit, &b->o_reccnt, &b->o_cigcnt, &b->o_recoff, &b->o_cigoff,
+                      &b->scan_tmp, &b->o_small, &b->o_posmatch, &b->o_post, &b->o_mapq, &b->o_emit, &b->o_reccnt, &b->o_cigcnt, &b->o_cigall, &b->o_recoff, &b->o_cigoff,
                       &b->o_recs, &b->o_pool, &b->o_codes };
     for (DevBuf* d : all) d->release();
     PinBuf* pins[] = { &b->h_raw, &b->h_top, &b->h_hbegin, &b->h_ord, &b->h_post, &b->h_mapq, &b->h_emit, &b->h_mhit };
@@ -1172,10 +1172,34 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
     if (n_m64 == 0) return GM_OK;
     if (n_m64 > 0x7FFFFFFFull) { gm_set_error("too many matches in one batch; map the block in smaller pieces"); return GM_E_BATCH_TOO_LARGE; }
     const uint32_t n_m = (uint32_t)n_m64;
+    // ---- device, part 1: everything that does not depend on the posteriors is enqueued BEFORE the host pass and runs under it ----
+    uint64_t n_p = 0;
+    if (b->cache_matches == n_m64 && b->cache_hits <= hits->positions_cap) n_p = b->cache_hits;     // the result of this batch's gm_map_batch: positions share the hit CSR
+    else for (uint64_t m = 0; m < n_m64; ++m) n_p = std::max<uint64_t>(n_p, hits->matches[m].pos_end);
+    if (n_p > hits->positions_cap) { gm_set_error("gm_hits: positions out of range"); return GM_E_ARG; }
+    const uint32_t ops_words = gm_ops_words(b->stride), codes_stride = 32u * ops_words;
+    const bool nuc = p->mode != GM_MODE_NORMAL && ix->nuc_on;
+    if (b->g_matches.ensure((size_t)n_m * sizeof(GmDevMatch)) || b->g_positions.ensure((size_t)(n_p + 1) * sizeof(GmDevPos)) ||
+        b->o_posmatch.ensure((size_t)(n_p + 1) * 4) || b->o_post.ensure((size_t)n_m * 4) || b->o_mapq.ensure((size_t)n_m * 4) || b->o_emit.ensure(n_m) ||
+        b->tb_items.ensure((size_t)n_m * sizeof(GmCand)) || b->tb_ops.ensure((size_t)n_m * ops_words * 8) || b->tb_len.ensure((size_t)n_m * 2) ||
+        b->o_reccnt.ensure((size_t)n_m * 4) || b->o_cigcnt.ensure((size_t)n_m * 4) || b->o_cigall.ensure((size_t)n_m * 4) || b->o_recoff.ensure(((size_t)n_m + 1) * 8) ||
+        b->o_cigoff.ensure(((size_t)n_m + 1) * 8) || b->scan_tmp.ensure(((size_t)std::max<uint32_t>(n_m, n) / 1024 + 8) * 8) || b->o_small.ensure(64) ||
+        (nuc && b->o_codes.ensure((size_t)n_m * codes_stride))) return GM_E_NOMEM;
+    const GmDevMatch* d_m = b->g_matches.as<GmDevMatch>(); const GmDevPos* d_p = b->g_positions.as<GmDevPos>();
+    HIPCHK(hipMemcpyAsync(b->g_matches.p, hits->matches, (size_t)n_m * sizeof(gm_match), hipMemcpyHostToDevice, st));
+    if (n_p) HIPCHK(hipMemcpyAsync(b->g_positions.p, hits->positions, (size_t)n_p * sizeof(gm_pos), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(b->o_posmatch.p, 0xFF, (size_t)(n_p + 1) * 4, st));
+    HIPCHK(hipMemsetAsync(b->o_small.p, 0, 64, st));
+    fill_dev_batch(b);
+    KCHK(gmk_out_items(d_m, n_m, 0, b->tb_items.as<GmCand>(), b->o_posmatch.as<uint32_t>(), st));
+    // one traceback per ScoredSeq, oriented by its first strand (NormalScoredSeq::score, ScoredSeq::get_SAM); the kernel also leaves the
+    // length of every sequence's CIGAR text and finds the longest aligned length
+    KCHK(gmk_traceback(ix->dev, dp, b->dev, b->tb_items.as<GmCand>(), n_m, b->tb_ops.as<unsigned long long>(), ops_words, b->tb_len.as<uint16_t>(),
+                       nullptr, b->o_cigall.as<uint32_t>(), b->o_small.as<uint32_t>(), st));
+    pc.lap("enqueue");
     // ---- host pass: ScoredSeq::get_SAM :300-309, is_greater :223-228, Driver.cpp:672-701 ----
     if (b->h_post.ensure((size_t)n_m * 4) || b->h_mapq.ensure((size_t)n_m * 4) || b->h_emit.ensure(n_m)) return GM_E_NOMEM;
     float* post = b->h_post.as<float>(); int32_t* mapq = b->h_mapq.as<int32_t>(); uint8_t* emit = b->h_emit.as<uint8_t>();
-    uint64_t n_p = 0;
     const double log10v = log(10), e_m1 = exp(-1.0);                   // e_m1: the empty NormalScoredSeq a winner has to beat, ScoredSeq.h:117-120
     auto mapq_of = [&](double total) {
         int q;
@@ -1185,6 +1209,7 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
     const int all = p->print_all_sam;
     const uint64_t cached_m = b->cache_matches, cached_h = b->cache_hits;
     const uint32_t* mhit = b->h_mhit.as<uint32_t>(); const float* ord = b->h_ord.as<float>(); const double* hexp = b->h_exp.data();
+    bool bad_hits = false;
     for (uint32_t i = 0; i < n; ++i) {
         const uint64_t m0 = hits->match_begin[i], m1 = hits->match_begin[i + 1];
         if (m0 == m1) continue;
@@ -1194,8 +1219,7 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
         double best_log = e_m1, best_total = 0;
         for (uint64_t m = m0; m < m1; ++m) {
             const gm_match& mm = hits->matches[m];
-            if (mm.read != i || mm.pos_end < mm.pos_begin) { gm_set_error("gm_hits: match does not belong to its read"); return GM_E_ARG; }
-            n_p = std::max<uint64_t>(n_p, mm.pos_end);
+            if (mm.read != i || mm.pos_end < mm.pos_begin || mm.pos_end > n_p) bad_hits = true;
             // exp(align_score): the value gm_map_batch already computed for the hit that gave this match its score, when the caller has
             // left the match as it was (exp is a function of the score alone, so equal score bits are all that has to hold)
             double lg;
@@ -1212,31 +1236,13 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
             mapq[best] = mapq_of(best_total);
         }
     }
-    if (n_p > hits->positions_cap) { gm_set_error("gm_hits: positions out of range"); return GM_E_ARG; }
+    if (bad_hits) { HIPCHK(hipStreamSynchronize(st)); gm_set_error("gm_hits: a match does not belong to its read (or its positions are out of range)"); return GM_E_ARG; }
     pc.lap("fp64");
-    // ---- device ----
-    const uint32_t ops_words = gm_ops_words(b->stride), codes_stride = 32u * ops_words;
-    const bool nuc = p->mode != GM_MODE_NORMAL && ix->nuc_on;
-    if (b->g_matches.ensure((size_t)n_m * sizeof(GmDevMatch)) || b->g_positions.ensure((size_t)(n_p + 1) * sizeof(GmDevPos)) ||
-        b->o_posmatch.ensure((size_t)(n_p + 1) * 4) || b->o_post.ensure((size_t)n_m * 4) || b->o_mapq.ensure((size_t)n_m * 4) || b->o_emit.ensure(n_m) ||
-        b->tb_items.ensure((size_t)n_m * sizeof(GmCand)) || b->tb_ops.ensure((size_t)n_m * ops_words * 8) || b->tb_len.ensure((size_t)n_m * 2) ||
-        b->o_reccnt.ensure((size_t)n_m * 4) || b->o_cigcnt.ensure((size_t)n_m * 4) || b->o_recoff.ensure(((size_t)n_m + 1) * 8) ||
-        b->o_cigoff.ensure(((size_t)n_m + 1) * 8) || b->scan_tmp.ensure(((size_t)std::max<uint32_t>(n_m, n) / 1024 + 8) * 8) || b->o_small.ensure(64) ||
-        (nuc && b->o_codes.ensure((size_t)n_m * codes_stride))) return GM_E_NOMEM;
-    const GmDevMatch* d_m = b->g_matches.as<GmDevMatch>(); const GmDevPos* d_p = b->g_positions.as<GmDevPos>();
-    HIPCHK(hipMemcpyAsync(b->g_matches.p, hits->matches, (size_t)n_m * sizeof(gm_match), hipMemcpyHostToDevice, st));
-    if (n_p) HIPCHK(hipMemcpyAsync(b->g_positions.p, hits->positions, (size_t)n_p * sizeof(gm_pos), hipMemcpyHostToDevice, st));
+    // ---- device, part 2 ----
     HIPCHK(hipMemcpyAsync(b->o_post.p, post, (size_t)n_m * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(b->o_mapq.p, mapq, (size_t)n_m * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(b->o_emit.p, emit, n_m, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(b->o_posmatch.p, 0xFF, (size_t)(n_p + 1) * 4, st));
-    HIPCHK(hipMemsetAsync(b->o_small.p, 0, 64, st));
-    fill_dev_batch(b);
-    KCHK(gmk_out_items(d_m, n_m, 0, b->o_emit.as<uint8_t>(), b->tb_items.as<GmCand>(), b->o_posmatch.as<uint32_t>(), b->o_reccnt.as<uint32_t>(), st));
-    // one traceback per ScoredSeq, oriented by its first strand (NormalScoredSeq::score, ScoredSeq::get_SAM); the kernel also sizes the
-    // CIGAR text of the printed ones and finds the longest aligned length
-    KCHK(gmk_traceback(ix->dev, dp, b->dev, b->tb_items.as<GmCand>(), n_m, b->tb_ops.as<unsigned long long>(), ops_words, b->tb_len.as<uint16_t>(),
-                       b->o_emit.as<uint8_t>(), b->o_cigcnt.as<uint32_t>(), b->o_small.as<uint32_t>(), st));
+    KCHK(gmk_out_sizes(d_m, n_m, b->o_emit.as<uint8_t>(), b->o_cigall.as<uint32_t>(), b->o_reccnt.as<uint32_t>(), b->o_cigcnt.as<uint32_t>(), st));
     KCHK(gmk_scan_u32(b->o_reccnt.as<uint32_t>(), n_m, b->o_recoff.as<uint64_t>(), b->scan_tmp.as<unsigned long long>(), st));
     KCHK(gmk_scan_u32(b->o_cigcnt.as<uint32_t>(), n_m, b->o_cigoff.as<uint64_t>(), b->scan_tmp.as<unsigned long long>(), st));
     uint64_t n_recs = 0, cig_len = 0; uint32_t max_span = 0;

@@ -167,7 +167,8 @@ int gmk_traceback(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& 
 int gmk_scan_u32(const uint32_t* in, uint64_t n, uint64_t* out, unsigned long long* tmp, void* stream);
 int gmk_group_count(const GmDevIndex& ix, const GmDevBatch& b, const GmDevGroup& g, int nw, int unique_only, uint32_t max_matches, void* stream);
 int gmk_group_write(const GmDevBatch& b, const GmDevGroup& g, void* stream);
-int gmk_out_items(const GmDevMatch* matches, uint32_t n_m, uint32_t read_base, const uint8_t* emit, GmCand* items, uint32_t* pos_match, uint32_t* rec_cnt, void* stream);
+int gmk_out_items(const GmDevMatch* matches, uint32_t n_m, uint32_t read_base, GmCand* items, uint32_t* pos_match, void* stream);
+int gmk_out_sizes(const GmDevMatch* matches, uint32_t n_m, const uint8_t* emit, const uint32_t* cig_all, uint32_t* rec_cnt, uint32_t* cig_cnt, void* stream);
 int gmk_out_write(const GmDevIndex& ix, const GmDevBatch& b, const GmDevMatch* matches, const GmDevPos* positions, uint32_t n_m, const uint8_t* emit,
                   const int32_t* mapq, const float* post, const unsigned long long* ops, uint32_t ops_words, const uint16_t* ops_len, int nw,
                   const uint64_t* rec_off, const uint64_t* cig_off, GmDevSamRec* recs, char* pool, void* stream);

@@ -2465,7 +2465,7 @@ __global__ void __launch_bounds__(256) k_traceback(GmDevIndex ix, GmDevParams p,
             }
             ops_len[ci] = outlen;
             my_span = outlen;
-            if (cig_cnt) cig_cnt[ci] = emit[ci] ? (p.nw ? ctext : gm_digits(L) + 1u) + 1u : 0u;       // --no_nw prints "<L>M" (ScoredSeq.h:330-340)
+            if (cig_cnt) cig_cnt[ci] = (emit && !emit[ci]) ? 0u : (p.nw ? ctext : gm_digits(L) + 1u) + 1u;       // emit == null: the length for every item       // --no_nw prints "<L>M" (ScoredSeq.h:330-340)
         }
         if (max_span) {
 #pragma unroll
@@ -2624,7 +2624,7 @@ __global__ void __launch_bounds__(NT) k_traceback_lane(GmDevIndex ix, GmDevParam
         }
         if (have) {
             ops_len[ci] = outlen;
-            if (cig_cnt) cig_cnt[ci] = emit[ci] ? (p.nw ? ctext : gm_digits(L) + 1u) + 1u : 0u;
+            if (cig_cnt) cig_cnt[ci] = (emit && !emit[ci]) ? 0u : (p.nw ? ctext : gm_digits(L) + 1u) + 1u;       // emit == null: the length for every item
         }
         if (max_span) {
             uint32_t my_span = outlen;

@@ -476,15 +476,24 @@ __global__ void __launch_bounds__(64) k_group_write_multi(GmDevBatch b, GmDevGro
 // ------------------------------------------------------------------------------------------------
 // output stage
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_out_items(const GmDevMatch* matches, uint32_t n_m, uint32_t read_base, const uint8_t* emit, GmCand* items,
-                                                   uint32_t* pos_match, uint32_t* rec_cnt) {
+__global__ void __launch_bounds__(256) k_out_items(const GmDevMatch* matches, uint32_t n_m, uint32_t read_base, GmCand* items, uint32_t* pos_match) {
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= n_m) return;
     const GmDevMatch mm = matches[m];
     GmCand c; c.rs = (mm.read - read_base) * 2u + mm.first_strand; c.b = (uint32_t)mm.first_pos; c.step = 0; c.flags = 0; c.pad = 0; c.score = 0;
     items[m] = c;
     for (uint32_t q = mm.pos_begin; q < mm.pos_end; ++q) pos_match[q] = m;
-    rec_cnt[m] = emit[m] ? mm.pos_end - mm.pos_begin : 0u;               // one SAM row per place of a printed sequence (ScoredSeq.h:375-401)
+}
+
+// once the host pass has said which sequences are printed: SAM rows and CIGAR bytes per match (the traceback kernel left the CIGAR
+// length of EVERY match, it ran while the host was still computing)
+__global__ void __launch_bounds__(256) k_out_sizes(const GmDevMatch* matches, uint32_t n_m, const uint8_t* emit, const uint32_t* cig_all, uint32_t* rec_cnt,
+                                                   uint32_t* cig_cnt) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_m) return;
+    const bool e = emit[m] != 0;
+    rec_cnt[m] = e ? matches[m].pos_end - matches[m].pos_begin : 0u;     // one SAM row per place of a printed sequence (ScoredSeq.h:375-401)
+    cig_cnt[m] = e ? cig_all[m] : 0u;
 }
 
 // run-length CIGAR text of a traceback (bin_seq.cpp:578-698) from the packed operations (2 bits each: 0 M, 1 I, 2 D); "" -> "*",
@@ -658,9 +667,15 @@ int gmk_group_write(const GmDevBatch& b, const GmDevGroup& g, void* stream) {
     return (int)hipGetLastError();
 }
 
-int gmk_out_items(const GmDevMatch* matches, uint32_t n_m, uint32_t read_base, const uint8_t* emit, GmCand* items, uint32_t* pos_match, uint32_t* rec_cnt, void* stream) {
+int gmk_out_items(const GmDevMatch* matches, uint32_t n_m, uint32_t read_base, GmCand* items, uint32_t* pos_match, void* stream) {
     if (n_m == 0) return 0;
-    hipLaunchKernelGGL(k_out_items, dim3(cdiv(n_m, 256)), dim3(256), 0, S_(stream), matches, n_m, read_base, emit, items, pos_match, rec_cnt);
+    hipLaunchKernelGGL(k_out_items, dim3(cdiv(n_m, 256)), dim3(256), 0, S_(stream), matches, n_m, read_base, items, pos_match);
+    return (int)hipGetLastError();
+}
+
+int gmk_out_sizes(const GmDevMatch* matches, uint32_t n_m, const uint8_t* emit, const uint32_t* cig_all, uint32_t* rec_cnt, uint32_t* cig_cnt, void* stream) {
+    if (n_m == 0) return 0;
+    hipLaunchKernelGGL(k_out_sizes, dim3(cdiv(n_m, 256)), dim3(256), 0, S_(stream), matches, n_m, emit, cig_all, rec_cnt, cig_cnt);
     return (int)hipGetLastError();
 }
 
