@@ -721,7 +721,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
     // the one-wave vote kernels leave their candidates in per read x strand slots (no bump counter on the wave's critical path)
     {
         static const bool fixed_ok = [] { const char* e = getenv("GM_VOTE_FIXED"); return !(e && !strcmp(e, "0")); }();
-        b->use_fixed = fixed_ok && dense == 1 && slots_hint <= 0;
+        b->use_fixed = fixed_ok && (dense == 1 || dense == 2) && !getenv("GM_VOTE_KERNEL");      // k_vote_tiny*, k_vote_slots (all forms)
         if (b->use_fixed && (b->fixed_cands.ensure(2 * (size_t)b->n * GM_FIXED_C * sizeof(GmCand)) || b->fixed_cnt.ensure(2 * (size_t)b->n + 64))) return GM_E_NOMEM;
     }
     fill_dev_batch(b);

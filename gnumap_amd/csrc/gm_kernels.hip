@@ -1509,14 +1509,17 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
         }
         return;
     }
-    // ---- emit: NW step = kmin-th lowest step that voted.  Each lane looks at two table slots; the wave reserves room in its
-    // candidate shard for both with ONE returning global atomic (that round trip is the tail of the workgroup's life)
-    {
-        static_assert(T2 / NT == 2, "two table slots per lane");
-        bool em[2]; uint32_t ky[2], st[2];
+    // ---- emit: NW step = kmin-th lowest step that voted.  Wave 0 looks at all four table slots per lane and leaves the candidates
+    // in the read x strand's OWN slots (plain stores, no bump counter to wait for; k_cand_gather moves them into the shards and keeps
+    // the candidates of neighbouring reads together for the DP kernel); more than GM_FIXED_C of them: one returning atomic as before
+    if (tid < 64) {
+        static_assert(T2 == 256, "four table slots per lane of wave 0");
+        bool em[4]; uint32_t ky[4], st[4], nb[4];
+        unsigned long long mk[4];
+        uint32_t total = 0;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const uint32_t slot = (uint32_t)(q * NT + tid);
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t slot = (uint32_t)(q * 64 + lane);
             const uint32_t key = keys[slot], v = vals[slot];
             em[q] = key != 0u && v >= (uint32_t)p.kmin;
             ky[q] = key; st[q] = 0;
@@ -1527,19 +1530,29 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
                     st[q] = m ? (uint32_t)(__ffsll((long long)m) - 1) : 0u;
                 } else st[q] = v > 65535u ? 65535u : v;
             }
+            mk[q] = __builtin_amdgcn_ballot_w64(em[q]);
+            nb[q] = total;
+            total += (uint32_t)__popcll(mk[q]);
         }
-        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(em[0]), m1 = __builtin_amdgcn_ballot_w64(em[1]);
-        const uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1);
-        if (n0 + n1 != 0u) {                         // wave-uniform
+        if (total != 0u && b.fixed_cands && total <= GM_FIXED_C) {            // wave-uniform
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (em[q]) {
+                    const uint32_t idx = nb[q] + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk[q] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk[q], 0u));
+                    GmCand c;
+                    c.rs = rs; c.b = ky[q]; c.step = (uint16_t)st[q]; c.flags = 4; c.pad = 0; c.score = 0.0f;
+                    b.fixed_cands[(size_t)rs * GM_FIXED_C + idx] = c;
+                }
+            if (lane == 0) b.fixed_cnt[rs] = (uint8_t)total;
+        } else if (total != 0u) {                    // wave-uniform
             const uint32_t shard = blockIdx.x & (GM_NSHARD - 1);
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&b.shard_cnt[shard * GM_SHARD_STRIDE], n0 + n1);
+            if (lane == 0) base = atomicAdd(&b.shard_cnt[shard * GM_SHARD_STRIDE], total);
             base = __builtin_amdgcn_readfirstlane(base);
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
+            for (int q = 0; q < 4; ++q)
                 if (em[q]) {
-                    const unsigned long long mq = q ? m1 : m0;
-                    const uint32_t idx = base + (q ? n0 : 0u) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
+                    const uint32_t idx = base + nb[q] + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk[q] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk[q], 0u));
                     if (idx < b.cand_region) {
                         GmCand c;
                         c.rs = rs; c.b = ky[q]; c.step = (uint16_t)st[q]; c.flags = 4; c.pad = 0; c.score = 0.0f;
