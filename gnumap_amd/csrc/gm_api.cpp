@@ -102,11 +102,11 @@ struct gm_batch {
     uint32_t n = 0, stride = 0, max_seeds = 0, illumina_until = 0;
     DevBuf bases, quals, len, status, self_score, min_score, top_score, seeds, n_seeds, n_entries, entry_off, coords,
         rs_overflow, retry_list, retry_off, gtab_keys, gtab_vals, cands, fixed_cands, fixed_cnt, heavy_list, heavy_off, heavy_k0, heavy_k1, heavy_tmp, hit_count, hit_begin, hit_cursor, raw_hits, counters, small, shards, big_list,
-        tb_items, tb_ops, tb_len, dep_pos, dep_span, dep_w, dep_codes, dep_coff,
+        tb_items, tb_ops, tb_len,
         // grouping (process_hits' unique map) and output stage, gm_output.hip
         g_sorted, g_ord, g_lead, g_krank, g_khash, g_nmatch, g_mbegin, g_multi, g_big, g_bigdone, g_sk0, g_sk1, g_si0, g_si1, g_matches, g_mhit, g_positions, scan_tmp,
         o_small, o_posmatch, o_post, o_mapq, o_emit, o_reccnt, o_cigcnt, o_cigall, o_recoff, o_cigoff, o_recs, o_pool, o_codes;
-    PinBuf h_raw, h_top, h_hbegin, h_ord, h_post, h_mapq, h_emit, h_mhit;
+    PinBuf h_top, h_hbegin, h_ord, h_post, h_mapq, h_emit, h_mhit;
     std::vector<double> h_exp;          // exp(score) of every accepted hit of the last gm_map_batch (reused by gm_output_batch)
     uint64_t cache_hits = 0, cache_matches = 0;
     const void* resume_ptr = nullptr;   // set when gm_map_batch returned GM_E_CAPACITY: the next call with the same reads resumes at the copies
@@ -488,12 +488,12 @@ extern "C" void gm_batch_destroy(gm_batch* b) {
     DevBuf* all[] = { &b->bases, &b->quals, &b->len, &b->status, &b->self_score, &b->min_score, &b->top_score, &b->seeds, &b->n_seeds,
                       &b->n_entries, &b->entry_off, &b->coords, &b->rs_overflow, &b->retry_list, &b->retry_off, &b->gtab_keys, &b->gtab_vals,
                       &b->cands, &b->fixed_cands, &b->fixed_cnt, &b->heavy_list, &b->heavy_off, &b->heavy_k0, &b->heavy_k1, &b->heavy_tmp, &b->hit_count, &b->hit_begin, &b->hit_cursor, &b->raw_hits, &b->counters, &b->small, &b->shards, &b->big_list, &b->tb_items, &b->tb_ops,
-                      &b->tb_len, &b->dep_pos, &b->dep_span, &b->dep_w, &b->dep_codes, &b->dep_coff,
+                      &b->tb_len,
                       &b->g_sorted, &b->g_ord, &b->g_lead, &b->g_krank, &b->g_khash, &b->g_nmatch, &b->g_mbegin, &b->g_multi, &b->g_big, &b->g_bigdone, &b->g_sk0, &b->g_sk1, &b->g_si0, &b->g_si1, &b->g_matches, &b->g_mhit, &b->g_positions,
                       &b->scan_tmp, &b->o_small, &b->o_posmatch, &b->o_post, &b->o_mapq, &b->o_emit, &b->o_reccnt, &b->o_cigcnt, &b->o_cigall, &b->o_recoff, &b->o_cigoff,
                       &b->o_recs, &b->o_pool, &b->o_codes };
     for (DevBuf* d : all) d->release();
-    PinBuf* pins[] = { &b->h_raw, &b->h_top, &b->h_hbegin, &b->h_ord, &b->h_post, &b->h_mapq, &b->h_emit, &b->h_mhit };
+    PinBuf* pins[] = { &b->h_top, &b->h_hbegin, &b->h_ord, &b->h_post, &b->h_mapq, &b->h_emit, &b->h_mhit };
     for (PinBuf* d : pins) d->release();
     for (int i = 0; i < gm_batch::NS; ++i) { if (b->sub_streams[i]) (void)hipStreamDestroy(b->sub_streams[i]); b->sub_gk[i].release(); b->sub_gv[i].release(); }
     if (b->sub_ready) (void)hipEventDestroy(b->sub_ready);

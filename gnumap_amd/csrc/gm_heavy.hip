@@ -20,15 +20,6 @@
 #include <algorithm>
 #include "gm_internal.h"
 
-namespace {
-__device__ __forceinline__ unsigned long long gh_wave_incl(uint32_t x, int lane) {
-    uint32_t v = x;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(v, off); if (lane >= off) v += t; }
-    return v;
-}
-}  // namespace
-
 __global__ void __launch_bounds__(256) k_heavy_collect(GmDevBatch b, uint32_t heavy_min, uint32_t* n_heavy, uint32_t* heavy_list /* {rs, n_seeds, SA hits} triples */) {
     const uint32_t rs = blockIdx.x * 256 + threadIdx.x;
     if (rs >= 2 * b.n) return;

@@ -7,11 +7,17 @@
 //   k_seed             adaptive k-mer walk + backward search, one lane per read x strand (align_sequence inc/align_seq2_raw.cpp:192-243,
 //                                                                                         bwt_match_exact/bwt_2occ/bwt_occ src/bwt.c:107-239)
 //   k_locate_sampled   faithful locate: LF walk to the next sampled rank                  (bwt_sa src/bwt.c:86-96)
-//   k_vote[_retry]     locate + vote, one wavefront per read x strand, LDS vote table     (inc/align_seq2_raw.cpp:262-274, process_hits :28-40)
-//   k_nw               banded probabilistic NW score, 8 lanes per candidate               (get_align_score_begin src/bin_seq.cpp:781-850)
+//   k_vote_*           locate + vote: k_vote_slots (dense seeds, 2 waves per read x strand), k_vote_tiny / _tiny2 (one wave, few hits in
+//                      short runs), k_vote_sparse + k_vote_fast_list, k_vote, k_vote_block, k_vote_retry (exact table in HBM);
+//                      k_cand_gather moves the candidates the vote waves left in their own slots into the shards
+//                                                                                         (inc/align_seq2_raw.cpp:262-274, process_hits :28-40)
+//   k_nw_lane, k_nw    banded probabilistic NW score: 1 lane / 8 lanes per candidate      (get_align_score_begin src/bin_seq.cpp:781-850)
 //   k_scatter_hits     accepted candidates -> per-read CSR
-//   k_traceback        forward banded DP with move bits + traceback                       (get_align_score_w_traceback src/bin_seq.cpp:445-718)
-//   k_coverage_add     amount_genome[(pos+i)/bin] += w                                    (GenomeBwt::AddScore src/GenomeBwt.cpp:483-490)
+//   k_traceback_lane, k_traceback   forward banded DP with move bits + traceback: 1 lane / 8 lanes per kept sequence
+//                                                                                         (get_align_score_w_traceback src/bin_seq.cpp:445-718)
+//   k_coverage_add     amount_genome[(pos+i)/bin] += w for caller-given deposits (gm_coverage_add)   (GenomeBwt::AddScore src/GenomeBwt.cpp:483-490)
+// The unique map, CIGAR text, SAM rows and the coverage deposit of a batch are in gm_output.hip; the sorted-key vote path for read x
+// strands with very many SA hits is in gm_heavy.hip.
 //
 // Arithmetic: ranks/coordinates are u32 (reference < 2^32-1 ranks); scores are fp32 with the reference's operation
 // order and NO fused multiply-add (built with -ffp-contract=off; mul/add also go through __fmul_rn/__fadd_rn).
@@ -1593,7 +1599,6 @@ __device__ __forceinline__ void gm_vote_tiny_body(const GmDevIndex& ix, const Gm
     const uint32_t* const src = FULL ? ix.full_sa : b.coords + b.entry_off[rs];
     // ---- loads: step j holds groups 4j .. 4j+3, lane -> group 4j + lane / 16, rank = first rank + lane % 16
     uint32_t bpv[UU], tg[UU];
-    unsigned long long zero_votes = 0;               // (step, lane) pairs that hold a b = 0 vote: rare
     const uint32_t sub = (uint32_t)lane & 15u;
 #pragma unroll
     for (int j = 0; j < UU; ++j) {
@@ -1737,7 +1742,6 @@ __global__ void __launch_bounds__(64, 8) k_vote_tiny(GmDevIndex ix, GmDevParams 
     __shared__ uint8_t s_lt[GMT_LCAP];
     __shared__ uint2 s_desc[GMT_Q];                   // {SA rank (flat entry index if !FULL) of the group's first hit, read offset | tag << 16 | hits << 24}
     __shared__ uint32_t s_cnt0[64];
-    uint32_t* const s_r0 = reinterpret_cast<uint32_t*>(s_r0v);
     const uint32_t rs = blockIdx.x;                   // grid = 2n
     const int lane = threadIdx.x;
     GmSeed sd; sd.k = 0; sd.l = 0; sd.pos = 0;
