@@ -78,3 +78,40 @@ def test_cli_with_the_group_traceback_form(mode, tmp_path):
     assert "".join(l for l in open(out + ".sam") if not l.startswith("@PG")) == ref_text(mode, "sam")
     ext = "sgr" if "sgr" in m["tracks"] else "gmp"
     compare_tracks(open(out + "." + ext).read(), ref_text(mode, ext), 3 if ext == "sgr" else 8)
+
+
+def _fastq_head(n_reads):
+    lines = open(os.path.join(GOLDEN, "syn.fq"), "rb").read().split(b"\n")
+    return lines[:4 * n_reads]
+
+
+@pytest.mark.parametrize("extra", [["--chunk_reads=29"], ["--batch=40"]], ids=["chunks", "blocks"])
+def test_cli_stops_at_a_malformed_record_like_the_reference_parser(extra, tmp_path):
+    """a record whose '+' line is missing ends the input there (SeqReader::get_more_fastq resynchronisation is out of scope: the driver
+    stops, like the reference does on a broken file): everything before it is mapped exactly as in the full run, nothing after it"""
+    lines = _fastq_head(200)
+    bad = lines[:4 * 120] + [lines[480], lines[481], b"this is not a plus line", lines[483]] + lines[4 * 121:]
+    fq = tmp_path / "bad.fq"
+    fq.write_bytes(b"\n".join(bad) + b"\n")
+    out = str(tmp_path / "o")
+    r = subprocess.run([EXE, "-g", os.path.join(GOLDEN, "syn.fa"), "-o", out, "-a", "0.9"] + extra + [str(fq)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "malformed FASTQ record" in r.stderr
+    names = [l.split("\t")[0] for l in open(out + ".sam") if not l.startswith("@")]
+    first120 = {l[1:].decode() for l in lines[0:480:4]}
+    assert names and set(names) <= first120
+    ref = [l.split("\t")[0] for l in ref_text("default", "sam").splitlines() if not l.startswith("@")]
+    assert names == [n for n in ref if n in first120]
+
+
+def test_cli_empty_and_tiny_inputs(tmp_path):
+    out = str(tmp_path / "o")
+    empty = tmp_path / "empty.fq"; empty.write_bytes(b"")
+    r = subprocess.run([EXE, "-g", os.path.join(GOLDEN, "syn.fa"), "-o", out, "-a", "0.9", str(empty)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert [l for l in open(out + ".sam") if not l.startswith("@")] == []
+    one = tmp_path / "one.fq"; one.write_bytes(b"\n".join(_fastq_head(1)))          # no trailing newline
+    r = subprocess.run([EXE, "-g", os.path.join(GOLDEN, "syn.fa"), "-o", out, "-a", "0.9", "--gpus=1", str(one)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    got = [l for l in open(out + ".sam") if not l.startswith("@")]
+    assert got == [l + "\n" for l in ref_text("default", "sam").splitlines() if not l.startswith("@")][:len(got)] and len(got) >= 1
