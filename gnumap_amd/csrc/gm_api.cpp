@@ -1053,6 +1053,10 @@ extern "C" int gm_map_batch(gm_index* ix, const gm_params* p, gm_batch* b, const
     PhaseClock pc("gm_map_batch");
     hipStream_t st = S_(stream);
     int rc;
+    {   // test switch: behave as if blocks above this size outgrew a launch (exercises the callers' halving)
+        static const uint32_t test_max = [] { const char* e = getenv("GM_TEST_MAX_BLOCK"); return e ? (uint32_t)atoi(e) : 0u; }();
+        if (test_max && reads->n > test_max) { gm_set_error("GM_TEST_MAX_BLOCK: block treated as too large"); return GM_E_BATCH_TOO_LARGE; }
+    }
     // a call repeated with larger output buffers after GM_E_CAPACITY picks up where the first one stopped: the block is still mapped
     // and grouped in HBM (same reads pointer, same count), only the copies to the host are left to do
     const bool resume = b->resume_ptr != nullptr && b->resume_ptr == (const void*)reads->bases && b->n == reads->n;

@@ -115,3 +115,18 @@ def test_cli_empty_and_tiny_inputs(tmp_path):
     assert r.returncode == 0, r.stderr[-1500:]
     got = [l for l in open(out + ".sam") if not l.startswith("@")]
     assert got == [l + "\n" for l in ref_text("default", "sam").splitlines() if not l.startswith("@")][:len(got)] and len(got) >= 1
+
+
+@pytest.mark.parametrize("mode", ["default", "bs_all", "illumina"])
+def test_cli_maps_a_too_large_block_in_halves(mode, tmp_path):
+    """GM_E_BATCH_TOO_LARGE (more than 2^31 candidates in one block on a repeat-rich reference) makes the driver map the block as two
+    halves, recursively; GM_TEST_MAX_BLOCK makes the library report it for every block above 60 reads: same SAM, same tracks"""
+    m = MANIFEST[mode]
+    out = str(tmp_path / "mine")
+    r = subprocess.run([EXE, "-g", os.path.join(GOLDEN, "syn.fa"), "-o", out, "-a", "0.9"] + m["argv"] + [os.path.join(GOLDEN, m["fastq"])],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, GM_TEST_MAX_BLOCK="60"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "mapped in halves" in r.stderr
+    assert "".join(l for l in open(out + ".sam") if not l.startswith("@PG")) == ref_text(mode, "sam")
+    ext = "sgr" if "sgr" in m["tracks"] else "gmp"
+    compare_tracks(open(out + "." + ext).read(), ref_text(mode, ext), 3 if ext == "sgr" else 8)
