@@ -653,7 +653,7 @@ int main(int argc, char** argv) {
             if (!b->failed && b->index <= stop_block.load()) {
                 std::vector<uint64_t> offs(b->text.size());
                 for (size_t k = 0; k < b->text.size(); ++k) { offs[k] = file_off; file_off += b->text[k].size(); }
-                const int nt = (int)std::min<size_t>(4, b->text.size());
+                const int nt = (int)std::min<size_t>(8, b->text.size());
                 std::atomic<size_t> nextp{ 0 }; std::atomic<int> bad{ 0 };
                 auto job = [&] { for (size_t k; (k = nextp++) < b->text.size();) if (!b->text[k].empty() && !pwrite_all(b->text[k].data(), b->text[k].size(), offs[k])) bad = 1; };
                 std::vector<std::thread> ws;

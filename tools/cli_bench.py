@@ -54,6 +54,9 @@ def main():
     out = os.path.join(a.dir, "out")
     env = dict(os.environ)
     for run in ("index+map", "map"):
+        for ext in (".sam", ".sgr", ".gmp"):                     # a fresh output file each time (overwriting 8 GB of page cache is a different test)
+            if os.path.exists(out + ext):
+                os.remove(out + ext)
         t0 = time.time()
         r = subprocess.run([exe, "-g", fa, "-o", out, "-v", "1"] + a.args.split() + [fq], capture_output=True, text=True, env=env)
         dt = time.time() - t0
