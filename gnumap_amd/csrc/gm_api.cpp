@@ -102,7 +102,7 @@ struct gm_batch {
     uint32_t n = 0, stride = 0, max_seeds = 0, illumina_until = 0;
     DevBuf bases, quals, len, status, self_score, min_score, top_score, seeds, n_seeds, n_entries, entry_off, coords,
         rs_overflow, retry_list, retry_off, gtab_keys, gtab_vals, cands, fixed_cands, fixed_cnt, heavy_list, heavy_off, heavy_k0, heavy_k1, heavy_tmp, hit_count, hit_begin, hit_cursor, raw_hits, counters, small, shards, big_list,
-        tb_items, tb_ops, tb_len,
+        tb_items, tb_ops, tb_len, band_moves,
         // grouping (process_hits' unique map) and output stage, gm_output.hip
         g_sorted, g_ord, g_lead, g_krank, g_khash, g_nmatch, g_mbegin, g_multi, g_big, g_bigdone, g_sk0, g_sk1, g_si0, g_si1, g_matches, g_mhit, g_positions, scan_tmp,
         o_small, o_posmatch, o_post, o_mapq, o_emit, o_reccnt, o_cigcnt, o_cigall, o_recoff, o_cigoff, o_recs, o_pool, o_codes;
@@ -169,7 +169,7 @@ extern "C" int gm_params_finalize(gm_params* p) {
     if (p->finalized) return GM_OK;
     if (p->mer < 1 || p->mer > 32) { gm_set_error("-m/--mer_size: must be 1..32 (MAX_MER_SIZE)"); return GM_E_ARG; }
     if (p->min_seed_hits < 1) { gm_set_error("-k/--num_seed: Invalid matching seed number"); return GM_E_ARG; }
-    if (p->max_gap != 3) { gm_set_error("-M/--max_gap: this build's kernels implement the default band (3)"); return GM_E_UNSUPPORTED; }
+    if (p->max_gap < 1 || p->max_gap > 7) { gm_set_error("-M/--max_gap: 1 .. 7 (band rows of up to 17 cells)"); return GM_E_UNSUPPORTED; }
     if (p->jump <= 0) p->jump = p->mer / 2;
     if (p->jump < 1) p->jump = 1;
     p->match *= p->adjust; p->transition *= p->adjust; p->transversion *= p->adjust; p->gap *= p->adjust;
@@ -260,7 +260,7 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
         d_tab = it->second.as<float>();
     }
     dp.mer = p->mer; dp.jump = p->jump; dp.kmin = p->min_seed_hits; dp.nw = p->nw; dp.fast = p->fast;
-    dp.pos_strand = p->pos_strand; dp.neg_strand = p->neg_strand; dp.align_is_fraction = p->align_is_fraction;
+    dp.pos_strand = p->pos_strand; dp.neg_strand = p->neg_strand; dp.align_is_fraction = p->align_is_fraction; dp.max_gap = p->max_gap;
     { const char* e = getenv("GM_DBG"); dp.dbg = e ? atoi(e) : 0; }
     // k-mer interval table: the last T characters of every seed are one lookup (GM_KMER_TABLE=0 keeps the pure occ walk;
     // GM_KMER_TABLE=<T> picks another suffix length, at most 16)
@@ -488,7 +488,7 @@ extern "C" void gm_batch_destroy(gm_batch* b) {
     DevBuf* all[] = { &b->bases, &b->quals, &b->len, &b->status, &b->self_score, &b->min_score, &b->top_score, &b->seeds, &b->n_seeds,
                       &b->n_entries, &b->entry_off, &b->coords, &b->rs_overflow, &b->retry_list, &b->retry_off, &b->gtab_keys, &b->gtab_vals,
                       &b->cands, &b->fixed_cands, &b->fixed_cnt, &b->heavy_list, &b->heavy_off, &b->heavy_k0, &b->heavy_k1, &b->heavy_tmp, &b->hit_count, &b->hit_begin, &b->hit_cursor, &b->raw_hits, &b->counters, &b->small, &b->shards, &b->big_list, &b->tb_items, &b->tb_ops,
-                      &b->tb_len,
+                      &b->tb_len, &b->band_moves,
                       &b->g_sorted, &b->g_ord, &b->g_lead, &b->g_krank, &b->g_khash, &b->g_nmatch, &b->g_mbegin, &b->g_multi, &b->g_big, &b->g_bigdone, &b->g_sk0, &b->g_sk1, &b->g_si0, &b->g_si1, &b->g_matches, &b->g_mhit, &b->g_positions,
                       &b->scan_tmp, &b->o_small, &b->o_posmatch, &b->o_post, &b->o_mapq, &b->o_emit, &b->o_reccnt, &b->o_cigcnt, &b->o_cigall, &b->o_recoff, &b->o_cigoff,
                       &b->o_recs, &b->o_pool, &b->o_codes };
@@ -535,6 +535,7 @@ static void fill_dev_batch(gm_batch* b) {
     d.raw_hits = b->raw_hits.as<GmRawHit>(); d.raw_cap = b->raw_cap;
     d.counters = b->counters.as<unsigned long long>();
     d.n_retry = b->small.as<uint32_t>() + 1; d.n_big = b->small.as<uint32_t>() + 2; d.big_list = b->big_list.as<uint32_t>();
+    d.band_moves = b->band_moves.as<unsigned long long>(); d.band_moves_words = b->band_moves.cap / 8;
 }
 
 extern "C" int gm_batch_upload(gm_batch* b, const gm_params* p, const gm_reads* r, void* stream) {
@@ -1194,6 +1195,7 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
     if (n_p) HIPCHK(hipMemcpyAsync(b->g_positions.p, hits->positions, (size_t)n_p * sizeof(gm_pos), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(b->o_posmatch.p, 0xFF, (size_t)(n_p + 1) * 4, st));
     HIPCHK(hipMemsetAsync(b->o_small.p, 0, 64, st));
+    if (p->max_gap != 3 && b->band_moves.ensure(gm_band_moves_words(n_m, b->stride) * 8)) return GM_E_NOMEM;
     fill_dev_batch(b);
     KCHK(gmk_out_items(d_m, n_m, 0, b->tb_items.as<GmCand>(), b->o_posmatch.as<uint32_t>(), st));
     // one traceback per ScoredSeq, oriented by its first strand (NormalScoredSeq::score, ScoredSeq::get_SAM); the kernel also leaves the
@@ -1392,6 +1394,7 @@ extern "C" int gm_dev_traceback(gm_index* ix, const gm_params* p, const gm_reads
         if (b->tb_items.ensure((size_t)n * sizeof(GmCand) + 16) || b->tb_ops.ensure((size_t)n * ow * 8 + 16) || b->tb_len.ensure((size_t)n * 2 + 16)) { rc = GM_E_NOMEM; break; }
         if (n && hipMemcpy(b->tb_items.p, c.data(), (size_t)n * sizeof(GmCand), hipMemcpyHostToDevice) != hipSuccess) { rc = GM_E_HIP; break; }
         if (n && hipMemset(b->tb_ops.p, 0, (size_t)n * ow * 8) != hipSuccess) { rc = GM_E_HIP; break; }
+        if (p->max_gap != 3) { if (b->band_moves.ensure(gm_band_moves_words(n, b->stride) * 8)) { rc = GM_E_NOMEM; break; } fill_dev_batch(b); }
         if (gmk_traceback(ix->dev, dp, b->dev, b->tb_items.as<GmCand>(), n, b->tb_ops.as<unsigned long long>(), ow, b->tb_len.as<uint16_t>(), nullptr, nullptr, nullptr, nullptr)) { rc = GM_E_HIP; break; }
         if (n && hipMemcpy(packed.data(), b->tb_ops.p, (size_t)n * ow * 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = GM_E_HIP; break; }
         if (n && hipMemcpy(ops_len, b->tb_len.p, (size_t)n * 2, hipMemcpyDeviceToHost) != hipSuccess) { rc = GM_E_HIP; break; }

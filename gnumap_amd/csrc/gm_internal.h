@@ -29,6 +29,7 @@ struct GmDevIndex {
 
 struct GmDevParams {
     int mer, jump, kmin, nw, fast, pos_strand, neg_strand, align_is_fraction;
+    int max_gap;                    // -M: band half-width of the DP (3 = the register-band kernels, anything else = gm_band.hip)
     uint32_t hcap;
     int dbg;                        // GM_DBG bits for kernel timing experiments (0 in production)
     float gap, align_score, cutoff;
@@ -104,6 +105,8 @@ struct GmDevBatch {
     uint32_t* n_retry;              // device counter
     uint32_t* n_big;                // device counter: read x strands handed from k_vote_sparse to k_vote_fast_list
     uint32_t* big_list;             // 2n
+    unsigned long long* band_moves; // -M other than 3: move words of k_traceback_band, [row][item]; band_moves_words of them
+    uint64_t band_moves_words;
 };
 
 // device mirrors of the public records (include/gnumap_hip.h: gm_match, gm_pos, gm_sam_rec; layouts asserted in gm_api.cpp), so that
@@ -155,6 +158,14 @@ int gmk_heavy_chunk(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch
                     size_t tmp_bytes, unsigned item_bits, void* stream);
 int gmk_vote_retry(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, uint32_t j0, uint32_t n_retry, void* stream);
 int gmk_nw(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint32_t n_cands, void* stream);
+// gm_band.hip: the DP kernels for a band half-width other than 3 (-M)
+int gmk_nw_band(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint32_t n_cands, int G, void* stream);
+int gmk_traceback_band(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, const GmCand* items, uint32_t n, unsigned long long* ops,
+                       uint32_t ops_words, uint16_t* ops_len, const uint8_t* emit, uint32_t* cig_cnt, uint32_t* max_span, int G, void* stream);
+inline uint64_t gm_band_moves_words(uint32_t n, uint32_t stride) {          // at most 512 MB, at least one workgroup's worth of items
+    const uint64_t rows = (uint64_t)stride + 1, cap = (512ull << 20) / 8, all = (uint64_t)n * rows;
+    return all < cap ? all : (cap > 128 * rows ? cap : 128 * rows);
+}
 int gmk_compact(const GmDevBatch& b, void* stream);
 int gmk_scan_hits(const GmDevBatch& b, void* stream);
 int gmk_scatter(const GmDevBatch& b, uint32_t grid, void* stream);

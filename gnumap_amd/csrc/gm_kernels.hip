@@ -2860,6 +2860,7 @@ static inline uint32_t lp_of(uint32_t stride) { return (stride + 7u) & ~7u; }
 
 int gmk_nw(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint32_t n_cands, void* stream) {
     if (b.n == 0) return 0;
+    if (p.max_gap != 3) return gmk_nw_band(ix, p, b, n_cands, p.max_gap, stream);
     static const bool wave_form = [] { const char* e = getenv("GM_NW"); return e && !strcmp(e, "wave"); }();
     if (!wave_form) {
         // ~4 candidates per lane: fewer, larger workgroups leave a long tail (measured at 17 M candidates: 2048 workgroups 6.1 ms,
@@ -2915,6 +2916,7 @@ int gmk_locate(const GmDevIndex& ix, const uint32_t* ranks, uint32_t n, int use_
 int gmk_traceback(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, const GmCand* items, uint32_t n,
                   unsigned long long* ops, uint32_t ops_words, uint16_t* ops_len, const uint8_t* emit, uint32_t* cig_cnt, uint32_t* max_span, void* stream) {
     if (n == 0) return 0;
+    if (p.max_gap != 3) return gmk_traceback_band(ix, p, b, items, n, ops, ops_words, ops_len, emit, cig_cnt, max_span, p.max_gap, stream);
     uint32_t Lp = lp_of(b.stride);
     static const bool group_form = [] { const char* e = getenv("GM_TRACEBACK"); return e && !strcmp(e, "group"); }();   // GM_TRACEBACK=group: the 8-lane form for every length (tests)
     if (!group_form && Lp <= 511) {              // lane form: one lane per item, move rows in LDS

@@ -79,7 +79,7 @@ typedef struct {
     int min_seed_hits;          /* -k  gMIN_JUMP_MATCHES (2) */
     uint32_t max_kmer_hits;     /* -h  gMAX_KMER_SIZE (0 = unlimited) */
     uint32_t max_matches;       /* -T  gMAX_MATCHES (1000) */
-    int max_gap;                /* -M  gMAX_GAP (3); the kernels are built for 3 */
+    int max_gap;                /* -M  gMAX_GAP (3); 1 .. 7 (3 runs the register-band kernels, the rest the LDS-band kernels of gm_band.hip) */
     int nw;                     /* !--no_nw */
     int fast;                   /* --fast */
     int unique_only;            /* -u */

@@ -60,6 +60,12 @@ MODES = {
     # finalized parameters (OracleLib.apply_subst / gm_params_load_subst)
     "subst_all":      (["-S", "subst.txt", "--print_all_sam"], dict(print_all_sam=1, _subst="subst.txt"), "syn.fq"),
     "subst_bs":       (["-S", "subst.txt", "-b"], dict(mode=1, _subst="subst.txt"), "syn.fq"),
+    # -M: band half-width of the DP (gMAX_GAP); the product runs these on the generic band kernels (gm_band.hip)
+    "M1":             (["-M", "1"], dict(max_gap=1), "syn.fq"),
+    "M2_all":         (["-M", "2", "--print_all_sam"], dict(max_gap=2, print_all_sam=1), "syn.fq"),
+    "M5_all":         (["-M", "5", "-a", "0.8", "--print_all_sam"], dict(max_gap=5, align_score=0.8, print_all_sam=1), "syn.fq"),
+    "M7_bs":          (["--max_gap=7", "-b"], dict(max_gap=7, mode=1), "syn.fq"),
+    "M4_ill":         (["-M", "4", "--illumina"], dict(max_gap=4, illumina=1), "syn_ill.fq"),
 }
 
 

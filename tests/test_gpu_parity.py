@@ -93,6 +93,60 @@ def test_traceback_cigars(ix_full, golden, packed):
         assert rle(o) == bytes(golden["tb_cigar"][i]), i
 
 
+def _indel_reads(syn_fa, n, seed, lens=(100, 36, 151, 7, 300)):
+    """reads cut from chrA with substitutions AND short insertions / deletions (1 .. 6 bases), so that the best path uses the band"""
+    rng = np.random.default_rng(seed)
+    genome = b"".join(l.strip() for l in open(syn_fa, "rb") if not l.startswith(b">")).upper().replace(b"N", b"A")
+    reads, begins = [], []
+    for k in range(n):
+        L = int(lens[k % len(lens)])
+        p0 = int(rng.integers(1000, 130_000))
+        s = bytearray(genome[p0:p0 + L + 16])
+        for _ in range(int(rng.integers(0, 4))):
+            q = int(rng.integers(1, max(2, L - 8))); w = int(rng.integers(1, 7))
+            if rng.integers(0, 2): del s[q:q + w]
+            else: s[q:q] = bytes(b"ACGT"[int(x)] for x in rng.integers(0, 4, w))
+        s = s[:L]
+        for q in rng.integers(0, L, max(1, L // 30)):
+            s[q] = b"ACGT"[int(rng.integers(0, 4))]
+        reads.append((f"indel{k}_{p0}", bytes(s), bytes((33 + rng.integers(2, 41, L)).astype(np.uint8))))
+        begins.append(p0)
+    return reads, begins
+
+
+@pytest.mark.parametrize("G", [1, 2, 3, 4, 5, 7])
+def test_band_width_kernels_match_oracle(G, ix_full, oracle, oix, syn_fa):
+    """-M / --max_gap: DP score bits and traceback operations of the generic band kernels (gm_band.hip; G = 3 runs the register-band
+    kernels on the same inputs) against the oracle's restatement of bin_seq.cpp:781-850 / :445-718, candidates shifted by up to
+    G + 2 bases either way so that paths run along and into the band's edge"""
+    reads, begins = _indel_reads(syn_fa, 60, 100 + G)
+    B, Q, Ln = g.pack_reads([r[1] for r in reads], [r[2] for r in reads])
+    p = g.Params(max_gap=G); op = oracle.params(max_gap=G)
+    ridx, strand, pos = [], [], []
+    for i, b0 in enumerate(begins):
+        for sh in (0, -1, 2, -(G + 2), G + 1):
+            for st in (0, 1):
+                ridx.append(i); strand.append(st); pos.append(b0 + sh)
+    ridx = np.array(ridx, np.uint32); strand = np.array(strand, np.uint8); pos = np.array(pos, np.uint64)
+    score, valid = ix_full.dev_nw_score(p, B, Q, Ln, ridx, strand, pos)
+    ops = ix_full.dev_traceback(p, B, Q, Ln, ridx, strand, pos)
+    assert valid.all()
+    n_gapped = 0
+    for k in range(len(ridx)):
+        name, seq, qual = reads[ridx[k]]
+        P = oracle.pwm(seq, qual); cons = seq
+        if strand[k]:
+            P = revcomp_pwm(P); cons = revcomp_str(seq).upper()
+        w = oracle.window(oix, int(pos[k]), len(seq))
+        assert len(w) == len(seq)
+        want = np.float32(oracle.lib.gmo_nw_score(C.byref(op), np.ascontiguousarray(P, np.float32), len(seq), w))
+        assert score[k].view(np.uint32) == want.view(np.uint32), (name, k, score[k], want)
+        _, alen, cig = oracle.traceback(op, P, cons, w)
+        assert len(ops[k]) == alen and rle(ops[k]) == cig, (name, k, rle(ops[k]), cig)
+        n_gapped += (b"I" in cig) or (b"D" in cig)
+    assert n_gapped > 50
+
+
 # ------------------------------------------------------------------ the whole hot path vs the oracle
 CONFIGS = {
     "default": {},
@@ -115,6 +169,10 @@ CONFIGS = {
     "a07_q50": dict(align_score=0.7, cutoff=50.0),
     "m20_j2": dict(mer=20, jump=2),                             # 40 seeds per strand: 64-bit step masks inside k_vote_slots (<= 40 slots)
     "m6_j2": dict(mer=6, jump=2),                               # 48 seeds x ~70 hits per strand: > 32 seeds (64-bit step masks), > 40 slots (list kernel)
+    "M1": dict(max_gap=1),                                      # -M: generic band kernels (gm_band.hip)
+    "M2_a07": dict(max_gap=2, align_score=0.7),
+    "M5_bs": dict(max_gap=5, mode=1),
+    "M7_k1": dict(max_gap=7, min_seed_hits=1, mer=14),
 }
 
 
@@ -220,7 +278,7 @@ def _long_reads(syn_fa, L, n, seed):
 
 
 @pytest.mark.parametrize("L,kw", [(250, {}), (330, dict(mer=12, jump=4)), (600, {}), (1000, dict(mer=16, jump=8)),
-                                  (1500, dict(mer=16, jump=8)), (2048, dict(mer=20, jump=10))])      # > 1280 bases: k_seed tiles of fewer reads (LDS budget)
+                                  (1500, dict(mer=16, jump=8)), (2048, dict(mer=20, jump=10)), (600, dict(max_gap=5)), (2048, dict(mer=20, jump=10, max_gap=1))])      # > 1280 bases: k_seed tiles of fewer reads (LDS budget)
 def test_long_reads_all_vote_kernels(L, kw, ix_full, oracle, oix, syn_fa):
     """L=250: 64-bit step masks; L=600 at j=5: more than 64 seeds -> the ordered vote kernel"""
     reads = _long_reads(syn_fa, L, 24, L)
