@@ -102,13 +102,14 @@ struct gm_batch {
     uint32_t n = 0, stride = 0, max_seeds = 0, illumina_until = 0;
     DevBuf bases, quals, len, status, self_score, min_score, top_score, seeds, n_seeds, n_entries, entry_off, coords,
         rs_overflow, retry_list, retry_off, gtab_keys, gtab_vals, cands, fixed_cands, fixed_cnt, heavy_list, heavy_off, heavy_k0, heavy_k1, heavy_tmp, hit_count, hit_begin, hit_cursor, raw_hits, counters, small, shards, big_list,
-        tb_items, tb_ops, tb_len, band_moves,
+        tb_items, tb_ops, tb_len, band_moves, pack,
         // grouping (process_hits' unique map) and output stage, gm_output.hip
         g_sorted, g_ord, g_lead, g_krank, g_khash, g_nmatch, g_mbegin, g_multi, g_big, g_bigdone, g_sk0, g_sk1, g_si0, g_si1, g_matches, g_mhit, g_positions, scan_tmp,
         o_small, o_posmatch, o_post, o_mapq, o_emit, o_reccnt, o_cigcnt, o_cigall, o_recoff, o_cigoff, o_recs, o_pool, o_codes;
     PinBuf h_top, h_hbegin, h_ord, h_post, h_mapq, h_emit, h_mhit;
     std::vector<double> h_exp;          // exp(score) of every accepted hit of the last gm_map_batch (reused by gm_output_batch)
     uint64_t cache_hits = 0, cache_matches = 0;
+    bool use_pack = false;              // the fused seed lookup is on for this pass (k_prep writes the 2-bit read forms)
     const void* resume_ptr = nullptr;   // set when gm_map_batch returned GM_E_CAPACITY: the next call with the same reads resumes at the copies
     uint32_t cand_cap = 0;
     bool use_fixed = false;             // k_vote_tiny* leave their candidates in per read x strand slots (gathered by k_cand_gather)
@@ -261,6 +262,7 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
     }
     dp.mer = p->mer; dp.jump = p->jump; dp.kmin = p->min_seed_hits; dp.nw = p->nw; dp.fast = p->fast;
     dp.pos_strand = p->pos_strand; dp.neg_strand = p->neg_strand; dp.align_is_fraction = p->align_is_fraction; dp.max_gap = p->max_gap;
+    dp.fused = 0; dp.heavy_min = 0xFFFFFFFFu;
     { const char* e = getenv("GM_DBG"); dp.dbg = e ? atoi(e) : 0; }
     // k-mer interval table: the last T characters of every seed are one lookup (GM_KMER_TABLE=0 keeps the pure occ walk;
     // GM_KMER_TABLE=<T> picks another suffix length, at most 16)
@@ -488,7 +490,7 @@ extern "C" void gm_batch_destroy(gm_batch* b) {
     DevBuf* all[] = { &b->bases, &b->quals, &b->len, &b->status, &b->self_score, &b->min_score, &b->top_score, &b->seeds, &b->n_seeds,
                       &b->n_entries, &b->entry_off, &b->coords, &b->rs_overflow, &b->retry_list, &b->retry_off, &b->gtab_keys, &b->gtab_vals,
                       &b->cands, &b->fixed_cands, &b->fixed_cnt, &b->heavy_list, &b->heavy_off, &b->heavy_k0, &b->heavy_k1, &b->heavy_tmp, &b->hit_count, &b->hit_begin, &b->hit_cursor, &b->raw_hits, &b->counters, &b->small, &b->shards, &b->big_list, &b->tb_items, &b->tb_ops,
-                      &b->tb_len, &b->band_moves,
+                      &b->tb_len, &b->band_moves, &b->pack,
                       &b->g_sorted, &b->g_ord, &b->g_lead, &b->g_krank, &b->g_khash, &b->g_nmatch, &b->g_mbegin, &b->g_multi, &b->g_big, &b->g_bigdone, &b->g_sk0, &b->g_sk1, &b->g_si0, &b->g_si1, &b->g_matches, &b->g_mhit, &b->g_positions,
                       &b->scan_tmp, &b->o_small, &b->o_posmatch, &b->o_post, &b->o_mapq, &b->o_emit, &b->o_reccnt, &b->o_cigcnt, &b->o_cigall, &b->o_recoff, &b->o_cigoff,
                       &b->o_recs, &b->o_pool, &b->o_codes };
@@ -536,6 +538,7 @@ static void fill_dev_batch(gm_batch* b) {
     d.counters = b->counters.as<unsigned long long>();
     d.n_retry = b->small.as<uint32_t>() + 1; d.n_big = b->small.as<uint32_t>() + 2; d.big_list = b->big_list.as<uint32_t>();
     d.band_moves = b->band_moves.as<unsigned long long>(); d.band_moves_words = b->band_moves.cap / 8;
+    d.pack = b->use_pack ? b->pack.as<uint32_t>() : nullptr; d.pack_w2 = gm_pack_w2(b->stride); d.pack_words = gm_pack_words(b->stride);
 }
 
 extern "C" int gm_batch_upload(gm_batch* b, const gm_params* p, const gm_reads* r, void* stream) {
@@ -719,6 +722,20 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
             if (prc <= 0) return prc;                    // done, or a real error
         }
     }
+    // read x strands with very many SA hits (repeat seeds without -h) leave the ordinary vote kernels before they start: sorted-key
+    // path of gm_heavy.hip, routed by the seed search's own hit count.  GM_HEAVY_MIN / GM_HEAVY_BUDGET (keys per chunk) are test switches.
+    static const uint32_t heavy_min = [] { const char* e = getenv("GM_HEAVY_MIN"); return e ? (uint32_t)atoll(e) : 16384u; }();
+    static const uint64_t heavy_budget = [] { const char* e = getenv("GM_HEAVY_BUDGET"); return e ? (uint64_t)atoll(e) : (uint64_t)1 << 27; }();
+    dp.heavy_min = heavy_min;
+    // seed lookup inside the one-wave vote kernels (k_vote_tiny / k_vote_tiny2 on the full SA, the k-mer table covering the whole
+    // seed): no k_seed launch, no seed rows through HBM.  GM_SEED_FUSED=0 keeps the two-kernel form.
+    {
+        static const bool fused_ok = [] { const char* e = getenv("GM_SEED_FUSED"); return !(e && !strcmp(e, "0")); }();
+        dp.fused = fused_ok && use_full && dense == 1 && slots_hint <= 0 && !getenv("GM_VOTE_KERNEL") && b->max_seeds <= 64 && dp.kmer_tab && dp.kmer_ctab && dp.kmer_T == p->mer &&
+                   p->mer <= 16 && p->jump >= 1 && !(dp.dbg & 128);
+        b->use_pack = dp.fused != 0;
+        if (b->use_pack && b->pack.ensure((size_t)b->n * gm_pack_words(b->stride) * 4 + 64)) return GM_E_NOMEM;
+    }
     // the one-wave vote kernels leave their candidates in per read x strand slots (no bump counter on the wave's critical path)
     {
         static const bool fixed_ok = [] { const char* e = getenv("GM_VOTE_FIXED"); return !(e && !strcmp(e, "0")); }();
@@ -728,7 +745,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
     fill_dev_batch(b);
     HIPCHK(hipMemsetAsync(b->counters.p, 0, GMK_N * 8, st));
     { KTimer t(b, GM_K_PREP, st); KCHK(gmk_prep(ix->dev, dp, b->dev, st)); }
-    { KTimer t(b, GM_K_SEED, st); KCHK(gmk_seed(ix->dev, dp, b->dev, st)); }
+    if (!dp.fused) { KTimer t(b, GM_K_SEED, st); KCHK(gmk_seed(ix->dev, dp, b->dev, st)); }
     unsigned long long ctr[GMK_N];
     if (!use_full) {
         // faithful mode: locate every SA hit by LF walks into coords[] first (exact size from the seed kernel)
@@ -739,15 +756,12 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         KCHK(gmk_scan_entries(b->dev, st));
         { KTimer t(b, GM_K_LOCATE, st); KCHK(gmk_locate_sampled(ix->dev, b->dev, st)); }
     }
-    // read x strands with very many SA hits (repeat seeds without -h) leave the ordinary vote kernels before they start: sorted-key
-    // path of gm_heavy.hip, routed by k_seed's own hit count.  GM_HEAVY_MIN / GM_HEAVY_BUDGET (keys per chunk) are test switches.
-    static const uint32_t heavy_min = [] { const char* e = getenv("GM_HEAVY_MIN"); return e ? (uint32_t)atoll(e) : 16384u; }();
-    static const uint64_t heavy_budget = [] { const char* e = getenv("GM_HEAVY_BUDGET"); return e ? (uint64_t)atoll(e) : (uint64_t)1 << 27; }();
     std::vector<uint32_t> heavy;                     // {rs, n_seeds, SA hits} triples
-    {
-        if (b->heavy_list.ensure(3 * 2 * (size_t)b->n * 4 + 64)) return GM_E_NOMEM;
+    if (b->heavy_list.ensure(3 * 2 * (size_t)b->n * 4 + 64)) return GM_E_NOMEM;
+    // the list of the heavy path: right after k_seed, or (fused form) after the first vote launch, which left them alone
+    auto collect_heavy = [&]() -> int {
         HIPCHK(hipMemsetAsync(b->small.as<uint32_t>() + 3, 0, 4, st));
-        KCHK(gmk_heavy_collect(b->dev, heavy_min, b->small.as<uint32_t>() + 3, b->heavy_list.as<uint32_t>(), st));
+        KCHK(gmk_heavy_collect(b->dev, heavy_min, b->small.as<uint32_t>() + 3, b->heavy_list.as<uint32_t>(), dp.fused, st));
         uint32_t nh = 0;
         HIPCHK(hipMemcpyAsync(&nh, b->small.as<uint32_t>() + 3, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -756,7 +770,9 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
             heavy.resize(3 * (size_t)nh);
             HIPCHK(hipMemcpy(heavy.data(), b->heavy_list.p, heavy.size() * 4, hipMemcpyDeviceToHost));
         }
-    }
+        return GM_OK;
+    };
+    if (!dp.fused) { rc = collect_heavy(); if (rc) return rc; }
     auto run_heavy = [&]() -> int {                  // expand + sort + run-length vote, chunk by chunk under the key budget
         const uint32_t nh = (uint32_t)(heavy.size() / 3);
         std::vector<unsigned long long> off;
@@ -798,7 +814,12 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         HIPCHK(hipMemsetAsync(b->counters.as<unsigned long long>() + GMK_HEAVY_SLOTS, 0, 8, st));
         HIPCHK(hipMemsetAsync(b->counters.as<unsigned long long>() + GMK_OVERFLOW_RS, 0, 8, st));
         if (b->use_fixed) HIPCHK(hipMemsetAsync(b->fixed_cnt.p, 0, 2 * (size_t)b->n, st));
+        if (dp.fused) {                              // the seed search runs inside the vote launch: its work counters start over with it
+            HIPCHK(hipMemsetAsync(b->counters.as<unsigned long long>() + GMK_KMERS, 0, 4 * 8, st));            // KMERS, OCC, SEEDS, SA_HITS
+            HIPCHK(hipMemsetAsync(b->counters.as<unsigned long long>() + GMK_OCC_BLOCKS, 0, 2 * 8, st));       // OCC_BLOCKS, TAB_LOOKUPS
+        }
         { KTimer t(b, GM_K_VOTE, st); KCHK(gmk_vote(ix->dev, dp, b->dev, use_full, dense, slots_hint, st)); KCHK(gmk_cand_gather(b->dev, st)); }
+        if (dp.fused) { heavy.clear(); rc = collect_heavy(); if (rc) return rc; }
         uint32_t small[2];
         HIPCHK(hipMemcpyAsync(small, b->small.p, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(ctr, b->counters.p, sizeof ctr, hipMemcpyDeviceToHost, st));

@@ -20,14 +20,39 @@
 #include <algorithm>
 #include "gm_internal.h"
 
-__global__ void __launch_bounds__(256) k_heavy_collect(GmDevBatch b, uint32_t heavy_min, uint32_t* n_heavy, uint32_t* heavy_list /* {rs, n_seeds, SA hits} triples */) {
-    const uint32_t rs = blockIdx.x * 256 + threadIdx.x;
-    if (rs >= 2 * b.n) return;
-    const uint32_t ns = b.n_seeds[rs];
-    if (ns == 0 || b.n_entries[rs] <= heavy_min) return;
-    const uint32_t j = atomicAdd(n_heavy, 1u);
-    heavy_list[3 * j] = rs; heavy_list[3 * j + 1] = ns; heavy_list[3 * j + 2] = b.n_entries[rs];
-    b.n_seeds[rs] = 0;                                   // the ordinary vote kernels see nothing to do
+// sum_counters: the seeds were looked up inside the vote kernel (GmDevParams::fused), which leaves the per read x strand counts only:
+// the work counters k_seed keeps (one k-mer and one table probe per seed; SA hits) are summed here, one atomic per wave
+__global__ void __launch_bounds__(256) k_heavy_collect(GmDevBatch b, uint32_t heavy_min, uint32_t* n_heavy, uint32_t* heavy_list /* {rs, n_seeds, SA hits} triples */,
+                                                       int sum_counters) {
+    unsigned long long a = 0, e = 0;
+    const uint32_t n2 = 2 * b.n, n4 = n2 >> 2;           // four read x strands per thread and step: one 8-byte and one 16-byte load
+    auto take = [&](uint32_t rs, uint32_t ns, uint32_t ne) {
+        a += ns; e += ne;
+        if (ns == 0 || ne <= heavy_min) return;
+        const uint32_t j = atomicAdd(n_heavy, 1u);
+        heavy_list[3 * j] = rs; heavy_list[3 * j + 1] = ns; heavy_list[3 * j + 2] = ne;
+        b.n_seeds[rs] = 0;                               // the ordinary vote kernels see nothing to do
+    };
+    for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < n4; q += gridDim.x * 256) {
+        const uint2 s4 = reinterpret_cast<const uint2*>(b.n_seeds)[q];
+        const uint4 e4 = reinterpret_cast<const uint4*>(b.n_entries)[q];
+        take(4 * q, s4.x & 0xFFFFu, e4.x); take(4 * q + 1, s4.x >> 16, e4.y); take(4 * q + 2, s4.y & 0xFFFFu, e4.z); take(4 * q + 3, s4.y >> 16, e4.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n2 & 3u)) { const uint32_t rs = 4 * n4 + threadIdx.x; take(rs, b.n_seeds[rs], b.n_entries[rs]); }
+    if (sum_counters) {                                  // one set of atomics per workgroup of a small grid (they all hit one line)
+        __shared__ unsigned long long s_a[4], s_e[4];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); e += __shfl_xor(e, off); }
+        if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_e[threadIdx.x >> 6] = e; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            a = s_a[0] + s_a[1] + s_a[2] + s_a[3]; e = s_e[0] + s_e[1] + s_e[2] + s_e[3];
+            if (a) {
+                atomicAdd(&b.counters[GMK_KMERS], a); atomicAdd(&b.counters[GMK_TAB_LOOKUPS], a); atomicAdd(&b.counters[GMK_SEEDS], a);
+                atomicAdd(&b.counters[GMK_SA_HITS], e);
+            }
+        }
+    }
 }
 
 // one workgroup per heavy read x strand of the chunk [j0, j0 + nj)
@@ -104,9 +129,9 @@ __global__ void __launch_bounds__(256) k_heavy_runs(GmDevBatch b, const uint32_t
 
 static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-int gmk_heavy_collect(const GmDevBatch& b, uint32_t heavy_min, uint32_t* n_heavy, uint32_t* heavy_list, void* stream) {
+int gmk_heavy_collect(const GmDevBatch& b, uint32_t heavy_min, uint32_t* n_heavy, uint32_t* heavy_list, int sum_counters, void* stream) {
     if (b.n == 0) return 0;
-    hipLaunchKernelGGL(k_heavy_collect, dim3((uint32_t)((2ull * b.n + 255) / 256)), dim3(256), 0, S_(stream), b, heavy_min, n_heavy, heavy_list);
+    hipLaunchKernelGGL(k_heavy_collect, dim3((uint32_t)std::min<unsigned long long>((2ull * b.n / 4 + 255) / 256 + 1, 1024ull)), dim3(256), 0, S_(stream), b, heavy_min, n_heavy, heavy_list, sum_counters);
     return (int)hipGetLastError();
 }
 

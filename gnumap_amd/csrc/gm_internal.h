@@ -30,6 +30,8 @@ struct GmDevIndex {
 struct GmDevParams {
     int mer, jump, kmin, nw, fast, pos_strand, neg_strand, align_is_fraction;
     int max_gap;                    // -M: band half-width of the DP (3 = the register-band kernels, anything else = gm_band.hip)
+    int fused;                      // 1 = the one-wave vote kernels look their seeds up themselves (no k_seed launch, no seed rows in HBM)
+    uint32_t heavy_min;             // read x strands with more SA hits than this go to the sorted-key path (gm_heavy.hip)
     uint32_t hcap;
     int dbg;                        // GM_DBG bits for kernel timing experiments (0 in production)
     float gap, align_score, cutoff;
@@ -105,6 +107,13 @@ struct GmDevBatch {
     uint32_t* n_retry;              // device counter
     uint32_t* n_big;                // device counter: read x strands handed from k_vote_sparse to k_vote_fast_list
     uint32_t* big_list;             // 2n
+    // 2-bit forms of the reads for the fused seed lookup (written by k_prep when non-null), pack_words words per read:
+    //   [0]                  length | (some base is not ACGT) << 16 | (status != 0) << 17
+    //   F  [1, w2+2)         base p of the read at bit 2 (16 w2 - 1 - p): 2 mer bits from bit 2 (16 w2 - i - mer) are the table code of
+    //                        the k-mer [i, i+mer) (last character lowest)
+    //   F' [w2+2, 2 w2+3)    the same for the reverse complement of the read (its base p' at bit 2 (16 w2 - 1 - p'))
+    // so that a k-mer's words sit at an address that does not depend on the read's length: one round trip for both.
+    uint32_t* pack; uint32_t pack_w2, pack_words;
     unsigned long long* band_moves; // -M other than 3: move words of k_traceback_band, [row][item]; band_moves_words of them
     uint64_t band_moves_words;
 };
@@ -151,7 +160,9 @@ int gmk_locate_sampled(const GmDevIndex& ix, const GmDevBatch& b, void* stream);
 int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, int dense, int slots_hint, void* stream);
 int gmk_cand_gather(const GmDevBatch& b, void* stream);
 // gm_heavy.hip: read x strands with more than heavy_min SA hits (sorted-key vote path)
-int gmk_heavy_collect(const GmDevBatch& b, uint32_t heavy_min, uint32_t* n_heavy, uint32_t* heavy_list /* {rs, n_seeds, SA hits} triples */, void* stream);
+int gmk_heavy_collect(const GmDevBatch& b, uint32_t heavy_min, uint32_t* n_heavy, uint32_t* heavy_list /* {rs, n_seeds, SA hits} triples */, int sum_counters, void* stream);
+inline uint32_t gm_pack_w2(uint32_t stride) { return (stride + 15u) / 16u; }
+inline uint32_t gm_pack_words(uint32_t stride) { const uint32_t w2 = gm_pack_w2(stride); return (1u + 2u * (w2 + 1u) + 3u) & ~3u; }
 size_t gmk_heavy_sort_temp_bytes(size_t n_keys);
 int gmk_heavy_chunk(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, const uint32_t* heavy_list, uint32_t j0, uint32_t nj,
                     const unsigned long long* key_off, unsigned long long* keys0, unsigned long long* keys1, unsigned long long n_keys, void* tmp,

@@ -350,6 +350,10 @@ __global__ void __launch_bounds__(256) k_prep(GmDevIndex ix, GmDevParams p, GmDe
         float self = 0.0f;
         double mn;
         float score = 0.0f;
+        // 2-bit forms of the read for the fused seed lookup (GmDevBatch::pack): 16 bases = one word of each form
+        uint32_t* const prow = b.pack ? b.pack + (size_t)r * b.pack_words : nullptr;
+        uint32_t pk = 0, any_n = 0, carry = 0;
+        const uint32_t rsh = 2u * (16u * b.pack_w2 - L);     // the reverse-strand form is the complemented read shifted up to the top of its words
         for (uint32_t i0 = 0; i0 < L; i0 += 8) {             // rows are 8-byte aligned (stride is a multiple of 8)
             const uint2 bw = *reinterpret_cast<const uint2*>(rb + i0);
             const uint2 qw = *reinterpret_cast<const uint2*>(rq + i0);
@@ -359,6 +363,7 @@ __global__ void __launch_bounds__(256) k_prep(GmDevIndex ix, GmDevParams p, GmDe
                     uint32_t ch = ((t < 4 ? bw.x : bw.y) >> ((t & 3) * 8)) & 255u;
                     uint32_t qc = ((t < 4 ? qw.x : qw.y) >> ((t & 3) * 8)) & 255u;
                     const uint32_t cl = s_cls[ch];
+                    if (prow) { pk |= (cl & 3u) << (((i0 & 8u) + t) << 1); any_n |= cl >> 3; }
                     float v;
                     if (qc < 128u && (cl < 8u || uni)) {
                         v = term[cl][qc];                    // NaN when the probability is negative, like the direct form
@@ -370,6 +375,20 @@ __global__ void __launch_bounds__(256) k_prep(GmDevIndex ix, GmDevParams p, GmDe
                     }
                     if (v != v) bad = 1;                     // negative probability (SeqReader.cpp:1171-1189)
                     score = __fadd_rn(score, v);
+                }
+            }
+            if (prow) {
+                if ((i0 & 8u) || i0 + 8 >= L) {              // a word of 16 bases is complete (or the read ends)
+                    const uint32_t w = i0 >> 4;
+                    uint32_t rv = __brev(pk);
+                    rv = ((rv >> 1) & 0x55555555u) | ((rv & 0x55555555u) << 1);       // 2-bit groups in reverse order
+                    prow[1u + b.pack_w2 - 1u - w] = rv;
+                    const uint32_t g = ~pk, bs = rsh & 31u;
+                    uint32_t* const rform = prow + b.pack_w2 + 2u + (rsh >> 5);
+                    rform[w] = (g << bs) | carry;
+                    carry = bs ? g >> (32u - bs) : 0u;
+                    if (i0 + 8 >= L) rform[w + 1u] = carry;   // the word above the last one takes what was shifted out (its own padding word when bs = 0)
+                    pk = 0;
                 }
             }
         }
@@ -386,6 +405,7 @@ __global__ void __launch_bounds__(256) k_prep(GmDevIndex ix, GmDevParams p, GmDe
             mn = (double)p.kmin;                             // Driver.cpp:502
         }
         b.status[r] = st;
+        if (prow) prow[0] = L | (any_n << 16) | ((st != 0 ? 1u : 0u) << 17);
         b.self_score[r] = self;
         b.min_score[r] = mn;
         b.top_score[r] = 0.0f;
@@ -394,6 +414,91 @@ __global__ void __launch_bounds__(256) k_prep(GmDevIndex ix, GmDevParams p, GmDe
     }
     }
     gm_count(b, GMK_BAD_QUAL, bad);
+}
+
+// The adaptive k-mer walk of align_sequence (inc/align_seq2_raw.cpp:200-231) over one read x strand: rb = the read's bases (LDS or
+// HBM), out = its seed row.  The counters are the caller's (added to, never reset).
+__device__ __forceinline__ void gm_seed_walk(const GmDevIndex& ix, const GmDevParams& p, const unsigned char* rb, const uint32_t L, const uint32_t strand,
+                                             GmSeed* out, const uint32_t max_seeds, unsigned long long& nk, unsigned long long& nocc, unsigned long long& nblk,
+                                             unsigned long long& ntab, unsigned long long& nseed, unsigned long long& nent) {
+    uint32_t last = L - (uint32_t)p.mer;
+    uint32_t i = 0;
+    while (i < last) {
+        // bwt_match_exact on the k-mer at [i, i+mer), right to left
+        uint32_t k = 0, l = ix.seq_len;
+        int t = p.mer - 1;
+        bool ok = true;
+        ++nk;
+        if (p.kmer_tab) {
+            // the last kmer_T characters in one lookup of the memoised backward search
+            uint32_t code = 0;
+            for (int q = 0; q < p.kmer_T; ++q, --t) {
+                uint32_t pos = i + (uint32_t)t;
+                uint32_t c = gm_nt4(strand ? rb[L - 1 - pos] : rb[pos]);
+                if (c > 3) { ok = false; break; }           // t = position of the rightmost non-ACGT
+                if (strand) c = 3 - c;
+                code |= c << (2 * q);
+            }
+            if (ok) {
+                ++ntab;
+                bool answered = false;
+                if (p.kmer_ctab) {                           // 2 MB, L2 resident: start rank + byte counts of 8 consecutive codes
+                    const uint4 rec = p.kmer_ctab[code >> 3];
+                    const uint32_t sub = code & 7u;
+                    const unsigned long long cw = (unsigned long long)rec.y | ((unsigned long long)rec.z << 32);
+                    const uint32_t cnt = (uint32_t)(cw >> (8 * sub)) & 255u;
+                    if (rec.w == 0u && cnt >= 224u) {        // empty, and the record says after how many characters: no second probe
+                        ok = false; t = p.mer - (int)(cnt - 223u);
+                        answered = true;
+                    } else if (rec.w == 0u) {
+                        unsigned long long below = sub ? (cw & (~0ull >> (64 - 8 * sub))) : 0ull;
+                        // bytes >= 224 are empty codes, not counts: a byte's bit 7 survives iff its bits 7, 6 and 5 are all set
+                        const unsigned long long emp = below & (below << 1) & (below << 2) & 0x8080808080808080ull;
+                        below &= ~((emp >> 7) * 0xFFull);
+                        unsigned long long s2 = (below & 0x00FF00FF00FF00FFull) + ((below >> 8) & 0x00FF00FF00FF00FFull);      // 4 x 16-bit sums
+                        const uint32_t pre = (uint32_t)((s2 * 0x0001000100010001ull) >> 48);
+                        k = rec.x + pre; l = k + cnt - 1;
+                        answered = true;
+                    }
+                }
+                if (!answered) {
+                    const uint2 iv = p.kmer_tab[code];
+                    if (iv.x == 0xFFFFFFFFu) { ok = false; t = p.mer - (int)iv.y; }   // the last iv.y characters do not occur
+                    else { k = iv.x; l = iv.y; }
+                }
+            }
+        }
+        for (; ok && t >= 0; --t) {
+            uint32_t pos = i + (uint32_t)t;
+            uint32_t c = gm_nt4(strand ? rb[L - 1 - pos] : rb[pos]);
+            if (c > 3) { ok = false; break; }
+            if (strand) c = 3 - c;
+            uint32_t ok_ = gm_occ_plane(ix, k - 1, c);
+            uint32_t ol_ = gm_occ_plane(ix, l, c);
+            nocc += 2;
+            {   // 64-byte blocks of the REFERENCE layout this step touches (bwt_2occ src/bwt.c:132-163: one when k-1 and l
+                // share a block) - kept as the unit of the algorithmic-bytes accounting
+                uint32_t k1 = k - 1, kb = k1 - ((k1 >= ix.primary) ? 1u : 0u), lb = l - ((l >= ix.primary) ? 1u : 0u);
+                bool ks = (k1 == 0xFFFFFFFFu) || (k1 == ix.seq_len), ls = (l == ix.seq_len);
+                nblk += (ks ? 0u : 1u) + (ls ? 0u : 1u) - ((!ks && !ls && (kb >> 7) == (lb >> 7)) ? 1u : 0u);
+            }
+            k = gm_L2(ix, c) + ok_ + 1;
+            l = gm_L2(ix, c) + ol_;
+            if (k > l) { ok = false; break; }
+        }
+        if (!ok) {
+            // the suffix [i+t, i+mer) of this k-mer does not occur (or holds a non-ACGT): every k-mer starting in
+            // [i, i+t] contains it, so the reference's one-by-one slide (:200-231) fails on all of them too
+            i += (uint32_t)t + 1;
+            continue;
+        }
+        uint32_t cnt = l - k + 1;
+        if (p.hcap > 0 && cnt > p.hcap) { i += 1; continue; }       // too many hits: slide by one (:213-217)
+        if (nseed < max_seeds && !(p.dbg & 128)) { GmSeed sd; sd.k = k; sd.l = l; sd.pos = i; out[nseed] = sd; }
+        ++nseed;
+        nent += cnt;
+        i += (uint32_t)p.jump;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -431,85 +536,7 @@ __global__ void __launch_bounds__(256, 8) k_seed(GmDevIndex ix, GmDevParams p, G
         if (on) {
             uint32_t L = b.len[r];
             const unsigned char* rb = s_reads + (size_t)(r - r0) * b.stride;
-            GmSeed* out = b.seeds + (size_t)rs * b.max_seeds;
-            uint32_t last = L - (uint32_t)p.mer;
-            uint32_t i = 0;
-            while (i < last) {
-                // bwt_match_exact on the k-mer at [i, i+mer), right to left
-                uint32_t k = 0, l = ix.seq_len;
-                int t = p.mer - 1;
-                bool ok = true;
-                ++nk;
-                if (p.kmer_tab) {
-                    // the last kmer_T characters in one lookup of the memoised backward search
-                    uint32_t code = 0;
-                    for (int q = 0; q < p.kmer_T; ++q, --t) {
-                        uint32_t pos = i + (uint32_t)t;
-                        uint32_t c = gm_nt4(strand ? rb[L - 1 - pos] : rb[pos]);
-                        if (c > 3) { ok = false; break; }           // t = position of the rightmost non-ACGT
-                        if (strand) c = 3 - c;
-                        code |= c << (2 * q);
-                    }
-                    if (ok) {
-                        ++ntab;
-                        bool answered = false;
-                        if (p.kmer_ctab) {                           // 2 MB, L2 resident: start rank + byte counts of 8 consecutive codes
-                            const uint4 rec = p.kmer_ctab[code >> 3];
-                            const uint32_t sub = code & 7u;
-                            const unsigned long long cw = (unsigned long long)rec.y | ((unsigned long long)rec.z << 32);
-                            const uint32_t cnt = (uint32_t)(cw >> (8 * sub)) & 255u;
-                            if (rec.w == 0u && cnt >= 224u) {        // empty, and the record says after how many characters: no second probe
-                                ok = false; t = p.mer - (int)(cnt - 223u);
-                                answered = true;
-                            } else if (rec.w == 0u) {
-                                unsigned long long below = sub ? (cw & (~0ull >> (64 - 8 * sub))) : 0ull;
-                                // bytes >= 224 are empty codes, not counts: a byte's bit 7 survives iff its bits 7, 6 and 5 are all set
-                                const unsigned long long emp = below & (below << 1) & (below << 2) & 0x8080808080808080ull;
-                                below &= ~((emp >> 7) * 0xFFull);
-                                unsigned long long s2 = (below & 0x00FF00FF00FF00FFull) + ((below >> 8) & 0x00FF00FF00FF00FFull);      // 4 x 16-bit sums
-                                const uint32_t pre = (uint32_t)((s2 * 0x0001000100010001ull) >> 48);
-                                k = rec.x + pre; l = k + cnt - 1;
-                                answered = true;
-                            }
-                        }
-                        if (!answered) {
-                            const uint2 iv = p.kmer_tab[code];
-                            if (iv.x == 0xFFFFFFFFu) { ok = false; t = p.mer - (int)iv.y; }   // the last iv.y characters do not occur
-                            else { k = iv.x; l = iv.y; }
-                        }
-                    }
-                }
-                for (; ok && t >= 0; --t) {
-                    uint32_t pos = i + (uint32_t)t;
-                    uint32_t c = gm_nt4(strand ? rb[L - 1 - pos] : rb[pos]);
-                    if (c > 3) { ok = false; break; }
-                    if (strand) c = 3 - c;
-                    uint32_t ok_ = gm_occ_plane(ix, k - 1, c);
-                    uint32_t ol_ = gm_occ_plane(ix, l, c);
-                    nocc += 2;
-                    {   // 64-byte blocks of the REFERENCE layout this step touches (bwt_2occ src/bwt.c:132-163: one when k-1 and l
-                        // share a block) - kept as the unit of the algorithmic-bytes accounting
-                        uint32_t k1 = k - 1, kb = k1 - ((k1 >= ix.primary) ? 1u : 0u), lb = l - ((l >= ix.primary) ? 1u : 0u);
-                        bool ks = (k1 == 0xFFFFFFFFu) || (k1 == ix.seq_len), ls = (l == ix.seq_len);
-                        nblk += (ks ? 0u : 1u) + (ls ? 0u : 1u) - ((!ks && !ls && (kb >> 7) == (lb >> 7)) ? 1u : 0u);
-                    }
-                    k = gm_L2(ix, c) + ok_ + 1;
-                    l = gm_L2(ix, c) + ol_;
-                    if (k > l) { ok = false; break; }
-                }
-                if (!ok) {
-                    // the suffix [i+t, i+mer) of this k-mer does not occur (or holds a non-ACGT): every k-mer starting in
-                    // [i, i+t] contains it, so the reference's one-by-one slide (:200-231) fails on all of them too
-                    i += (uint32_t)t + 1;
-                    continue;
-                }
-                uint32_t cnt = l - k + 1;
-                if (p.hcap > 0 && cnt > p.hcap) { i += 1; continue; }       // too many hits: slide by one (:213-217)
-                if (nseed < b.max_seeds && !(p.dbg & 128)) { GmSeed sd; sd.k = k; sd.l = l; sd.pos = i; out[nseed] = sd; }
-                ++nseed;
-                nent += cnt;
-                i += (uint32_t)p.jump;
-            }
+            gm_seed_walk(ix, p, rb, L, strand, b.seeds + (size_t)rs * b.max_seeds, b.max_seeds, nk, nocc, nblk, ntab, nseed, nent);
         }
         b.n_seeds[rs] = (uint16_t)(nseed < b.max_seeds ? nseed : b.max_seeds);
         b.n_entries[rs] = nent > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nent;
@@ -1579,6 +1606,132 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
     if (prof) atomicAdd(&b.counters[GMK_DBG8], 1ull);
 }
 
+// ---- seeds of the one-wave vote kernels ---------------------------------------------------------------------------------------
+// SEED = false: the read x strand's row of b.seeds, written by k_seed.
+// SEED = true (GmDevParams::fused; full SA, the k-mer table covers the whole seed): the wave looks its seeds up itself and no seed
+// row goes through HBM.  While nothing fails the adaptive walk (gm_seed_walk) visits i = 0, jump, 2 jump ... < L - mer, so lane j
+// takes the k-mer at j * jump: its table code is 2 * mer bits of the read's 2-bit form (k_prep: GmDevBatch::pack), one 16-byte
+// table record gives the interval.  A k-mer that does not occur or exceeds -h changes the positions of all later ones, and so does
+// a non-ACGT base: then lane 0 runs the walk itself, exactly as k_seed does, into LDS.  Either way the seeds are those of k_seed.
+// n_seeds / n_entries of every read x strand still go to HBM (6 bytes): the heavy-path routing and the work counters
+// (k_heavy_collect) read them; the kernels a read x strand may be handed to (list, retry, heavy) get its seed row written first.
+// The serial walk of the rare cases is kept OUT OF LINE: inlined, the index fields it needs were loaded at the top of every wave
+// and pushed ~40 scalar registers into vector lanes (one vector instruction each, on a kernel that is bound by vector issue).
+// The callee finds the kernel's arguments where the hardware put them (the kernarg segment: ix, p, b in this order).
+struct GmKArgs { GmDevIndex ix; GmDevParams p; GmDevBatch b; };
+// one lane.  out = where the seeds go (LDS), or null: the read x strand's row in HBM, for the kernel it is handed to.  count = add the
+// failed k-mers to the work counters (k_heavy_collect counts one k-mer and one table probe per seed).  Returns the number of seeds.
+__device__ __attribute__((noinline)) uint32_t gm_seed_walk_ool(const GmKArgs* a, const uint32_t rs, GmSeed* out, const int count) {
+    const GmDevBatch& b = a->b;
+    unsigned long long nk = 0, nocc = 0, nblk = 0, ntab = 0, nseed = 0, nent = 0;
+    const uint32_t r = rs >> 1;
+    gm_seed_walk(a->ix, a->p, b.bases + (size_t)r * b.stride, b.len[r], rs & 1u, out ? out : b.seeds + (size_t)rs * b.max_seeds, b.max_seeds, nk, nocc, nblk, ntab,
+                 nseed, nent);
+    if (count) {
+        if (nk > nseed) atomicAdd(&b.counters[GMK_KMERS], nk - nseed);
+        if (ntab > nseed) atomicAdd(&b.counters[GMK_TAB_LOOKUPS], ntab - nseed);
+        if (nocc) { atomicAdd(&b.counters[GMK_OCC], nocc); atomicAdd(&b.counters[GMK_OCC_BLOCKS], nblk); }
+    }
+    return (uint32_t)nseed;
+}
+__device__ __forceinline__ const GmKArgs* gm_kargs() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (const GmKArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    return nullptr;
+#endif
+}
+
+// returns false when the wave has nothing more to do (no seeds, or handed to the heavy path)
+template <bool SEED>
+__device__ __forceinline__ bool gm_tiny_seeds(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, const uint32_t rs, const int lane,
+                                              GmSeed* scratch /* LDS, 64 seeds, free to use */, GmSeed& sd, uint32_t& ns, uint32_t& ie_all) {
+    sd.k = 0; sd.l = 0; sd.pos = 0;
+    ie_all = 0xFFFFFFFFu;                             // inclusive scan of the seeds' hit counts when the function has computed it
+    if (!SEED) {
+        if ((uint32_t)lane < b.max_seeds) sd = b.seeds[(size_t)rs * b.max_seeds + lane];
+        ns = b.n_seeds[rs];
+        return true;
+    }
+    const uint32_t r = rs >> 1, strand = rs & 1u;
+    ns = 0;
+    // one round trip: the row's header and the two words that hold this lane's k-mer (their address does not depend on the length)
+    const uint32_t m = (uint32_t)p.mer, w2 = b.pack_w2;
+    const uint32_t i = (uint32_t)lane * (uint32_t)p.jump;
+    const uint32_t* const row = b.pack + (size_t)r * b.pack_words;
+    const bool inrow = i + m <= 16u * w2;
+    const uint32_t o = inrow ? 2u * (16u * w2 - i - m) : 0u;
+    const uint32_t* const form = row + (strand ? w2 + 2u : 1u);
+    const uint32_t hdr = row[0], f0 = form[o >> 5], f1 = form[(o >> 5) + 1u];
+    const uint32_t L = hdr & 0xFFFFu;
+    const bool on = !((hdr >> 17) & 1u) && (strand ? p.neg_strand : p.pos_strand);      // wave-uniform
+    if (on) {
+        const bool act = i + m < L;                                                      // lanes 0 .. ceil((L - mer) / jump) - 1
+        const uint32_t nreg = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(act));
+        bool bad = act && ((hdr >> 16) & 1u);                                            // a read with a non-ACGT base takes the serial walk
+        uint32_t k = 0, cnt = 0;
+        if (act && !bad) {
+            const uint32_t code = (uint32_t)((((unsigned long long)f1 << 32) | f0) >> (o & 31u)) & (m >= 16u ? 0xFFFFFFFFu : ((1u << (2u * m)) - 1u));
+            {                                                                            // the table probe of gm_seed_walk
+                bool answered = false;
+                if (p.kmer_ctab) {
+                    const uint4 rec = p.kmer_ctab[code >> 3];
+                    asm volatile("" :: "v"(rec.x), "v"(rec.y), "v"(rec.z), "v"(rec.w));      // ONE 16-byte load (the compiler would fetch rec.x in a second trip, where it is used)
+                    // the record of gm_seed_walk, decoded per 32-bit half: the bytes below this code's (empty codes, >= 224, count 0) add up
+                    // in two byte-sum instructions
+                    const uint32_t sub = code & 7u, sh = (sub & 3u) << 3;
+                    const uint32_t own = sub < 4u ? rec.y : rec.z;
+                    cnt = (own >> sh) & 255u;
+                    if (rec.w == 0u && cnt >= 224u) { bad = true; answered = true; }
+                    else if (rec.w == 0u) {
+                        const uint32_t part = own & ((1u << sh) - 1u);                  // bytes below the code's inside its own half
+                        uint32_t lo = sub < 4u ? part : rec.y, hi = sub < 4u ? 0u : part;
+                        lo &= ~(((lo & (lo << 1) & (lo << 2) & 0x80808080u) >> 7) * 0xFFu);
+                        hi &= ~(((hi & (hi << 1) & (hi << 2) & 0x80808080u) >> 7) * 0xFFu);
+                        k = rec.x + __builtin_amdgcn_sad_u8(lo, 0u, __builtin_amdgcn_sad_u8(hi, 0u, 0u));
+                        answered = true;
+                    }
+                }
+                if (!answered) {
+                    const uint2 iv = p.kmer_tab[code];
+                    if (iv.x == 0xFFFFFFFFu) bad = true;
+                    else { k = iv.x; cnt = iv.y - iv.x + 1u; }
+                }
+                if (p.hcap > 0 && cnt > p.hcap) bad = true;
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(bad) == 0ull) {
+            ns = nreg;
+            if (act) { sd.k = k; sd.l = k + cnt - 1u; sd.pos = i; }
+        } else {                                                                          // rare: the serial walk, by lane 0
+            uint32_t nseed = 0;
+            if (lane == 0) nseed = gm_seed_walk_ool(gm_kargs(), rs, scratch, 1);
+            __syncthreads();
+            ns = (uint32_t)__builtin_amdgcn_readlane((int)nseed, 0);
+            if ((uint32_t)lane < ns) sd = scratch[lane];
+            __syncthreads();
+        }
+    }
+    // n_seeds / n_entries (saturating, like k_seed) of this read x strand
+    const uint32_t c_all = (uint32_t)lane < ns ? sd.l - sd.k + 1u : 0u;
+    uint32_t e_all;
+    if (__builtin_amdgcn_ballot_w64(c_all > (1u << 24)) != 0ull) {                       // the 32-bit sum could overflow
+        const unsigned long long e64 = gm_wave_sum((unsigned long long)c_all);
+        e_all = e64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)e64;
+        if (lane == 0 && e64 > 0xFFFFFFFFull) atomicAdd(&b.counters[GMK_SA_HITS], e64 - 0xFFFFFFFFull);     // k_heavy_collect adds n_entries
+    } else {
+        ie_all = gm_wave_scan_incl(c_all);                                               // the caller's scan of the hit counts, unless --fast cuts the seeds
+        e_all = (uint32_t)__builtin_amdgcn_readlane((int)ie_all, 63);
+    }
+    if (lane == 0) { b.n_seeds[rs] = (uint16_t)ns; b.n_entries[rs] = e_all; }
+    if (ns == 0) return false;
+    if (e_all > p.heavy_min) {                                                            // sorted-key path: it reads the seed row
+        if ((uint32_t)lane < ns) b.seeds[(size_t)rs * b.max_seeds + lane] = sd;
+        return false;
+    }
+    return true;
+}
+
 // ---- k_vote_tiny: one WAVEFRONT per read x strand, for at most 256 SA hits in at most 32 groups of 16 ranks ----------------
 // Long seeds on a large reference (-m 14 on 3.1 Gbp: 13 seeds x ~12 hits) leave k_vote_slots latency-bound: a workgroup's life is
 // three dependent HBM round trips (seeds, SA ranks, candidate reservation) and 10 KB of LDS allow 16 of them per CU.  Here a read x
@@ -1591,7 +1744,7 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
 // the part of k_vote_tiny after its descriptors are in LDS, unrolled for UU load steps (4 groups of 16 ranks each) and LQ list
 // chunks of 64 hits: the kernel is vector-issue bound, and a read x strand of 13 seeds x ~12 hits fills 4 of the 8 steps and 3 of
 // the 4 chunks - the step counts are wave-uniform, so the kernel picks the instantiation instead of walking empty steps
-template <bool MASK64, bool FULL, int UU, int LQ>
+template <bool MASK64, bool FULL, bool SEED, int UU, int LQ>
 __device__ __forceinline__ void gm_vote_tiny_body(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, const uint32_t rs, const int lane, const uint32_t E,
                                                   uint4* s_r0v, uint32_t* s_lbp, uint8_t* s_lt, const uint2* s_desc, uint32_t* s_cnt0) {
     constexpr int T2 = 128;
@@ -1668,6 +1821,7 @@ __device__ __forceinline__ void gm_vote_tiny_body(const GmDevIndex& ix, const Gm
     __syncthreads();
     if (__builtin_amdgcn_ballot_w64(full) != 0ull || nkeys > (uint32_t)(T2 * 3 / 4)) {     // hand this read x strand to the global-table kernel
         if (lane == 0) {
+            if (SEED) (void)gm_seed_walk_ool(gm_kargs(), rs, nullptr, 0);      // the retry kernel reads the seed row
             b.rs_overflow[rs] = 1;
             const uint32_t j = atomicAdd(b.n_retry, 1u);
             const uint32_t need = 2 * E; uint32_t sz = 1024; while (sz < need && sz < 0x80000000u) sz <<= 1;
@@ -1735,7 +1889,7 @@ __device__ __forceinline__ void gm_vote_tiny_body(const GmDevIndex& ix, const Gm
     }
 }
 
-template <bool MASK64, bool FULL>
+template <bool MASK64, bool FULL, bool SEED>
 __global__ void __launch_bounds__(64, 8) k_vote_tiny(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
     __shared__ uint4 s_r0v[192];                      // 3 KB: words [0,256) = 512 x 16-bit counters, [256,768) = 128 x key | votes | low mask | high mask
     __shared__ uint32_t s_lbp[GMT_LCAP];
@@ -1744,16 +1898,20 @@ __global__ void __launch_bounds__(64, 8) k_vote_tiny(GmDevIndex ix, GmDevParams 
     __shared__ uint32_t s_cnt0[64];
     const uint32_t rs = blockIdx.x;                   // grid = 2n
     const int lane = threadIdx.x;
-    GmSeed sd; sd.k = 0; sd.l = 0; sd.pos = 0;
-    if ((uint32_t)lane < b.max_seeds) sd = b.seeds[(size_t)rs * b.max_seeds + lane];
-    uint32_t ns = b.n_seeds[rs];
-    if (p.nw && p.fast && ns > 1) ns = 1;
+    GmSeed sd; uint32_t ns, ie_all;
+    if (!gm_tiny_seeds<SEED>(ix, p, b, rs, lane, reinterpret_cast<GmSeed*>(s_r0v), sd, ns, ie_all)) return;
+    const bool cut = p.nw && p.fast && ns > 1;
+    if (cut) ns = 1;
     const uint32_t cnt = (uint32_t)lane < ns ? sd.l - sd.k + 1 : 0u;
     const uint32_t nq = (cnt + 15u) >> 4;
-    const uint32_t ie = gm_wave_scan_incl(cnt), iq = gm_wave_scan_incl(nq);
+    uint32_t ie;
+    if (SEED && !cut && __builtin_amdgcn_ballot_w64(ie_all == 0xFFFFFFFFu) == 0ull) ie = ie_all;      // wave-uniform
+    else ie = gm_wave_scan_incl(cnt);
+    const uint32_t iq = gm_wave_scan_incl(nq);
     const uint32_t E = __builtin_amdgcn_readlane(ie, 63), Q = __builtin_amdgcn_readlane(iq, 63);
     if (Q == 0) return;                               // wave-uniform: nothing to vote on
     if (Q > GMT_Q || E > GMT_LCAP) {                  // wave-uniform: hand over to the list kernel
+        if (SEED && (uint32_t)lane < b.max_seeds) b.seeds[(size_t)rs * b.max_seeds + lane] = sd;
         if (lane == 0) { const uint32_t at = atomicAdd(b.n_big, 1u); b.big_list[at] = rs; }
         return;
     }
@@ -1771,11 +1929,11 @@ __global__ void __launch_bounds__(64, 8) k_vote_tiny(GmDevIndex ix, GmDevParams 
     }
     __syncthreads();
     if (Q <= 16u) {
-        if (E <= 192u) gm_vote_tiny_body<MASK64, FULL, 4, 3>(ix, p, b, rs, lane, E, s_r0v, s_lbp, s_lt, s_desc, s_cnt0);
-        else gm_vote_tiny_body<MASK64, FULL, 4, 4>(ix, p, b, rs, lane, E, s_r0v, s_lbp, s_lt, s_desc, s_cnt0);
+        if (E <= 192u) gm_vote_tiny_body<MASK64, FULL, SEED, 4, 3>(ix, p, b, rs, lane, E, s_r0v, s_lbp, s_lt, s_desc, s_cnt0);
+        else gm_vote_tiny_body<MASK64, FULL, SEED, 4, 4>(ix, p, b, rs, lane, E, s_r0v, s_lbp, s_lt, s_desc, s_cnt0);
     } else {
-        if (E <= 192u) gm_vote_tiny_body<MASK64, FULL, 8, 3>(ix, p, b, rs, lane, E, s_r0v, s_lbp, s_lt, s_desc, s_cnt0);
-        else gm_vote_tiny_body<MASK64, FULL, 8, 4>(ix, p, b, rs, lane, E, s_r0v, s_lbp, s_lt, s_desc, s_cnt0);
+        if (E <= 192u) gm_vote_tiny_body<MASK64, FULL, SEED, 8, 3>(ix, p, b, rs, lane, E, s_r0v, s_lbp, s_lt, s_desc, s_cnt0);
+        else gm_vote_tiny_body<MASK64, FULL, SEED, 8, 4>(ix, p, b, rs, lane, E, s_r0v, s_lbp, s_lt, s_desc, s_cnt0);
     }
 }
 
@@ -1784,7 +1942,7 @@ __global__ void __launch_bounds__(64, 8) k_vote_tiny(GmDevIndex ix, GmDevParams 
 // filter and, where their slot reached -k, straight into a 256-slot exact table.  6.8 KB of LDS: 23 read x strands per CU.
 #define GMT2_Q 64
 #define GMT2_E 384
-template <bool MASK64, bool FULL>
+template <bool MASK64, bool FULL, bool SEED>
 __global__ void __launch_bounds__(64, 6) k_vote_tiny2(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
     constexpr int U = GMT2_Q / 4, T2 = 256;
     __shared__ uint4 s_r0v[384];                      // 6 KB: words [0,512) = 1024 x 16-bit counters, [512,1536) = 256 x key | votes | low mask | high mask
@@ -1793,16 +1951,20 @@ __global__ void __launch_bounds__(64, 6) k_vote_tiny2(GmDevIndex ix, GmDevParams
     uint32_t* const s_r0 = reinterpret_cast<uint32_t*>(s_r0v);
     const uint32_t rs = blockIdx.x;                   // grid = 2n
     const int lane = threadIdx.x;
-    GmSeed sd; sd.k = 0; sd.l = 0; sd.pos = 0;
-    if ((uint32_t)lane < b.max_seeds) sd = b.seeds[(size_t)rs * b.max_seeds + lane];
-    uint32_t ns = b.n_seeds[rs];
-    if (p.nw && p.fast && ns > 1) ns = 1;
+    GmSeed sd; uint32_t ns, ie_all;
+    if (!gm_tiny_seeds<SEED>(ix, p, b, rs, lane, reinterpret_cast<GmSeed*>(s_r0v), sd, ns, ie_all)) return;
+    const bool cut = p.nw && p.fast && ns > 1;
+    if (cut) ns = 1;
     const uint32_t cnt = (uint32_t)lane < ns ? sd.l - sd.k + 1 : 0u;
     const uint32_t nq = (cnt + 15u) >> 4;
-    const uint32_t ie = gm_wave_scan_incl(cnt), iq = gm_wave_scan_incl(nq);
+    uint32_t ie;
+    if (SEED && !cut && __builtin_amdgcn_ballot_w64(ie_all == 0xFFFFFFFFu) == 0ull) ie = ie_all;      // wave-uniform
+    else ie = gm_wave_scan_incl(cnt);
+    const uint32_t iq = gm_wave_scan_incl(nq);
     const uint32_t E = __builtin_amdgcn_readlane(ie, 63), Q = __builtin_amdgcn_readlane(iq, 63);
     if (Q == 0) return;                               // wave-uniform: nothing to vote on
     if (Q > GMT2_Q || E > GMT2_E) {                   // wave-uniform: hand over to the list kernel
+        if (SEED && (uint32_t)lane < b.max_seeds) b.seeds[(size_t)rs * b.max_seeds + lane] = sd;
         if (lane == 0) { const uint32_t at = atomicAdd(b.n_big, 1u); b.big_list[at] = rs; }
         return;
     }
@@ -1877,6 +2039,7 @@ __global__ void __launch_bounds__(64, 6) k_vote_tiny2(GmDevIndex ix, GmDevParams
     __syncthreads();
     if (__builtin_amdgcn_ballot_w64(full) != 0ull || nkeys > (uint32_t)(T2 * 3 / 4)) {     // hand this read x strand to the global-table kernel
         if (lane == 0) {
+            if (SEED) (void)gm_seed_walk_ool(gm_kargs(), rs, nullptr, 0);      // the retry kernel reads the seed row
             b.rs_overflow[rs] = 1;
             const uint32_t j = atomicAdd(b.n_retry, 1u);
             const uint32_t need = 2 * E; uint32_t sz = 1024; while (sz < need && sz < 0x80000000u) sz <<= 1;
@@ -2805,8 +2968,11 @@ int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, in
             const int slot_form = dense == 2 ? 64 : slots_hint == 0 ? 0 : slots_hint < 0 ? -1 : slots_hint <= 14 ? 16 : slots_hint <= 22 ? 24 : GMS_SMAX;      // 0 = k_vote_tiny, -1 = k_vote_tiny2
             const uint32_t lgrid = (uint32_t)std::min<uint64_t>(cdiv(2ull * b.n, 4), 256 * 20);
 #define GM_LAUNCH_VSL1(M, F, S) hipLaunchKernelGGL((k_vote_slots<M, F, S>), dim3(2 * b.n), dim3(128), 0, S_(stream), ix, p, b)
-#define GM_LAUNCH_VSL(M, F) do { if (slot_form == 0) hipLaunchKernelGGL((k_vote_tiny<M, F>), dim3(2 * b.n), dim3(64), 0, S_(stream), ix, p, b); \
-                                 else if (slot_form == -1) hipLaunchKernelGGL((k_vote_tiny2<M, F>), dim3(2 * b.n), dim3(64), 0, S_(stream), ix, p, b); \
+#define GM_LAUNCH_VSL(M, F) do { if (slot_form == 0 && F && p.fused) hipLaunchKernelGGL((k_vote_tiny<M, true, true>), dim3(2 * b.n), dim3(64), 0, S_(stream), ix, p, b); \
+                                 else if (slot_form == -1 && F && p.fused) hipLaunchKernelGGL((k_vote_tiny2<M, true, true>), dim3(2 * b.n), dim3(64), 0, S_(stream), ix, p, b); \
+                                 else if (p.fused) { return (int)hipErrorInvalidValue; } \
+                                 else if (slot_form == 0) hipLaunchKernelGGL((k_vote_tiny<M, F, false>), dim3(2 * b.n), dim3(64), 0, S_(stream), ix, p, b); \
+                                 else if (slot_form == -1) hipLaunchKernelGGL((k_vote_tiny2<M, F, false>), dim3(2 * b.n), dim3(64), 0, S_(stream), ix, p, b); \
                                  else if (slot_form == 64) GM_LAUNCH_VSL1(M, F, 64); else if (slot_form == 16) GM_LAUNCH_VSL1(M, F, 16); \
                                  else if (slot_form == 24) GM_LAUNCH_VSL1(M, F, 24); else GM_LAUNCH_VSL1(M, F, GMS_SMAX); } while (0)
             if (m64) { if (use_full_sa) GM_LAUNCH_VSL(true, true); else GM_LAUNCH_VSL(true, false); }

@@ -478,7 +478,13 @@ _VARIANT_ORACLE = {}
                                  dict(GM_VOTE="block", GM_VOTE_SLOTS="0", GM_VOTE_FIXED="0"), dict(GM_VOTE="block", GM_VOTE_SLOTS="-1", GM_VOTE_FIXED="0"),   # candidates through the bump counters instead of own slots + k_cand_gather
                                  dict(GM_NW_ROWS="0"),
                                  dict(GM_HEAVY_MIN="64"), dict(GM_HEAVY_MIN="8", GM_HEAVY_BUDGET="200000"),      # sorted-key path for read x strands with many SA hits (several chunks)
-                                 dict(GM_HEAVY_MIN="64", GM_TEST_SAMPLED="1")],                                              # streaming DP rows instead of rows in registers
+                                 dict(GM_HEAVY_MIN="64", GM_TEST_SAMPLED="1"),
+                                 # the one-wave kernels look their seeds up themselves on the full SA (fused form, the default): the two-kernel form,
+                                 # a table without its compact form, 14- / 16-mers with a table that long, hand-over to the heavy path
+                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="0", GM_SEED_FUSED="0"), dict(GM_VOTE="block", GM_VOTE_SLOTS="-1", GM_SEED_FUSED="0"),
+                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="0", GM_KMER_COMPACT="0"), dict(GM_VOTE="block", GM_VOTE_SLOTS="0", GM_KMER_TABLE="16"),
+                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="-1", GM_KMER_TABLE="14"),
+                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="0", GM_HEAVY_MIN="64"), dict(GM_VOTE="block", GM_VOTE_SLOTS="-1", GM_HEAVY_MIN="8", GM_HEAVY_BUDGET="200000")],
                          ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()))
 @pytest.mark.parametrize("cfg", ["default", "no_nw", "k3", "h30", "m6_j2", "m20_j2", "k1"])
 def test_every_kernel_variant_matches_oracle(env, cfg, syn_fa, oracle, oix, syn_reads, packed, tmp_path):
@@ -509,7 +515,8 @@ ix = g.Index({syn_fa!r}, flags=0 if os.environ.get('GM_TEST_SAMPLED') else g.GM_
 p = g.Params(**{CONFIGS[cfg]!r})
 b = g.Batch(ix, len(reads), B.shape[1])
 res = b.map(p, B, Q, Ln)
-np.savez({out!r}, **{{k: v for k, v in res.items() if not k.startswith('_')}})
+ctr = b.counters()
+np.savez({out!r}, **{{k: v for k, v in res.items() if not k.startswith('_')}}, **{{'ctr_' + k: np.int64(v) for k, v in ctr.items()}})
 """
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=300)
     assert r.returncode == 0, r.stderr[-1500:]
@@ -518,3 +525,17 @@ np.savez({out!r}, **{{k: v for k, v in res.items() if not k.startswith('_')}})
         _VARIANT_ORACLE[cfg] = _oracle_results(oracle, oix, oracle.params(**CONFIGS[cfg]), syn_reads)
     _compare(res, _VARIANT_ORACLE[cfg], syn_reads)
     assert len(res["matches"]) > 400
+    return {k[4:]: int(v) for k, v in res.items() if k.startswith("ctr_")}
+
+
+@pytest.mark.parametrize("cfg", ["default", "h30", "m6_j2", "k1", "no_nw"])
+@pytest.mark.parametrize("slots", ["0", "-1"])
+def test_fused_seed_lookup_counts_the_same_work(cfg, slots, syn_fa, oracle, oix, syn_reads, tmp_path):
+    """seed lookup inside k_vote_tiny / k_vote_tiny2 (lane j takes the k-mer at j * jump; a failed or capped k-mer or an N sends the
+    read x strand through the serial walk) against the k_seed form: same results (both compared with the oracle) and the same work
+    counters - k-mers searched, table probes, seeds, SA hits, candidates, DP cells"""
+    env = dict(GM_VOTE="block", GM_VOTE_SLOTS=slots, GM_KMER_TABLE="14")
+    fused = _run_variant(env, cfg, syn_fa, oracle, oix, syn_reads, tmp_path)
+    plain = _run_variant(dict(env, GM_SEED_FUSED="0"), cfg, syn_fa, oracle, oix, syn_reads, tmp_path)
+    assert fused == plain, (fused, plain)
+    assert fused["seeds_used"] > 5000 and fused["kmers_searched"] >= fused["seeds_used"]
