@@ -110,14 +110,22 @@ def make_reads(codes_t, n, L, seed, device):
     return B, Q, Ln
 
 
-def algorithmic_bytes(c, L, n_reads):
-    """per-launch algorithmic bytes of each kernel from the kernel-side work counters (DESIGN.md 'Algorithmic bytes')"""
+def algorithmic_bytes(c, L, n_reads, fused=False):
+    """per-launch algorithmic bytes of each kernel from the kernel-side work counters (DESIGN.md 'Algorithmic bytes').
+    fused: the seed lookup runs inside the vote kernel (no k_seed launch): k_prep also writes the reads' 2-bit forms (both strands +
+    a header word), the vote kernel reads them and the table records instead of seed rows"""
     win = L // 4 + 1
+    forms = n_reads * (2 * (L // 4 + 1) + 4)
+    vote = c["sa_hits"] * 4 + c["candidates"] * 16
+    if fused:
+        vote += c["occ_blocks"] * 64 + c.get("table_lookups", 0) * 8 + forms + 2 * n_reads * 6
+    else:
+        vote += c["seeds_used"] * 12
     return {
-        "k_prep": n_reads * (2 * L + 17),
+        "k_prep": n_reads * (2 * L + 17) + (forms if fused else 0),
         "k_seed": c["occ_blocks"] * 64 + c.get("table_lookups", 0) * 8 + n_reads * 2 * L + c["seeds_used"] * 12 + 2 * n_reads * 6,
         "k_locate_sampled": c["lf_steps"] * 64 + c["sa_hits"] * 8,
-        "k_vote": c["sa_hits"] * 4 + c["seeds_used"] * 12 + c["candidates"] * 16,
+        "k_vote": vote,
         "k_nw": c["candidates"] * (16 + 2 * L + win + 4),
         "k_compact(scan+scatter)": n_reads * 16 + c["candidates"] * 16 + c["accepted"] * 16,
         "k_vote_retry": 0,
@@ -359,7 +367,8 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         value = world * a.reads * a.steps / elapsed
-        alg = algorithmic_bytes(counters, a.read_len, a.reads)
+        fused = ktimes.get("k_seed", (0.0, 0))[1] == 0 and a.locate == "full"      # seed lookup inside the vote kernel
+        alg = algorithmic_bytes(counters, a.read_len, a.reads, fused)
         per_kernel = {}
         for k, (ms, n) in ktimes.items():
             if n:
@@ -410,6 +419,7 @@ def main():
                                    f"-a 0.9 -m {p.mer} -j {p.jump} -k {p.min_seed_hits} -h {p.max_kmer_hits}, {'--no_nw' if a.no_nw else 'NormalScoredSeq NW'}, locate={a.locate}-SA",
                        "reads_per_gpu": a.reads, "read_len": a.read_len, "genome_mbp": a.genome_mbp, "sharding": f"reads x{world} (no data-path collective)"},
             "roofline": roof,
+            "seed_lookup": "fused into the vote kernel" if fused else "k_seed",
             "cpu_baseline": cpu,
             "abi_reads_per_s": round(abi["reads_per_s"], 1) if abi else None,
             "abi": abi,

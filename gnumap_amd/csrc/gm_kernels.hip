@@ -1663,6 +1663,7 @@ __device__ __forceinline__ bool gm_tiny_seeds(const GmDevIndex& ix, const GmDevP
     const uint32_t o = inrow ? 2u * (16u * w2 - i - m) : 0u;
     const uint32_t* const form = row + (strand ? w2 + 2u : 1u);
     const uint32_t hdr = row[0], f0 = form[o >> 5], f1 = form[(o >> 5) + 1u];
+    asm volatile("" :: "v"(f0), "v"(f1));             // issued here, beside the header, not after the branch on it
     const uint32_t L = hdr & 0xFFFFu;
     const bool on = !((hdr >> 17) & 1u) && (strand ? p.neg_strand : p.pos_strand);      // wave-uniform
     if (on) {
