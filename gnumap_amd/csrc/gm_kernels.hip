@@ -1738,7 +1738,7 @@ __device__ __forceinline__ bool gm_tiny_seeds(const GmDevIndex& ix, const GmDevP
 // three dependent HBM round trips (seeds, SA ranks, candidate reservation) and 10 KB of LDS allow 16 of them per CU.  Here a read x
 // strand is one wave and 4.9 KB of LDS (32 per CU: every wave slot of the CU), a descriptor covers 16 consecutive ranks of one seed (a 64-lane step holds
 // four seeds' hits: ~75 % of the lanes carry a hit instead of ~20 %), there is no first counting filter (every hit goes to the
-// list), and the list goes through the second filter (512 x 16 bit) into a 128-slot exact table as in k_vote_slots.
+// list), and the list goes through the second filter (4096 x 2 bit: seen / seen again) into a 128-slot exact table as in k_vote_slots.
 // More hits or groups than that -> b.big_list -> k_vote_fast_list; a table that fills up -> the retry kernel.
 #define GMT_Q 32                         // 16-rank groups per read x strand
 #define GMT_LCAP 256                     // hits per read x strand
@@ -1791,8 +1791,11 @@ __device__ __forceinline__ void gm_vote_tiny_body(const GmDevIndex& ix, const Gm
         const uint32_t i = 64u * q + (uint32_t)lane;
         bp4[q] = i < n_l ? s_lbp[i] : 0u;
         if (bp4[q] != 0u) {
-            const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> 23;
-            atomicAdd(&s_r0[h2 & 255u], 1u << ((h2 >> 8) << 4));
+            // filter: 4096 slots of two bits in the 256 words - "seen" and "seen again".  At ~160 hits a slot is shared by chance by
+            // ~4 % of them (a 16-bit counter per slot, 512 slots: ~30 %, and every such hit went through the CAS loop of the table)
+            const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> 20, sh = (h2 >> 8) << 1;
+            const uint32_t old = atomicOr(&s_r0[h2 & 255u], 1u << sh);
+            if ((old >> sh) & 1u) atomicOr(&s_r0[h2 & 255u], 2u << sh);
         }
     }
     __syncthreads();
@@ -1800,10 +1803,10 @@ __device__ __forceinline__ void gm_vote_tiny_body(const GmDevIndex& ix, const Gm
     uint32_t nkeys = 0;
 #pragma unroll
     for (int q = 0; q < LQ; ++q) {
-        const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> 23;
-        const uint32_t c = (s_r0[h2 & 255u] >> ((h2 >> 8) << 4)) & 0xFFFFu;
+        const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> 20;
+        const uint32_t c = (s_r0[h2 & 255u] >> ((h2 >> 8) << 1)) & 3u;                    // 1 = one hit in the slot, 3 = more
         bool fresh = false;
-        if (bp4[q] != 0u && c >= thr) {
+        if (bp4[q] != 0u && (c & (thr >= 2u ? 2u : 1u))) {
             const uint32_t bp = bp4[q], t = s_lt[64u * q + (uint32_t)lane];
             uint32_t slot = (bp * 0x9E3779B1u) >> 25;
             uint32_t old;
@@ -1892,7 +1895,7 @@ __device__ __forceinline__ void gm_vote_tiny_body(const GmDevIndex& ix, const Gm
 
 template <bool MASK64, bool FULL, bool SEED>
 __global__ void __launch_bounds__(64, 8) k_vote_tiny(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
-    __shared__ uint4 s_r0v[192];                      // 3 KB: words [0,256) = 512 x 16-bit counters, [256,768) = 128 x key | votes | low mask | high mask
+    __shared__ uint4 s_r0v[192];                      // 3 KB: words [0,256) = 4096 x 2-bit filter, [256,768) = 128 x key | votes | low mask | high mask
     __shared__ uint32_t s_lbp[GMT_LCAP];
     __shared__ uint8_t s_lt[GMT_LCAP];
     __shared__ uint2 s_desc[GMT_Q];                   // {SA rank (flat entry index if !FULL) of the group's first hit, read offset | tag << 16 | hits << 24}
@@ -1939,14 +1942,14 @@ __global__ void __launch_bounds__(64, 8) k_vote_tiny(GmDevIndex ix, GmDevParams 
 }
 
 // ---- k_vote_tiny2: the same one-wave form for up to 384 hits in up to 64 groups (150-bp reads on a human-size reference: 20
-// seeds x ~12 hits; 10-mers on 20 Mbp).  No list at all: the hits stay in registers (16 steps), go through the 1024 x 16-bit
-// filter and, where their slot reached -k, straight into a 256-slot exact table.  6.8 KB of LDS: 23 read x strands per CU.
+// seeds x ~12 hits; 10-mers on 20 Mbp).  No list at all: the hits stay in registers (16 steps), go through the 8192 x 2-bit
+// filter and, where their slot was hit again, straight into a 256-slot exact table.  6.8 KB of LDS: 23 read x strands per CU.
 #define GMT2_Q 64
 #define GMT2_E 384
 template <bool MASK64, bool FULL, bool SEED>
 __global__ void __launch_bounds__(64, 6) k_vote_tiny2(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
     constexpr int U = GMT2_Q / 4, T2 = 256;
-    __shared__ uint4 s_r0v[384];                      // 6 KB: words [0,512) = 1024 x 16-bit counters, [512,1536) = 256 x key | votes | low mask | high mask
+    __shared__ uint4 s_r0v[384];                      // 6 KB: words [0,512) = 8192 x 2-bit filter, [512,1536) = 256 x key | votes | low mask | high mask
     __shared__ uint2 s_desc[GMT2_Q];
     __shared__ uint32_t s_cnt0[64];
     uint32_t* const s_r0 = reinterpret_cast<uint32_t*>(s_r0v);
@@ -2004,8 +2007,9 @@ __global__ void __launch_bounds__(64, 6) k_vote_tiny2(GmDevIndex ix, GmDevParams
         any0 |= z;
         if (!hit) bpv[j] = 0u;
         if (bpv[j] != 0u) {
-            const uint32_t h2 = (bpv[j] * 0x85EBCA6Bu) >> 22;
-            atomicAdd(&s_r0[h2 & 511u], 1u << ((h2 >> 9) << 4));
+            const uint32_t h2 = (bpv[j] * 0x85EBCA6Bu) >> 19, sh = (h2 >> 9) << 1;       // 8192 slots of two bits: seen / seen again (k_vote_tiny)
+            const uint32_t old = atomicOr(&s_r0[h2 & 511u], 1u << sh);
+            if ((old >> sh) & 1u) atomicOr(&s_r0[h2 & 511u], 2u << sh);
         }
     }
     const bool wave_any0 = __builtin_amdgcn_ballot_w64(any0) != 0ull;
@@ -2018,10 +2022,10 @@ __global__ void __launch_bounds__(64, 6) k_vote_tiny2(GmDevIndex ix, GmDevParams
 #pragma unroll
     for (int j = 0; j < U; ++j) {
         const uint32_t bp = bpv[j];
-        const uint32_t h2 = (bp * 0x85EBCA6Bu) >> 22;
-        const uint32_t c = (s_r0[h2 & 511u] >> ((h2 >> 9) << 4)) & 0xFFFFu;
+        const uint32_t h2 = (bp * 0x85EBCA6Bu) >> 19;
+        const uint32_t c = (s_r0[h2 & 511u] >> ((h2 >> 9) << 1)) & 3u;
         bool fresh = false;
-        if (bp != 0u && c >= thr) {
+        if (bp != 0u && (c & (thr >= 2u ? 2u : 1u))) {
             const uint32_t t = tg[j];
             uint32_t slot = (bp * 0x9E3779B1u) >> 24;
             uint32_t old;

@@ -62,12 +62,19 @@ def main():
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / a.steps * 1e3
         c = batch.counters()
+        batch.set_profiling(True)                      # one more pass with HIP events around every kernel
+        batch.kernel_times()
+        batch.map_device(p)
+        torch.cuda.synchronize()
+        kt = batch.kernel_times()
+        batch.set_profiling(False)
+        per = "  ".join(f"{k.split('(')[0][2:]} {v[0]:.2f}" for k, v in kt.items() if v[1])
         same = True
         if base_counters is None:
             base_counters = c
         else:
             same = all(c[k] == base_counters[k] for k in ("candidates", "accepted", "nw_cells", "sa_hits"))
-        print(f"[sweep] {s or '(default)':48s} {ms:8.3f} ms / step  {a.reads / ms / 1e3:8.1f} M reads/s  counters {'same' if same else 'DIFFER'}", flush=True)
+        print(f"[sweep] {s or '(default)':48s} {ms:8.3f} ms / step  {a.reads / ms / 1e3:8.1f} M reads/s  counters {'same' if same else 'DIFFER'}  | {per}", flush=True)
         for k in sets:
             del os.environ[k]
 
