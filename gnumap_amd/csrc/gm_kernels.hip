@@ -1737,14 +1737,15 @@ __device__ __forceinline__ bool gm_tiny_seeds(const GmDevIndex& ix, const GmDevP
 // Long seeds on a large reference (-m 14 on 3.1 Gbp: 13 seeds x ~12 hits) leave k_vote_slots latency-bound: a workgroup's life is
 // three dependent HBM round trips (seeds, SA ranks, candidate reservation) and 10 KB of LDS allow 16 of them per CU.  Here a read x
 // strand is one wave and 4.9 KB of LDS (32 per CU: every wave slot of the CU), a descriptor covers 16 consecutive ranks of one seed (a 64-lane step holds
-// four seeds' hits: ~75 % of the lanes carry a hit instead of ~20 %), there is no first counting filter (every hit goes to the
-// list), and the list goes through the second filter (4096 x 2 bit: seen / seen again) into a 128-slot exact table as in k_vote_slots.
+// four seeds' hits: ~75 % of the lanes carry a hit instead of ~20 %), there is no first counting filter: the hits go through
+// the second filter (4096 x 2 bit: seen / seen again) into a 128-slot exact table as in k_vote_slots - straight from their load
+// steps when there are four of those (at most 16 groups), through a dense list of 64-hit chunks when there are eight.
 // More hits or groups than that -> b.big_list -> k_vote_fast_list; a table that fills up -> the retry kernel.
 #define GMT_Q 32                         // 16-rank groups per read x strand
 #define GMT_LCAP 256                     // hits per read x strand
 // the part of k_vote_tiny after its descriptors are in LDS, unrolled for UU load steps (4 groups of 16 ranks each) and LQ list
-// chunks of 64 hits: the kernel is vector-issue bound, and a read x strand of 13 seeds x ~12 hits fills 4 of the 8 steps and 3 of
-// the 4 chunks - the step counts are wave-uniform, so the kernel picks the instantiation instead of walking empty steps
+// chunks of 64 hits (LQ = 0: no list): the kernel is vector-issue bound, and a read x strand of 13 seeds x ~12 hits fills 4 of the
+// 8 steps - the step counts are wave-uniform, so the kernel picks the instantiation instead of walking empty steps
 template <bool MASK64, bool FULL, bool SEED, int UU, int LQ>
 __device__ __forceinline__ void gm_vote_tiny_body(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, const uint32_t rs, const int lane, const uint32_t E,
                                                   uint4* s_r0v, uint32_t* s_lbp, uint8_t* s_lt, const uint2* s_desc, uint32_t* s_cnt0) {
@@ -1763,9 +1764,11 @@ __device__ __forceinline__ void gm_vote_tiny_body(const GmDevIndex& ix, const Gm
         if (valid) v = src[d.x + sub];
         bpv[j] = valid ? __builtin_elementwise_sub_sat(v, d.y & 0xFFFFu) : 0xFFFFFFFFu;      // :267; 0xFFFFFFFF = no hit (never a window start)
     }
-    // ---- every hit goes to the list; b = 0 votes are counted per step tag
+    // ---- LQ > 0: every hit goes to the list (dense chunks of 64); LQ = 0: the hits stay in their load steps.  b = 0 votes are counted per step tag
+    constexpr int NP = LQ == 0 ? UU : LQ;
     uint32_t wcount = 0;
     bool any0 = false;
+    uint32_t bp4[NP];
 #pragma unroll
     for (int j = 0; j < UU; ++j) {
         const bool hit = bpv[j] != 0xFFFFFFFFu;
@@ -1773,23 +1776,24 @@ __device__ __forceinline__ void gm_vote_tiny_body(const GmDevIndex& ix, const Gm
         if (z) atomicAdd(&s_cnt0[tg[j]], 1u);
         any0 |= z;
         const bool pass = hit && !z;
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
-        if (pass) {
-            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, wcount));      // < E <= GMT_LCAP
-            s_lbp[at] = bpv[j]; s_lt[at] = (uint8_t)tg[j];
+        if constexpr (LQ == 0) bp4[j] = pass ? bpv[j] : 0u;
+        else {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+            if (pass) {
+                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, wcount));      // < E <= GMT_LCAP
+                s_lbp[at] = bpv[j]; s_lt[at] = (uint8_t)tg[j];
+            }
+            wcount += (uint32_t)__popcll(m);
         }
-        wcount += (uint32_t)__popcll(m);
     }
     const bool wave_any0 = __builtin_amdgcn_ballot_w64(any0) != 0ull;
-    __syncthreads();
+    if constexpr (LQ != 0) __syncthreads();
     uint32_t* const keys = s_r0 + 256; uint32_t* const vals = keys + T2; uint32_t* const mlo = keys + 2 * T2; uint32_t* const mhi = keys + 3 * T2;
     const uint32_t n_l = wcount;
     const uint32_t thr = (uint32_t)(p.kmin < 1 ? 1 : p.kmin);
-    uint32_t bp4[LQ];
 #pragma unroll
-    for (int q = 0; q < LQ; ++q) {
-        const uint32_t i = 64u * q + (uint32_t)lane;
-        bp4[q] = i < n_l ? s_lbp[i] : 0u;
+    for (int q = 0; q < NP; ++q) {
+        if constexpr (LQ != 0) { const uint32_t i = 64u * q + (uint32_t)lane; bp4[q] = i < n_l ? s_lbp[i] : 0u; }
         if (bp4[q] != 0u) {
             // filter: 4096 slots of two bits in the 256 words - "seen" and "seen again".  At ~160 hits a slot is shared by chance by
             // ~4 % of them (a 16-bit counter per slot, 512 slots: ~30 %, and every such hit went through the CAS loop of the table)
@@ -1802,12 +1806,14 @@ __device__ __forceinline__ void gm_vote_tiny_body(const GmDevIndex& ix, const Gm
     bool full = false;
     uint32_t nkeys = 0;
 #pragma unroll
-    for (int q = 0; q < LQ; ++q) {
+    for (int q = 0; q < NP; ++q) {
         const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> 20;
         const uint32_t c = (s_r0[h2 & 255u] >> ((h2 >> 8) << 1)) & 3u;                    // 1 = one hit in the slot, 3 = more
         bool fresh = false;
         if (bp4[q] != 0u && (c & (thr >= 2u ? 2u : 1u))) {
-            const uint32_t bp = bp4[q], t = s_lt[64u * q + (uint32_t)lane];
+            uint32_t t;
+            if constexpr (LQ == 0) t = tg[q]; else t = s_lt[64u * q + (uint32_t)lane];
+            const uint32_t bp = bp4[q];
             uint32_t slot = (bp * 0x9E3779B1u) >> 25;
             uint32_t old;
             int probes = 0;
@@ -1933,8 +1939,9 @@ __global__ void __launch_bounds__(64, 8) k_vote_tiny(GmDevIndex ix, GmDevParams 
     }
     __syncthreads();
     if (Q <= 16u) {
-        if (E <= 192u) gm_vote_tiny_body<MASK64, FULL, SEED, 4, 3>(ix, p, b, rs, lane, E, s_r0v, s_lbp, s_lt, s_desc, s_cnt0);
-        else gm_vote_tiny_body<MASK64, FULL, SEED, 4, 4>(ix, p, b, rs, lane, E, s_r0v, s_lbp, s_lt, s_desc, s_cnt0);
+        // four load steps: the hits stay where they were loaded (no list: with the two-bit filter few hits reach the table, and
+        // the 3 - 4 dense chunks the list buys cost more than the fourth sparse step; measured 16.6 -> 16.45 ms)
+        gm_vote_tiny_body<MASK64, FULL, SEED, 4, 0>(ix, p, b, rs, lane, E, s_r0v, s_lbp, s_lt, s_desc, s_cnt0);
     } else {
         if (E <= 192u) gm_vote_tiny_body<MASK64, FULL, SEED, 8, 3>(ix, p, b, rs, lane, E, s_r0v, s_lbp, s_lt, s_desc, s_cnt0);
         else gm_vote_tiny_body<MASK64, FULL, SEED, 8, 4>(ix, p, b, rs, lane, E, s_r0v, s_lbp, s_lt, s_desc, s_cnt0);
