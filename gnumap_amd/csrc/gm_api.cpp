@@ -728,11 +728,16 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
     static const uint64_t heavy_budget = [] { const char* e = getenv("GM_HEAVY_BUDGET"); return e ? (uint64_t)atoll(e) : (uint64_t)1 << 27; }();
     dp.heavy_min = heavy_min;
     // seed lookup inside the one-wave vote kernels (k_vote_tiny / k_vote_tiny2 on the full SA, the k-mer table covering the whole
-    // seed): no k_seed launch, no seed rows through HBM.  GM_SEED_FUSED=0 keeps the two-kernel form.
+    // seed): no k_seed launch, no seed rows through HBM.  It pays while a k-mer that changes the walk (one that does not occur, or
+    // exceeds -h) is rare - such a read x strand is walked by ONE lane: every k-mer must be expected >= 8 times in the reference
+    // (absent with probability e^-8; measured on 100 Mbp: -m 12, 6 per k-mer, 4 % of the waves on the serial walk: 29.0 against 26.5 ms;
+    // -m 14, 0.4 per k-mer: 398 against 29.5 ms) and -h, if set, must sit well above that.  GM_SEED_FUSED=0 / 1: never / whenever possible.
     {
-        static const bool fused_ok = [] { const char* e = getenv("GM_SEED_FUSED"); return !(e && !strcmp(e, "0")); }();
-        dp.fused = fused_ok && use_full && dense == 1 && slots_hint <= 0 && !getenv("GM_VOTE_KERNEL") && b->max_seeds <= 64 && dp.kmer_tab && dp.kmer_ctab && dp.kmer_T == p->mer &&
-                   p->mer <= 16 && p->jump >= 1 && !(dp.dbg & 128);
+        static const int fused_env = [] { const char* e = getenv("GM_SEED_FUSED"); return e ? atoi(e) : -1; }();
+        const double occ = (double)ix->h.seq_len / pow(4.0, (double)std::min(p->mer, 31));
+        const bool pays = occ >= 8.0 && (p->max_kmer_hits == 0 || (double)p->max_kmer_hits >= occ + 6.0 * sqrt(occ) + 8.0);
+        dp.fused = (fused_env < 0 ? pays : fused_env != 0) && use_full && (dense == 1 || dense == 2) && !getenv("GM_VOTE_KERNEL") && b->max_seeds <= 64 && dp.kmer_tab &&
+                   dp.kmer_ctab && dp.kmer_T == p->mer && p->mer <= 16 && p->jump >= 1 && !(dp.dbg & 128);
         b->use_pack = dp.fused != 0;
         if (b->use_pack && b->pack.ensure((size_t)b->n * gm_pack_words(b->stride) * 4 + 64)) return GM_E_NOMEM;
     }

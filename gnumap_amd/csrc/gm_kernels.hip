@@ -1292,13 +1292,142 @@ __device__ __forceinline__ uint32_t gm_wave_scan_incl(uint32_t x) {
     return v;
 }
 
+// ---- seeds of the vote kernels that take one read x strand per wave / workgroup ---------------------------------------------------------------------------------------
+// SEED = false: the read x strand's row of b.seeds, written by k_seed.
+// SEED = true (GmDevParams::fused; full SA, the k-mer table covers the whole seed): the wave looks its seeds up itself and no seed
+// row goes through HBM.  While nothing fails the adaptive walk (gm_seed_walk) visits i = 0, jump, 2 jump ... < L - mer, so lane j
+// takes the k-mer at j * jump: its table code is 2 * mer bits of the read's 2-bit form (k_prep: GmDevBatch::pack), one 16-byte
+// table record gives the interval.  A k-mer that does not occur or exceeds -h changes the positions of all later ones, and so does
+// a non-ACGT base: then lane 0 runs the walk itself, exactly as k_seed does, into LDS.  Either way the seeds are those of k_seed.
+// n_seeds / n_entries of every read x strand still go to HBM (6 bytes): the heavy-path routing and the work counters
+// (k_heavy_collect) read them; the kernels a read x strand may be handed to (list, retry, heavy) get its seed row written first.
+// The serial walk of the rare cases is kept OUT OF LINE: inlined, the index fields it needs were loaded at the top of every wave
+// and pushed ~40 scalar registers into vector lanes (one vector instruction each, on a kernel that is bound by vector issue).
+// The callee finds the kernel's arguments where the hardware put them (the kernarg segment: ix, p, b in this order).
+struct GmKArgs { GmDevIndex ix; GmDevParams p; GmDevBatch b; };
+// one lane.  out = where the seeds go (LDS), or null: the read x strand's row in HBM, for the kernel it is handed to.  count = add the
+// failed k-mers to the work counters (k_heavy_collect counts one k-mer and one table probe per seed).  Returns the number of seeds.
+__device__ __attribute__((noinline)) uint32_t gm_seed_walk_ool(const GmKArgs* a, const uint32_t rs, GmSeed* out, const int count) {
+    const GmDevBatch& b = a->b;
+    unsigned long long nk = 0, nocc = 0, nblk = 0, ntab = 0, nseed = 0, nent = 0;
+    const uint32_t r = rs >> 1;
+    gm_seed_walk(a->ix, a->p, b.bases + (size_t)r * b.stride, b.len[r], rs & 1u, out ? out : b.seeds + (size_t)rs * b.max_seeds, b.max_seeds, nk, nocc, nblk, ntab,
+                 nseed, nent);
+    if (count) {
+        if (nk > nseed) atomicAdd(&b.counters[GMK_KMERS], nk - nseed);
+        if (ntab > nseed) atomicAdd(&b.counters[GMK_TAB_LOOKUPS], ntab - nseed);
+        if (nocc) { atomicAdd(&b.counters[GMK_OCC], nocc); atomicAdd(&b.counters[GMK_OCC_BLOCKS], nblk); }
+    }
+    return (uint32_t)nseed;
+}
+__device__ __forceinline__ const GmKArgs* gm_kargs() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (const GmKArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    return nullptr;
+#endif
+}
+
+// returns false when the wave has nothing more to do (no seeds, or handed to the heavy path)
+template <bool SEED>
+__device__ __forceinline__ bool gm_tiny_seeds(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, const uint32_t rs, const int lane,
+                                              GmSeed* scratch /* LDS, 64 seeds, free to use */, GmSeed& sd, uint32_t& ns, uint32_t& ie_all) {
+    sd.k = 0; sd.l = 0; sd.pos = 0;
+    ie_all = 0xFFFFFFFFu;                             // inclusive scan of the seeds' hit counts when the function has computed it
+    if (!SEED) {
+        if ((uint32_t)lane < b.max_seeds) sd = b.seeds[(size_t)rs * b.max_seeds + lane];
+        ns = b.n_seeds[rs];
+        return true;
+    }
+    const uint32_t r = rs >> 1, strand = rs & 1u;
+    ns = 0;
+    // one round trip: the row's header and the two words that hold this lane's k-mer (their address does not depend on the length)
+    const uint32_t m = (uint32_t)p.mer, w2 = b.pack_w2;
+    const uint32_t i = (uint32_t)lane * (uint32_t)p.jump;
+    const uint32_t* const row = b.pack + (size_t)r * b.pack_words;
+    const bool inrow = i + m <= 16u * w2;
+    const uint32_t o = inrow ? 2u * (16u * w2 - i - m) : 0u;
+    const uint32_t* const form = row + (strand ? w2 + 2u : 1u);
+    const uint32_t hdr = row[0], f0 = form[o >> 5], f1 = form[(o >> 5) + 1u];
+    asm volatile("" :: "v"(f0), "v"(f1));             // issued here, beside the header, not after the branch on it
+    const uint32_t L = hdr & 0xFFFFu;
+    const bool on = !((hdr >> 17) & 1u) && (strand ? p.neg_strand : p.pos_strand);      // wave-uniform
+    if (on) {
+        const bool act = i + m < L;                                                      // lanes 0 .. ceil((L - mer) / jump) - 1
+        const uint32_t nreg = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(act));
+        bool bad = act && ((hdr >> 16) & 1u);                                            // a read with a non-ACGT base takes the serial walk
+        uint32_t k = 0, cnt = 0;
+        if (act && !bad) {
+            const uint32_t code = (uint32_t)((((unsigned long long)f1 << 32) | f0) >> (o & 31u)) & (m >= 16u ? 0xFFFFFFFFu : ((1u << (2u * m)) - 1u));
+            {                                                                            // the table probe of gm_seed_walk
+                bool answered = false;
+                if (p.kmer_ctab) {
+                    const uint4 rec = p.kmer_ctab[code >> 3];
+                    asm volatile("" :: "v"(rec.x), "v"(rec.y), "v"(rec.z), "v"(rec.w));      // ONE 16-byte load (the compiler would fetch rec.x in a second trip, where it is used)
+                    // the record of gm_seed_walk, decoded per 32-bit half: the bytes below this code's (empty codes, >= 224, count 0) add up
+                    // in two byte-sum instructions
+                    const uint32_t sub = code & 7u, sh = (sub & 3u) << 3;
+                    const uint32_t own = sub < 4u ? rec.y : rec.z;
+                    cnt = (own >> sh) & 255u;
+                    if (rec.w == 0u && cnt >= 224u) { bad = true; answered = true; }
+                    else if (rec.w == 0u) {
+                        const uint32_t part = own & ((1u << sh) - 1u);                  // bytes below the code's inside its own half
+                        uint32_t lo = sub < 4u ? part : rec.y, hi = sub < 4u ? 0u : part;
+                        lo &= ~(((lo & (lo << 1) & (lo << 2) & 0x80808080u) >> 7) * 0xFFu);
+                        hi &= ~(((hi & (hi << 1) & (hi << 2) & 0x80808080u) >> 7) * 0xFFu);
+                        k = rec.x + __builtin_amdgcn_sad_u8(lo, 0u, __builtin_amdgcn_sad_u8(hi, 0u, 0u));
+                        answered = true;
+                    }
+                }
+                if (!answered) {
+                    const uint2 iv = p.kmer_tab[code];
+                    if (iv.x == 0xFFFFFFFFu) bad = true;
+                    else { k = iv.x; cnt = iv.y - iv.x + 1u; }
+                }
+                if (p.hcap > 0 && cnt > p.hcap) bad = true;
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(bad) == 0ull) {
+            ns = nreg;
+            if (act) { sd.k = k; sd.l = k + cnt - 1u; sd.pos = i; }
+        } else {                                                                          // rare: the serial walk, by lane 0
+            uint32_t nseed = 0;
+            if (lane == 0) nseed = gm_seed_walk_ool(gm_kargs(), rs, scratch, 1);
+            // ONE wave runs this function (a one-wave workgroup, or wave 0 of k_vote_slots): the callee's stores to LDS have to
+            // be complete before the wave's other lanes read them, no workgroup barrier
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            ns = (uint32_t)__builtin_amdgcn_readlane((int)nseed, 0);
+            if ((uint32_t)lane < ns) sd = scratch[lane];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+    }
+    // n_seeds / n_entries (saturating, like k_seed) of this read x strand
+    const uint32_t c_all = (uint32_t)lane < ns ? sd.l - sd.k + 1u : 0u;
+    uint32_t e_all;
+    if (__builtin_amdgcn_ballot_w64(c_all > (1u << 24)) != 0ull) {                       // the 32-bit sum could overflow
+        const unsigned long long e64 = gm_wave_sum((unsigned long long)c_all);
+        e_all = e64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)e64;
+        if (lane == 0 && e64 > 0xFFFFFFFFull) atomicAdd(&b.counters[GMK_SA_HITS], e64 - 0xFFFFFFFFull);     // k_heavy_collect adds n_entries
+    } else {
+        ie_all = gm_wave_scan_incl(c_all);                                               // the caller's scan of the hit counts, unless --fast cuts the seeds
+        e_all = (uint32_t)__builtin_amdgcn_readlane((int)ie_all, 63);
+    }
+    if (lane == 0) { b.n_seeds[rs] = (uint16_t)ns; b.n_entries[rs] = e_all; }
+    if (ns == 0) return false;
+    if (e_all > p.heavy_min) {                                                            // sorted-key path: it reads the seed row
+        if ((uint32_t)lane < ns) b.seeds[(size_t)rs * b.max_seeds + lane] = sd;
+        return false;
+    }
+    return true;
+}
+
 #define GMS_SMAX 40                      // slots (64 lanes each) a read x strand may take in this kernel
 #define GMS_LCAP 540                     // compacted list entries per workgroup (more -> retry kernel)
 // SMAX = slots a read x strand may take: 16 / 24 / 40 for few seeds or few hits per seed (every slot of the form is walked,
 // used or not, so the small forms are the fast ones there), 64 = BIG, the form for 41..64 slots (e.g. 10-mers on a 150 Mbp
 // reference: ~150 hits per seed): 32 slots per wave, a longer list, the second filter takes the whole zeroed region
 // (4096 x 16 bit) and the table its own 4 KB.
-template <bool MASK64, bool FULL, int SMAX>
+template <bool MASK64, bool FULL, int SMAX, bool SEED>
 __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vote_slots(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
     constexpr bool BIG = SMAX == 64;
     constexpr int LCAP = BIG ? 1280 : SMAX == 16 ? 320 : GMS_LCAP;      // 16-slot form: 10.0 KB of LDS, 16 workgroups per CU
@@ -1320,15 +1449,17 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
     long long tck = prof ? clock64() : 0;
     auto tick = [&](int slot) { if (prof) { long long now = clock64(); atomicAdd(&b.counters[GMK_DBG0 + slot], (unsigned long long)(now - tck)); tck = now; } };
     if (wave == 0) {                                 // seeds -> slot descriptors
-        GmSeed sd; sd.k = 0; sd.l = 0; sd.pos = 0;
-        if ((uint32_t)lane < b.max_seeds) sd = b.seeds[(size_t)rs * b.max_seeds + lane];      // not waiting for n_seeds: one round trip
-        uint32_t ns = b.n_seeds[rs];
+        // SEED: the wave looks the seeds up itself (gm_tiny_seeds: lane j takes the k-mer at j * jump; no k_seed launch)
+        GmSeed sd; uint32_t ns, ie_all;
+        const bool go = gm_tiny_seeds<SEED>(ix, p, b, rs, lane, reinterpret_cast<GmSeed*>(s_lbp), sd, ns, ie_all);      // SEED = false: the seed row, not waiting for n_seeds: one round trip
+        if (!go) ns = 0;                         // nothing to vote on, or left to the heavy path
         if (p.nw && p.fast && ns > 1) ns = 1;
         const uint32_t cnt = (uint32_t)lane < ns ? sd.l - sd.k + 1 : 0u;
         const uint32_t nsl = (cnt + 63u) >> 6;
         const uint32_t ie = gm_wave_scan_incl(cnt), is = gm_wave_scan_incl(nsl);
         uint32_t E0 = __builtin_amdgcn_readlane(ie, 63), S0 = __builtin_amdgcn_readlane(is, 63);
         if (S0 > SMAX) {                         // wave-uniform: hand over to the list kernel
+            if (SEED && (uint32_t)lane < b.max_seeds) b.seeds[(size_t)rs * b.max_seeds + lane] = sd;
             if (lane == 0) { const uint32_t at = atomicAdd(b.n_big, 1u); b.big_list[at] = rs; }
             S0 = 0; E0 = 0;
         } else {
@@ -1532,6 +1663,7 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
     const bool failed = lfull || s_full || s_nkeys > (uint32_t)(T2 * 3 / 4);
     if (failed) {                                    // hand this read x strand to the global-table kernel
         if (tid == 0) {
+            if (SEED) (void)gm_seed_walk_ool(gm_kargs(), rs, nullptr, 0);      // the retry kernel reads the seed row
             b.rs_overflow[rs] = 1;
             const uint32_t j = atomicAdd(b.n_retry, 1u);
             const uint32_t need = 2 * E; uint32_t sz = 1024; while (sz < need && sz < 0x80000000u) sz <<= 1;
@@ -1606,133 +1738,6 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
     if (prof) atomicAdd(&b.counters[GMK_DBG8], 1ull);
 }
 
-// ---- seeds of the one-wave vote kernels ---------------------------------------------------------------------------------------
-// SEED = false: the read x strand's row of b.seeds, written by k_seed.
-// SEED = true (GmDevParams::fused; full SA, the k-mer table covers the whole seed): the wave looks its seeds up itself and no seed
-// row goes through HBM.  While nothing fails the adaptive walk (gm_seed_walk) visits i = 0, jump, 2 jump ... < L - mer, so lane j
-// takes the k-mer at j * jump: its table code is 2 * mer bits of the read's 2-bit form (k_prep: GmDevBatch::pack), one 16-byte
-// table record gives the interval.  A k-mer that does not occur or exceeds -h changes the positions of all later ones, and so does
-// a non-ACGT base: then lane 0 runs the walk itself, exactly as k_seed does, into LDS.  Either way the seeds are those of k_seed.
-// n_seeds / n_entries of every read x strand still go to HBM (6 bytes): the heavy-path routing and the work counters
-// (k_heavy_collect) read them; the kernels a read x strand may be handed to (list, retry, heavy) get its seed row written first.
-// The serial walk of the rare cases is kept OUT OF LINE: inlined, the index fields it needs were loaded at the top of every wave
-// and pushed ~40 scalar registers into vector lanes (one vector instruction each, on a kernel that is bound by vector issue).
-// The callee finds the kernel's arguments where the hardware put them (the kernarg segment: ix, p, b in this order).
-struct GmKArgs { GmDevIndex ix; GmDevParams p; GmDevBatch b; };
-// one lane.  out = where the seeds go (LDS), or null: the read x strand's row in HBM, for the kernel it is handed to.  count = add the
-// failed k-mers to the work counters (k_heavy_collect counts one k-mer and one table probe per seed).  Returns the number of seeds.
-__device__ __attribute__((noinline)) uint32_t gm_seed_walk_ool(const GmKArgs* a, const uint32_t rs, GmSeed* out, const int count) {
-    const GmDevBatch& b = a->b;
-    unsigned long long nk = 0, nocc = 0, nblk = 0, ntab = 0, nseed = 0, nent = 0;
-    const uint32_t r = rs >> 1;
-    gm_seed_walk(a->ix, a->p, b.bases + (size_t)r * b.stride, b.len[r], rs & 1u, out ? out : b.seeds + (size_t)rs * b.max_seeds, b.max_seeds, nk, nocc, nblk, ntab,
-                 nseed, nent);
-    if (count) {
-        if (nk > nseed) atomicAdd(&b.counters[GMK_KMERS], nk - nseed);
-        if (ntab > nseed) atomicAdd(&b.counters[GMK_TAB_LOOKUPS], ntab - nseed);
-        if (nocc) { atomicAdd(&b.counters[GMK_OCC], nocc); atomicAdd(&b.counters[GMK_OCC_BLOCKS], nblk); }
-    }
-    return (uint32_t)nseed;
-}
-__device__ __forceinline__ const GmKArgs* gm_kargs() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (const GmKArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-#else
-    return nullptr;
-#endif
-}
-
-// returns false when the wave has nothing more to do (no seeds, or handed to the heavy path)
-template <bool SEED>
-__device__ __forceinline__ bool gm_tiny_seeds(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, const uint32_t rs, const int lane,
-                                              GmSeed* scratch /* LDS, 64 seeds, free to use */, GmSeed& sd, uint32_t& ns, uint32_t& ie_all) {
-    sd.k = 0; sd.l = 0; sd.pos = 0;
-    ie_all = 0xFFFFFFFFu;                             // inclusive scan of the seeds' hit counts when the function has computed it
-    if (!SEED) {
-        if ((uint32_t)lane < b.max_seeds) sd = b.seeds[(size_t)rs * b.max_seeds + lane];
-        ns = b.n_seeds[rs];
-        return true;
-    }
-    const uint32_t r = rs >> 1, strand = rs & 1u;
-    ns = 0;
-    // one round trip: the row's header and the two words that hold this lane's k-mer (their address does not depend on the length)
-    const uint32_t m = (uint32_t)p.mer, w2 = b.pack_w2;
-    const uint32_t i = (uint32_t)lane * (uint32_t)p.jump;
-    const uint32_t* const row = b.pack + (size_t)r * b.pack_words;
-    const bool inrow = i + m <= 16u * w2;
-    const uint32_t o = inrow ? 2u * (16u * w2 - i - m) : 0u;
-    const uint32_t* const form = row + (strand ? w2 + 2u : 1u);
-    const uint32_t hdr = row[0], f0 = form[o >> 5], f1 = form[(o >> 5) + 1u];
-    asm volatile("" :: "v"(f0), "v"(f1));             // issued here, beside the header, not after the branch on it
-    const uint32_t L = hdr & 0xFFFFu;
-    const bool on = !((hdr >> 17) & 1u) && (strand ? p.neg_strand : p.pos_strand);      // wave-uniform
-    if (on) {
-        const bool act = i + m < L;                                                      // lanes 0 .. ceil((L - mer) / jump) - 1
-        const uint32_t nreg = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(act));
-        bool bad = act && ((hdr >> 16) & 1u);                                            // a read with a non-ACGT base takes the serial walk
-        uint32_t k = 0, cnt = 0;
-        if (act && !bad) {
-            const uint32_t code = (uint32_t)((((unsigned long long)f1 << 32) | f0) >> (o & 31u)) & (m >= 16u ? 0xFFFFFFFFu : ((1u << (2u * m)) - 1u));
-            {                                                                            // the table probe of gm_seed_walk
-                bool answered = false;
-                if (p.kmer_ctab) {
-                    const uint4 rec = p.kmer_ctab[code >> 3];
-                    asm volatile("" :: "v"(rec.x), "v"(rec.y), "v"(rec.z), "v"(rec.w));      // ONE 16-byte load (the compiler would fetch rec.x in a second trip, where it is used)
-                    // the record of gm_seed_walk, decoded per 32-bit half: the bytes below this code's (empty codes, >= 224, count 0) add up
-                    // in two byte-sum instructions
-                    const uint32_t sub = code & 7u, sh = (sub & 3u) << 3;
-                    const uint32_t own = sub < 4u ? rec.y : rec.z;
-                    cnt = (own >> sh) & 255u;
-                    if (rec.w == 0u && cnt >= 224u) { bad = true; answered = true; }
-                    else if (rec.w == 0u) {
-                        const uint32_t part = own & ((1u << sh) - 1u);                  // bytes below the code's inside its own half
-                        uint32_t lo = sub < 4u ? part : rec.y, hi = sub < 4u ? 0u : part;
-                        lo &= ~(((lo & (lo << 1) & (lo << 2) & 0x80808080u) >> 7) * 0xFFu);
-                        hi &= ~(((hi & (hi << 1) & (hi << 2) & 0x80808080u) >> 7) * 0xFFu);
-                        k = rec.x + __builtin_amdgcn_sad_u8(lo, 0u, __builtin_amdgcn_sad_u8(hi, 0u, 0u));
-                        answered = true;
-                    }
-                }
-                if (!answered) {
-                    const uint2 iv = p.kmer_tab[code];
-                    if (iv.x == 0xFFFFFFFFu) bad = true;
-                    else { k = iv.x; cnt = iv.y - iv.x + 1u; }
-                }
-                if (p.hcap > 0 && cnt > p.hcap) bad = true;
-            }
-        }
-        if (__builtin_amdgcn_ballot_w64(bad) == 0ull) {
-            ns = nreg;
-            if (act) { sd.k = k; sd.l = k + cnt - 1u; sd.pos = i; }
-        } else {                                                                          // rare: the serial walk, by lane 0
-            uint32_t nseed = 0;
-            if (lane == 0) nseed = gm_seed_walk_ool(gm_kargs(), rs, scratch, 1);
-            __syncthreads();
-            ns = (uint32_t)__builtin_amdgcn_readlane((int)nseed, 0);
-            if ((uint32_t)lane < ns) sd = scratch[lane];
-            __syncthreads();
-        }
-    }
-    // n_seeds / n_entries (saturating, like k_seed) of this read x strand
-    const uint32_t c_all = (uint32_t)lane < ns ? sd.l - sd.k + 1u : 0u;
-    uint32_t e_all;
-    if (__builtin_amdgcn_ballot_w64(c_all > (1u << 24)) != 0ull) {                       // the 32-bit sum could overflow
-        const unsigned long long e64 = gm_wave_sum((unsigned long long)c_all);
-        e_all = e64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)e64;
-        if (lane == 0 && e64 > 0xFFFFFFFFull) atomicAdd(&b.counters[GMK_SA_HITS], e64 - 0xFFFFFFFFull);     // k_heavy_collect adds n_entries
-    } else {
-        ie_all = gm_wave_scan_incl(c_all);                                               // the caller's scan of the hit counts, unless --fast cuts the seeds
-        e_all = (uint32_t)__builtin_amdgcn_readlane((int)ie_all, 63);
-    }
-    if (lane == 0) { b.n_seeds[rs] = (uint16_t)ns; b.n_entries[rs] = e_all; }
-    if (ns == 0) return false;
-    if (e_all > p.heavy_min) {                                                            // sorted-key path: it reads the seed row
-        if ((uint32_t)lane < ns) b.seeds[(size_t)rs * b.max_seeds + lane] = sd;
-        return false;
-    }
-    return true;
-}
-
 // ---- k_vote_tiny: one WAVEFRONT per read x strand, for at most 256 SA hits in at most 32 groups of 16 ranks ----------------
 // Long seeds on a large reference (-m 14 on 3.1 Gbp: 13 seeds x ~12 hits) leave k_vote_slots latency-bound: a workgroup's life is
 // three dependent HBM round trips (seeds, SA ranks, candidate reservation) and 10 KB of LDS allow 16 of them per CU.  Here a read x
@@ -1791,26 +1796,44 @@ __device__ __forceinline__ void gm_vote_tiny_body(const GmDevIndex& ix, const Gm
     uint32_t* const keys = s_r0 + 256; uint32_t* const vals = keys + T2; uint32_t* const mlo = keys + 2 * T2; uint32_t* const mhi = keys + 3 * T2;
     const uint32_t n_l = wcount;
     const uint32_t thr = (uint32_t)(p.kmin < 1 ? 1 : p.kmin);
+    const bool few = E <= 136u;                      // wave-uniform: which filter (measured: counters 8 % ahead at ~120 hits, two bits 5 % at ~156)
 #pragma unroll
-    for (int q = 0; q < NP; ++q) {
+    for (int q = 0; q < NP; ++q)
         if constexpr (LQ != 0) { const uint32_t i = 64u * q + (uint32_t)lane; bp4[q] = i < n_l ? s_lbp[i] : 0u; }
-        if (bp4[q] != 0u) {
-            // filter: 4096 slots of two bits in the 256 words - "seen" and "seen again".  At ~160 hits a slot is shared by chance by
-            // ~4 % of them (a 16-bit counter per slot, 512 slots: ~30 %, and every such hit went through the CAS loop of the table)
-            const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> 20, sh = (h2 >> 8) << 1;
-            const uint32_t old = atomicOr(&s_r0[h2 & 255u], 1u << sh);
-            if ((old >> sh) & 1u) atomicOr(&s_r0[h2 & 255u], 2u << sh);
-        }
+    if (few) {                                       // 512 counters of 16 bits: one non-returning atomic per hit
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+            if (bp4[q] != 0u) {
+                const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> 23;
+                atomicAdd(&s_r0[h2 & 255u], 1u << ((h2 >> 8) << 4));
+            }
+    } else {
+        // 4096 slots of two bits in the same 256 words - "seen" and "seen again".  At ~160 hits a slot is shared by chance by ~4 % of
+        // them (512 counters: ~30 %, and every such hit goes through the CAS loop of the table); the returning atomic costs ~7
+        // instructions per pass, which is why the counters stay for few hits (wave-uniform choice)
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+            if (bp4[q] != 0u) {
+                const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> 20, sh = (h2 >> 8) << 1;
+                const uint32_t old = atomicOr(&s_r0[h2 & 255u], 1u << sh);
+                if ((old >> sh) & 1u) atomicOr(&s_r0[h2 & 255u], 2u << sh);
+            }
     }
     __syncthreads();
+    bool reached[NP];
+    if (few) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> 23; reached[q] = ((s_r0[h2 & 255u] >> ((h2 >> 8) << 4)) & 0xFFFFu) >= thr; }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> 20; reached[q] = ((s_r0[h2 & 255u] >> ((h2 >> 8) << 1)) & (thr >= 2u ? 2u : 1u)) != 0u; }
+    }
     bool full = false;
     uint32_t nkeys = 0;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-        const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> 20;
-        const uint32_t c = (s_r0[h2 & 255u] >> ((h2 >> 8) << 1)) & 3u;                    // 1 = one hit in the slot, 3 = more
         bool fresh = false;
-        if (bp4[q] != 0u && (c & (thr >= 2u ? 2u : 1u))) {
+        if (bp4[q] != 0u && reached[q]) {
             uint32_t t;
             if constexpr (LQ == 0) t = tg[q]; else t = s_lt[64u * q + (uint32_t)lane];
             const uint32_t bp = bp4[q];
@@ -1941,7 +1964,8 @@ __global__ void __launch_bounds__(64, 8) k_vote_tiny(GmDevIndex ix, GmDevParams 
     if (Q <= 16u) {
         // four load steps: the hits stay where they were loaded (no list: with the two-bit filter few hits reach the table, and
         // the 3 - 4 dense chunks the list buys cost more than the fourth sparse step; measured 16.6 -> 16.45 ms)
-        gm_vote_tiny_body<MASK64, FULL, SEED, 4, 0>(ix, p, b, rs, lane, E, s_r0v, s_lbp, s_lt, s_desc, s_cnt0);
+        if (E <= 64u) gm_vote_tiny_body<MASK64, FULL, SEED, 4, 1>(ix, p, b, rs, lane, E, s_r0v, s_lbp, s_lt, s_desc, s_cnt0);      // one dense chunk
+        else gm_vote_tiny_body<MASK64, FULL, SEED, 4, 0>(ix, p, b, rs, lane, E, s_r0v, s_lbp, s_lt, s_desc, s_cnt0);
     } else {
         if (E <= 192u) gm_vote_tiny_body<MASK64, FULL, SEED, 8, 3>(ix, p, b, rs, lane, E, s_r0v, s_lbp, s_lt, s_desc, s_cnt0);
         else gm_vote_tiny_body<MASK64, FULL, SEED, 8, 4>(ix, p, b, rs, lane, E, s_r0v, s_lbp, s_lt, s_desc, s_cnt0);
@@ -2979,10 +3003,10 @@ int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, in
         if (slots_form) {                           // default: wave-uniform seed slots + the list kernel for what it hands over
             const int slot_form = dense == 2 ? 64 : slots_hint == 0 ? 0 : slots_hint < 0 ? -1 : slots_hint <= 14 ? 16 : slots_hint <= 22 ? 24 : GMS_SMAX;      // 0 = k_vote_tiny, -1 = k_vote_tiny2
             const uint32_t lgrid = (uint32_t)std::min<uint64_t>(cdiv(2ull * b.n, 4), 256 * 20);
-#define GM_LAUNCH_VSL1(M, F, S) hipLaunchKernelGGL((k_vote_slots<M, F, S>), dim3(2 * b.n), dim3(128), 0, S_(stream), ix, p, b)
+#define GM_LAUNCH_VSL1(M, F, S) do { if (F && p.fused) hipLaunchKernelGGL((k_vote_slots<M, true, S, true>), dim3(2 * b.n), dim3(128), 0, S_(stream), ix, p, b); \
+                                     else hipLaunchKernelGGL((k_vote_slots<M, F, S, false>), dim3(2 * b.n), dim3(128), 0, S_(stream), ix, p, b); } while (0)
 #define GM_LAUNCH_VSL(M, F) do { if (slot_form == 0 && F && p.fused) hipLaunchKernelGGL((k_vote_tiny<M, true, true>), dim3(2 * b.n), dim3(64), 0, S_(stream), ix, p, b); \
                                  else if (slot_form == -1 && F && p.fused) hipLaunchKernelGGL((k_vote_tiny2<M, true, true>), dim3(2 * b.n), dim3(64), 0, S_(stream), ix, p, b); \
-                                 else if (p.fused) { return (int)hipErrorInvalidValue; } \
                                  else if (slot_form == 0) hipLaunchKernelGGL((k_vote_tiny<M, F, false>), dim3(2 * b.n), dim3(64), 0, S_(stream), ix, p, b); \
                                  else if (slot_form == -1) hipLaunchKernelGGL((k_vote_tiny2<M, F, false>), dim3(2 * b.n), dim3(64), 0, S_(stream), ix, p, b); \
                                  else if (slot_form == 64) GM_LAUNCH_VSL1(M, F, 64); else if (slot_form == 16) GM_LAUNCH_VSL1(M, F, 16); \

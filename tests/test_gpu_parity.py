@@ -479,12 +479,19 @@ _VARIANT_ORACLE = {}
                                  dict(GM_NW_ROWS="0"),
                                  dict(GM_HEAVY_MIN="64"), dict(GM_HEAVY_MIN="8", GM_HEAVY_BUDGET="200000"),      # sorted-key path for read x strands with many SA hits (several chunks)
                                  dict(GM_HEAVY_MIN="64", GM_TEST_SAMPLED="1"),
-                                 # the one-wave kernels look their seeds up themselves on the full SA (fused form, the default): the two-kernel form,
-                                 # a table without its compact form, 14- / 16-mers with a table that long, hand-over to the heavy path
+                                 # the one-wave kernels look their seeds up themselves on the full SA (fused form: chosen when every k-mer is expected
+                                 # >= 8 times in the reference, forced here with GM_SEED_FUSED=1 - on this small reference most reads then take the
+                                 # serial walk of the irregular cases, which is the point): the two-kernel form, a table without its compact form
+                                 # (falls back to k_seed), 14- / 16-mers with a table that long, hand-over to the heavy path
                                  dict(GM_VOTE="block", GM_VOTE_SLOTS="0", GM_SEED_FUSED="0"), dict(GM_VOTE="block", GM_VOTE_SLOTS="-1", GM_SEED_FUSED="0"),
-                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="0", GM_KMER_COMPACT="0"), dict(GM_VOTE="block", GM_VOTE_SLOTS="0", GM_KMER_TABLE="16"),
-                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="-1", GM_KMER_TABLE="14"),
-                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="0", GM_HEAVY_MIN="64"), dict(GM_VOTE="block", GM_VOTE_SLOTS="-1", GM_HEAVY_MIN="8", GM_HEAVY_BUDGET="200000")],
+                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="0", GM_SEED_FUSED="1"), dict(GM_VOTE="block", GM_VOTE_SLOTS="-1", GM_SEED_FUSED="1"),
+                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="0", GM_SEED_FUSED="1", GM_KMER_COMPACT="0"), dict(GM_VOTE="block", GM_VOTE_SLOTS="0", GM_SEED_FUSED="1", GM_KMER_TABLE="16"),
+                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="-1", GM_SEED_FUSED="1", GM_KMER_TABLE="14"),
+                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="0", GM_SEED_FUSED="1", GM_HEAVY_MIN="64"),
+                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="-1", GM_SEED_FUSED="1", GM_HEAVY_MIN="8", GM_HEAVY_BUDGET="200000"),
+                                 # the same inside k_vote_slots (wave 0 of the workgroup looks the seeds up): every slot form, hand-over to the list / heavy kernels
+                                 dict(GM_VOTE="block", GM_SEED_FUSED="1"), dict(GM_VOTE="big", GM_SEED_FUSED="1"), dict(GM_VOTE="block", GM_VOTE_SLOTS="10", GM_SEED_FUSED="1"),
+                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="20", GM_SEED_FUSED="1"), dict(GM_VOTE="block", GM_SEED_FUSED="1", GM_HEAVY_MIN="64")],
                          ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()))
 @pytest.mark.parametrize("cfg", ["default", "no_nw", "k3", "h30", "m6_j2", "m20_j2", "k1"])
 def test_every_kernel_variant_matches_oracle(env, cfg, syn_fa, oracle, oix, syn_reads, packed, tmp_path):
@@ -529,13 +536,13 @@ np.savez({out!r}, **{{k: v for k, v in res.items() if not k.startswith('_')}}, *
 
 
 @pytest.mark.parametrize("cfg", ["default", "h30", "m6_j2", "k1", "no_nw"])
-@pytest.mark.parametrize("slots", ["0", "-1"])
+@pytest.mark.parametrize("slots", ["0", "-1", "40"])
 def test_fused_seed_lookup_counts_the_same_work(cfg, slots, syn_fa, oracle, oix, syn_reads, tmp_path):
-    """seed lookup inside k_vote_tiny / k_vote_tiny2 (lane j takes the k-mer at j * jump; a failed or capped k-mer or an N sends the
+    """seed lookup inside k_vote_tiny / k_vote_tiny2 / k_vote_slots (lane j takes the k-mer at j * jump; a failed or capped k-mer or an N sends the
     read x strand through the serial walk) against the k_seed form: same results (both compared with the oracle) and the same work
     counters - k-mers searched, table probes, seeds, SA hits, candidates, DP cells"""
     env = dict(GM_VOTE="block", GM_VOTE_SLOTS=slots, GM_KMER_TABLE="14")
-    fused = _run_variant(env, cfg, syn_fa, oracle, oix, syn_reads, tmp_path)
+    fused = _run_variant(dict(env, GM_SEED_FUSED="1"), cfg, syn_fa, oracle, oix, syn_reads, tmp_path)
     plain = _run_variant(dict(env, GM_SEED_FUSED="0"), cfg, syn_fa, oracle, oix, syn_reads, tmp_path)
     assert fused == plain, (fused, plain)
     assert fused["seeds_used"] > 5000 and fused["kmers_searched"] >= fused["seeds_used"]
