@@ -2,10 +2,13 @@
 //
 // Kernels, in pipeline order (reference file:line each one stands for):
 //   k_expand_full_sa   once per index: rank-sampled SA -> full 32-bit SA by LF walks     (bwt_sa/bwt_invPsi src/bwt.c:53-96)
-//   k_prep             read self score, -a threshold, status                             (set_top_matches src/Driver.cpp:446-503,
+//   k_prep             read self score, -a threshold, status; 2-bit forms of the read for the fused seed lookup
+//                                                                                        (set_top_matches src/Driver.cpp:446-503,
 //                                                                                         get_align_score_mid src/bin_seq.cpp:860-893)
 //   k_seed             adaptive k-mer walk + backward search, one lane per read x strand (align_sequence inc/align_seq2_raw.cpp:192-243,
 //                                                                                         bwt_match_exact/bwt_2occ/bwt_occ src/bwt.c:107-239)
+//                      - or, GmDevParams::fused, the same walk INSIDE k_vote_slots / k_vote_tiny / k_vote_tiny2 (gm_tiny_seeds<true>:
+//                      lane j takes the k-mer at j * jump; the serial walk gm_seed_walk only for the read x strands where that fails)
 //   k_locate_sampled   faithful locate: LF walk to the next sampled rank                  (bwt_sa src/bwt.c:86-96)
 //   k_vote_*           locate + vote: k_vote_slots (dense seeds, 2 waves per read x strand), k_vote_tiny / _tiny2 (one wave, few hits in
 //                      short runs), k_vote_sparse + k_vote_fast_list, k_vote, k_vote_block, k_vote_retry (exact table in HBM);

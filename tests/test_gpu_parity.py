@@ -497,6 +497,13 @@ _VARIANT_ORACLE = {}
 def test_every_kernel_variant_matches_oracle(env, cfg, syn_fa, oracle, oix, syn_reads, packed, tmp_path):
     """the dispatch heuristics pick kernels by seed density; force each variant on the same inputs and compare the result of
     gm_map_batch (status, self / top score, denominator, matches in key order, position sets) with the ORACLE, read by read"""
+    # the whole grid is 50 x 7 processes; the non-default forms run on the configurations that reach their special cases
+    if "GM_SEED_FUSED" in env and cfg in ("no_nw", "k3", "m20_j2"):
+        pytest.skip("fused seed lookup: covered by default / h30 / m6_j2 / k1 (m20_j2 is never fused: the table is shorter than the seed)")
+    if env.get("GM_VOTE_KERNEL") == "block" and cfg in ("no_nw", "h30", "k1", "m20_j2"):
+        pytest.skip("block form of the dense kernel (not the default): default / k3 / m6_j2")
+    if env.get("GM_KMER_TABLE") in ("13", "15") and cfg in ("no_nw", "k3", "h30"):
+        pytest.skip("odd table lengths matter for the long seeds")
     _run_variant(env, cfg, syn_fa, oracle, oix, syn_reads, tmp_path)
 
 
@@ -535,7 +542,7 @@ np.savez({out!r}, **{{k: v for k, v in res.items() if not k.startswith('_')}}, *
     return {k[4:]: int(v) for k, v in res.items() if k.startswith("ctr_")}
 
 
-@pytest.mark.parametrize("cfg", ["default", "h30", "m6_j2", "k1", "no_nw"])
+@pytest.mark.parametrize("cfg", ["default", "h30", "m6_j2"])
 @pytest.mark.parametrize("slots", ["0", "-1", "40"])
 def test_fused_seed_lookup_counts_the_same_work(cfg, slots, syn_fa, oracle, oix, syn_reads, tmp_path):
     """seed lookup inside k_vote_tiny / k_vote_tiny2 / k_vote_slots (lane j takes the k-mer at j * jump; a failed or capped k-mer or an N sends the
