@@ -731,11 +731,13 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
     // seed): no k_seed launch, no seed rows through HBM.  It pays while a k-mer that changes the walk (one that does not occur, or
     // exceeds -h) is rare - such a read x strand is walked by ONE lane: every k-mer must be expected >= 8 times in the reference
     // (absent with probability e^-8; measured on 100 Mbp: -m 12, 6 per k-mer, 4 % of the waves on the serial walk: 29.0 against 26.5 ms;
-    // -m 14, 0.4 per k-mer: 398 against 29.5 ms) and -h, if set, must sit well above that.  GM_SEED_FUSED=0 / 1: never / whenever possible.
+    // -m 14, 0.4 per k-mer: 398 against 29.5 ms) and no -h cap (below).  GM_SEED_FUSED=0 / 1: never / whenever possible.
     {
         static const int fused_env = [] { const char* e = getenv("GM_SEED_FUSED"); return e ? atoi(e) : -1; }();
         const double occ = (double)ix->h.seq_len / pow(4.0, (double)std::min(p->mer, 31));
-        const bool pays = occ >= 8.0 && (p->max_kmer_hits == 0 || (double)p->max_kmer_hits >= occ + 6.0 * sqrt(occ) + 8.0);
+        // -h: on a real reference the k-mers of repeats exceed any cap, and each of them makes the walk slide base by base (:213-217) in
+        // one lane - not measurable on the synthetic references of bench.py, so a capped run keeps k_seed unless forced
+        const bool pays = occ >= 8.0 && p->max_kmer_hits == 0;
         dp.fused = (fused_env < 0 ? pays : fused_env != 0) && use_full && (dense == 1 || dense == 2) && !getenv("GM_VOTE_KERNEL") && b->max_seeds <= 64 && dp.kmer_tab &&
                    dp.kmer_ctab && dp.kmer_T == p->mer && p->mer <= 16 && p->jump >= 1 && !(dp.dbg & 128);
         b->use_pack = dp.fused != 0;

@@ -1323,6 +1323,65 @@ __device__ __attribute__((noinline)) uint32_t gm_seed_walk_ool(const GmKArgs* a,
     }
     return (uint32_t)nseed;
 }
+// The walk of a read x strand whose regular positions do not all succeed, by the WHOLE wave (all 64 lanes call it): round after
+// round, lane j probes the k-mer at pos0 + j * jump; the seeds before the first k-mer that changes the walk are final, the walk
+// resumes behind it exactly as gm_seed_walk does (a k-mer whose last d characters do not occur: i += mer - d + 1; one above -h:
+// i += 1).  One probe round trip per failing k-mer instead of one per k-mer.  Reads with a non-ACGT base are not handled here
+// (the 2-bit forms do not say where it is): they take gm_seed_walk_ool.  out: LDS, max_seeds seeds.  Returns the number of seeds.
+__device__ __attribute__((noinline)) uint32_t gm_seed_rewalk_ool(const GmKArgs* a, const uint32_t rs, const int lane, GmSeed* out) {
+    const GmDevParams& p = a->p;
+    const GmDevBatch& b = a->b;
+    const uint32_t m = (uint32_t)p.mer, jump = (uint32_t)p.jump, w2 = b.pack_w2;
+    const uint32_t* const row = b.pack + (size_t)(rs >> 1) * b.pack_words;
+    const uint32_t* const form = row + ((rs & 1u) ? w2 + 2u : 1u);
+    const uint32_t L = row[0] & 0xFFFFu, last = L - m;
+    const uint32_t cmask = m >= 16u ? 0xFFFFFFFFu : ((1u << (2u * m)) - 1u);
+    uint32_t pos0 = 0, nseed = 0;
+    unsigned long long extra = 0;                    // k-mers searched beyond one per seed
+    while (pos0 < last) {
+        const uint32_t i = pos0 + (uint32_t)lane * jump;
+        const bool act = i < last;
+        uint32_t k = 0, cnt = 0, t = 0;
+        bool fail = false, capped = false;
+        if (act) {
+            const uint32_t o = 2u * (16u * w2 - i - m);
+            const uint32_t code = (uint32_t)((((unsigned long long)form[(o >> 5) + 1u] << 32) | form[o >> 5]) >> (o & 31u)) & cmask;
+            bool answered = false;
+            if (p.kmer_ctab) {                       // the table probe of gm_seed_walk
+                const uint4 rec = p.kmer_ctab[code >> 3];
+                const uint32_t sub = code & 7u;
+                const unsigned long long cw = (unsigned long long)rec.y | ((unsigned long long)rec.z << 32);
+                cnt = (uint32_t)(cw >> (8 * sub)) & 255u;
+                if (rec.w == 0u && cnt >= 224u) { fail = true; t = m - (cnt - 223u); answered = true; }
+                else if (rec.w == 0u) {
+                    unsigned long long below = sub ? (cw & (~0ull >> (64 - 8 * sub))) : 0ull;
+                    const unsigned long long emp = below & (below << 1) & (below << 2) & 0x8080808080808080ull;
+                    below &= ~((emp >> 7) * 0xFFull);
+                    const unsigned long long s2 = (below & 0x00FF00FF00FF00FFull) + ((below >> 8) & 0x00FF00FF00FF00FFull);
+                    k = rec.x + (uint32_t)((s2 * 0x0001000100010001ull) >> 48);
+                    answered = true;
+                }
+            }
+            if (!answered) {
+                const uint2 iv = p.kmer_tab[code];
+                if (iv.x == 0xFFFFFFFFu) { fail = true; t = m - iv.y; }
+                else { k = iv.x; cnt = iv.y - iv.x + 1u; }
+            }
+            if (!fail && p.hcap > 0 && cnt > p.hcap) { fail = true; capped = true; }
+        }
+        const unsigned long long fm = __builtin_amdgcn_ballot_w64(fail);
+        const uint32_t nact = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(act));
+        const uint32_t f = fm ? (uint32_t)(__ffsll((long long)fm) - 1) : nact;            // lanes before f hold final seeds
+        if ((uint32_t)lane < f && nseed + (uint32_t)lane < b.max_seeds) { GmSeed sd; sd.k = k; sd.l = k + cnt - 1u; sd.pos = i; out[nseed + (uint32_t)lane] = sd; }
+        nseed += f;
+        if (!fm) break;
+        ++extra;
+        const uint32_t t_f = (uint32_t)__builtin_amdgcn_readlane((int)t, (int)f), cap_f = (uint32_t)__builtin_amdgcn_readlane((int)(capped ? 1u : 0u), (int)f);
+        pos0 = pos0 + f * jump + (cap_f ? 1u : t_f + 1u);
+    }
+    if (lane == 0 && extra) { atomicAdd(&b.counters[GMK_KMERS], extra); atomicAdd(&b.counters[GMK_TAB_LOOKUPS], extra); }
+    return nseed < b.max_seeds ? nseed : b.max_seeds;
+}
 __device__ __forceinline__ const GmKArgs* gm_kargs() {
 #if defined(__HIP_DEVICE_COMPILE__)
     return (const GmKArgs*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1393,9 +1452,10 @@ __device__ __forceinline__ bool gm_tiny_seeds(const GmDevIndex& ix, const GmDevP
         if (__builtin_amdgcn_ballot_w64(bad) == 0ull) {
             ns = nreg;
             if (act) { sd.k = k; sd.l = k + cnt - 1u; sd.pos = i; }
-        } else {                                                                          // rare: the serial walk, by lane 0
+        } else {                                                                          // rare: the wave walks again round by round; a non-ACGT base: the serial walk, by lane 0
             uint32_t nseed = 0;
-            if (lane == 0) nseed = gm_seed_walk_ool(gm_kargs(), rs, scratch, 1);
+            if ((hdr >> 16) & 1u) { if (lane == 0) nseed = gm_seed_walk_ool(gm_kargs(), rs, scratch, 1); }
+            else nseed = gm_seed_rewalk_ool(gm_kargs(), rs, lane, scratch);
             // ONE wave runs this function (a one-wave workgroup, or wave 0 of k_vote_slots): the callee's stores to LDS have to
             // be complete before the wave's other lanes read them, no workgroup barrier
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
