@@ -727,17 +727,19 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
     static const uint32_t heavy_min = [] { const char* e = getenv("GM_HEAVY_MIN"); return e ? (uint32_t)atoll(e) : 16384u; }();
     static const uint64_t heavy_budget = [] { const char* e = getenv("GM_HEAVY_BUDGET"); return e ? (uint64_t)atoll(e) : (uint64_t)1 << 27; }();
     dp.heavy_min = heavy_min;
-    // seed lookup inside the one-wave vote kernels (k_vote_tiny / k_vote_tiny2 on the full SA, the k-mer table covering the whole
-    // seed): no k_seed launch, no seed rows through HBM.  It pays while a k-mer that changes the walk (one that does not occur, or
-    // exceeds -h) is rare - such a read x strand is walked by ONE lane: every k-mer must be expected >= 8 times in the reference
-    // (absent with probability e^-8; measured on 100 Mbp: -m 12, 6 per k-mer, 4 % of the waves on the serial walk: 29.0 against 26.5 ms;
-    // -m 14, 0.4 per k-mer: 398 against 29.5 ms) and no -h cap (below).  GM_SEED_FUSED=0 / 1: never / whenever possible.
+    // seed lookup inside the vote kernels that take one read x strand per wave / workgroup (full SA, the k-mer table covering the
+    // whole seed): no k_seed launch, no seed rows through HBM.  A k-mer that does not occur changes the positions of all later ones;
+    // the wave then walks again round by round (gm_seed_rewalk_ool), one probe round trip per failing k-mer.  That stays rare while
+    // even a k-mer with a sequencing error still occurs somewhere by chance - every k-mer expected >= 4 times in the reference
+    // (measured on 100 Mbp: -m 12, 6 per k-mer: 21.0 ms fused against 27.7; -m 14, 0.4 per k-mer: an erroneous k-mer dies one or two
+    // characters before its end, the walk creeps past the error in ~9 rounds, 207 against 29.5 ms - k_seed amortises those serial
+    // steps over 64 lanes).  GM_SEED_FUSED=0 / 1: never / whenever possible.
     {
         static const int fused_env = [] { const char* e = getenv("GM_SEED_FUSED"); return e ? atoi(e) : -1; }();
         const double occ = (double)ix->h.seq_len / pow(4.0, (double)std::min(p->mer, 31));
         // -h: on a real reference the k-mers of repeats exceed any cap, and each of them makes the walk slide base by base (:213-217) in
         // one lane - not measurable on the synthetic references of bench.py, so a capped run keeps k_seed unless forced
-        const bool pays = occ >= 8.0 && p->max_kmer_hits == 0;
+        const bool pays = occ >= 4.0 && p->max_kmer_hits == 0;
         dp.fused = (fused_env < 0 ? pays : fused_env != 0) && use_full && (dense == 1 || dense == 2) && !getenv("GM_VOTE_KERNEL") && b->max_seeds <= 64 && dp.kmer_tab &&
                    dp.kmer_ctab && dp.kmer_T == p->mer && p->mer <= 16 && p->jump >= 1 && !(dp.dbg & 128);
         b->use_pack = dp.fused != 0;
