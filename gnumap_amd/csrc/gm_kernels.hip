@@ -1655,7 +1655,7 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
     // loaded with all of them makes every wave step wait for its unluckiest lane (tens of dependent CAS round trips).  So
     // the list goes through a second counting filter first (other hash, 16-bit counters: at most LCAP entries, no
     // wrap), and only entries whose second slot also reached kmin enter the exact table, which then stays nearly empty.
-    // Both live in the zeroed filter memory: words [0,1024) = 2048 x 16-bit counters, words [1024,2048) = 256 slots of
+    // Both live in the zeroed filter memory: words [0,1024) = the second filter (16 384 slots of two bits), words [1024,2048) = 256 slots of
     // key | votes | low step mask | high step mask (key 0 = empty; b = 0 never gets here).
     constexpr int T2 = 256;
     constexpr uint32_t F2W = BIG ? 2047u : 1023u;     // second filter: words of two 16-bit counters
@@ -1674,8 +1674,11 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (bp4[q] != 0u) {
-                const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> (BIG ? 20 : 21);
-                atomicAdd(&s_r0[h2 & F2W], 1u << ((h2 >> F2S) << 4));
+                // two bits per slot, seen / seen again (as in k_vote_tiny): 16 384 (BIG: 32 768) slots in the words that held 2048
+                // (4096) 16-bit counters - 8 x fewer entries reach the CAS loop of the table by sharing a slot
+                const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> (BIG ? 17 : 18), sh = (h2 >> F2S) << 1;
+                const uint32_t old = atomicOr(&s_r0[h2 & F2W], 1u << sh);
+                if ((old >> sh) & 1u) atomicOr(&s_r0[h2 & F2W], 2u << sh);
             }
     }
     __syncthreads();
@@ -1692,13 +1695,13 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> (BIG ? 20 : 21);
-                c4[q] = (s_r0[h2 & F2W] >> ((h2 >> F2S) << 4)) & 0xFFFFu;
+                const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> (BIG ? 17 : 18);
+                c4[q] = (s_r0[h2 & F2W] >> ((h2 >> F2S) << 1)) & (thr >= 2u ? 2u : 1u);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 bool fresh = false;
-                if (bp4[q] != 0u && c4[q] >= thr) {
+                if (bp4[q] != 0u && c4[q] != 0u) {
                     const uint32_t i = i0 + 64u * q + (uint32_t)lane;
                     const uint32_t bp = bp4[q], t = (s_desc[s_lt[wave ? LCAP - 1 - i : i]].y >> 16) & 63u;
                     uint32_t slot = (bp * 0x9E3779B1u) >> 24;
