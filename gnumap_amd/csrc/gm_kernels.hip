@@ -1653,12 +1653,12 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
     }
     // ---- pass 2b: the list is mostly single positions that shared a filter slot with another one; a linear-probing table
     // loaded with all of them makes every wave step wait for its unluckiest lane (tens of dependent CAS round trips).  So
-    // the list goes through a second counting filter first (other hash, 16-bit counters: at most LCAP entries, no
-    // wrap), and only entries whose second slot also reached kmin enter the exact table, which then stays nearly empty.
+    // the list goes through a second filter first (other hash, two bits per slot: seen / seen again), and only entries whose
+    // second slot was hit again enter the exact table, which then stays nearly empty.
     // Both live in the zeroed filter memory: words [0,1024) = the second filter (16 384 slots of two bits), words [1024,2048) = 256 slots of
     // key | votes | low step mask | high step mask (key 0 = empty; b = 0 never gets here).
     constexpr int T2 = 256;
-    constexpr uint32_t F2W = BIG ? 2047u : 1023u;     // second filter: words of two 16-bit counters
+    constexpr uint32_t F2W = BIG ? 2047u : 1023u;     // second filter: words of sixteen 2-bit slots
     constexpr int F2S = BIG ? 11 : 10;
     uint32_t* const keys = BIG ? s_tab : s_r0 + 1024; uint32_t* const vals = keys + T2; uint32_t* const mlo = keys + 2 * T2; uint32_t* const mhi = keys + 3 * T2;
     const bool lfull = s_lcnt[0] + s_lcnt[1] > (uint32_t)LCAP;       // block-uniform

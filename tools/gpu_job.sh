@@ -1,5 +1,11 @@
 set -e
-timeout -k 10 700 python -m pytest tests/test_gpu_parity.py -x -q -k "every_kernel_variant and VOTE and not VOTE_SLOTS and not VOTE_KERNEL and not wave" > gpurun_out/slots2_tests.log 2>&1 || { tail -30 gpurun_out/slots2_tests.log; exit 1; }
-tail -2 gpurun_out/slots2_tests.log
-python3 tools/env_sweep.py --genome-mbp 100 --contigs 6 --mer 10 --sets "" "" 2>&1 | grep sweep | sed 's/^/[100 m10] /'
-python3 tools/env_sweep.py --genome-mbp 156 --contigs 1 --mer 10 --sets "" 2>&1 | grep sweep | sed 's/^/[156 m10] /'
+MATRIX=0 bash tools/collect_profiles.sh r02f > gpurun_out/collect_r02f.log 2>&1 || { tail -20 gpurun_out/collect_r02f.log; exit 1; }
+tail -2 gpurun_out/collect_r02f.log
+: > gpurun_out/matrix_rows_r02f.jsonl
+for args in "--genome-mbp 100 --contigs 6 --mer 10" "--genome-mbp 100 --contigs 6 --mer 10 --no-nw" "--genome-mbp 100 --contigs 6 --mer 12" "--genome-mbp 156 --contigs 1 --mer 10" "--genome-mbp 156 --contigs 1 --mer 10 --max-kmer-hits 150"; do
+  python3 bench.py $args --cpu-seconds 5 --abi-reads 2097152 >> gpurun_out/matrix_rows_r02f.jsonl 2>> gpurun_out/matrix_rows_r02f.log
+done
+python3 -c "
+import json
+for l in open('gpurun_out/matrix_rows_r02f.jsonl'):
+    j=json.loads(l); print(round(j['value']/1e6,1), j['ms_per_step'], j['seed_lookup'])"
