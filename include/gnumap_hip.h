@@ -154,7 +154,9 @@ typedef struct {
         table_lookups;
 } gm_counters;
 
-/* kernels of gm_map_batch_device, for the HIP-event timing of gm_batch_kernel_times */
+/* kernels of gm_map_batch_device, for the HIP-event timing of gm_batch_kernel_times.  GM_K_SEED has no launches when the seed
+ * lookup runs inside the vote kernel (full SA, k-mer table as long as the seed, k-mers expected >= 4 times in the reference, no -h;
+ * env GM_SEED_FUSED=0|1 overrides): its time is then part of GM_K_VOTE; the work counters are the same either way */
 enum { GM_K_PREP = 0, GM_K_SEED, GM_K_LOCATE, GM_K_VOTE, GM_K_VOTE_RETRY, GM_K_NW, GM_K_COMPACT, GM_K_COUNT };
 
 const char* gm_last_error(void);
