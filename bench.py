@@ -50,9 +50,29 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def make_genome(path, mbp, seed, n_contigs):
-    """i.i.d. uniform ACGT, split into contigs, FASTA with 100-column lines (deterministic), written in slabs"""
+REPEAT_FAMILIES, REPEAT_LEN, REPEAT_FRACTION, REPEAT_DIVERGENCE = 1000, 300, 0.10, 0.05
+
+
+def overlay_repeats(seq, rng, cons):
+    """SURVEY.md 8(d) "repeat-rich" variant: 10 % of the bases come from 1 000 families of 300-bp elements, every copy with 5 %
+    of its bases substituted.  `seq` holds codes 0..3 and is edited in place."""
+    m = len(seq)
+    k = int(REPEAT_FRACTION * m / REPEAT_LEN)
+    if k == 0 or m <= REPEAT_LEN:
+        return
+    at = rng.integers(0, m - REPEAT_LEN, k)
+    copies = cons[rng.integers(0, REPEAT_FAMILIES, k)]
+    mut = rng.random(copies.shape) < REPEAT_DIVERGENCE
+    copies = np.where(mut, (copies + rng.integers(1, 4, copies.shape, dtype=np.uint8)) & 3, copies).astype(np.uint8)
+    seq[(at[:, None] + np.arange(REPEAT_LEN)[None, :]).reshape(-1)] = copies.reshape(-1)
+
+
+def make_genome(path, mbp, seed, n_contigs, repeats=False):
+    """i.i.d. uniform ACGT (optionally with the repeat overlay), split into contigs, FASTA with 100-column lines (deterministic),
+    written in slabs"""
     rng = np.random.default_rng(seed)
+    rrng = np.random.default_rng(seed + 1000)
+    cons = rrng.integers(0, 4, (REPEAT_FAMILIES, REPEAT_LEN), dtype=np.uint8)
     G = int(mbp * 1_000_000)
     sizes = [G // n_contigs] * n_contigs
     sizes[-1] += G - sum(sizes)
@@ -63,7 +83,11 @@ def make_genome(path, mbp, seed, n_contigs):
             done = 0
             while done < n:
                 m = min(n - done, 200_000_000)
-                seq = acgt[rng.integers(0, 4, m, dtype=np.uint8)]
+                codes = rng.integers(0, 4, m, dtype=np.uint8)
+                if repeats:
+                    overlay_repeats(codes, rrng, cons)
+                seq = acgt[codes]
+                del codes
                 rows = m // 100
                 block = np.empty((rows, 101), np.uint8)
                 block[:, :100] = seq[:rows * 100].reshape(rows, 100)
@@ -237,69 +261,52 @@ def abi_rate(g, ix, p, B, Q, Ln, n_reads, block, n_threads, torch):
                 matches=sum(t[0] for t in totals), sam_records=sum(t[1] for t in totals))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genome-mbp", type=float, default=3100.0)
-    ap.add_argument("--contigs", type=int, default=24)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
-    ap.add_argument("--read-len", type=int, default=100)
-    ap.add_argument("--mer", type=int, default=14)
-    ap.add_argument("--jump", type=int, default=0, help="0 = mer / 2 (the reference's default)")
-    ap.add_argument("--max-kmer-hits", type=int, default=0)
-    ap.add_argument("--no-nw", action="store_true")
-    ap.add_argument("--locate", choices=["full", "sampled"], default="full")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline leg (0 = skip)")
-    ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--cpu-kind", choices=["auto", "reference", "port"], default="auto")
-    ap.add_argument("--abi-reads", type=int, default=4_194_304, help="reads of the gm_map_batch + gm_output_batch leg (0 = skip)")
-    ap.add_argument("--abi-block", type=int, default=262144)
-    ap.add_argument("--abi-threads", type=int, default=2)
-    ap.add_argument("--workdir", default=os.environ.get("GM_BENCH_DIR", "/tmp/gnumap_bench"))
-    a = ap.parse_args()
+def parity_sample(g, ix, p, fa, B, Q, Ln, L, kw, n_sample, block):
+    """Outside the timed region: one block of the benchmark reads through gm_map_batch (the same kernels the timed steps ran - the
+    kernel choice does not depend on the number of reads) and `n_sample` of its reads, spread over the block, compared with the
+    oracle read by read: status, denominator, top score, every match's score bits and position set.  The oracle is the checker
+    only (oracle/libgm_oracle.so); None when it did not travel."""
+    try:
+        from reflib import OracleLib
+        orc = OracleLib()
+    except Exception as e:                                    # pragma: no cover
+        log(f"[bench] parity sample skipped: {e}")
+        return None
+    n = min(block, len(B))
+    bt = g.Batch(ix, n, B.shape[1])
+    res = bt.map(p, B[:n], Q[:n], Ln[:n])
+    oix = orc.index_load(fa)
+    op = orc.params(**kw)
+    pick = np.unique(np.linspace(0, n - 1, n_sample).astype(np.int64))
+    mb, M, P = res["match_begin"], res["matches"], res["positions"]
+    bad = 0; n_matches = 0; unmapped = 0
+    for i in pick:
+        seq = B[i, :L].tobytes(); qual = Q[i, :L].tobytes()
+        o = orc.map_read(oix, op, orc.pwm(seq, qual), seq)
+        ms = M[int(mb[i]):int(mb[i + 1])]
+        same = res["status"][i] == o["status"] and res["denominator"][i] == o["denominator"] and res["top_score"][i] == o["top_score"] and len(ms) == len(o["hits"])
+        if same:
+            for m, hh in zip(ms, o["hits"]):
+                same &= bool(np.float32(m["score"]).view(np.uint32) == np.float32(hh["score"]).view(np.uint32))
+                same &= [(int(q["pos"]), int(q["strand"])) for q in P[m["pos_begin"]:m["pos_end"]]] == [(int(x), int(y)) for x, y in hh["pos"]]
+        n_matches += len(o["hits"]); unmapped += len(o["hits"]) == 0
+        bad += not same
+    bt.destroy()
+    return dict(n=int(len(pick)), mismatches=int(bad), oracle_matches=int(n_matches), oracle_unmapped=int(unmapped), block=int(n),
+                checked="status, denominator, top score, match score bits, position sets vs oracle/gm_oracle.c")
 
-    import torch
-    import gnumap_amd as g
-    from gnumap_amd import dist as gd
 
-    rank, world, local = gd.env_rank()
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: libgnumap_hip has no CPU fallback")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+def reference_key(a):
+    return f"g{a.genome_mbp:g}m_c{a.contigs}_s42" + ("r" if a.repeats else "")
 
-    kw = dict(mer=a.mer, jump=a.jump, max_kmer_hits=a.max_kmer_hits, nw=0 if a.no_nw else 1)
-    key = f"g{a.genome_mbp:g}m_c{a.contigs}_s42"
-    wd = os.path.join(a.workdir, key)
-    fa = os.path.join(wd, "genome.fa")
-    ready = fa + ".index_ready"
-    t_setup = time.time()
-    # the reference + index are made once per box by local rank 0 BEFORE the process group exists (no rank waits inside a collective)
-    if local == 0:
-        os.makedirs(wd, exist_ok=True)
-        if not os.path.exists(ready):
-            log(f"[bench] generating {a.genome_mbp:g} Mbp reference and building its index (once; untimed)")
-            make_genome(fa, a.genome_mbp, 42, a.contigs)
-            g.index_build(fa)
-            open(ready, "w").write("ok\n")
-    else:
-        while not os.path.exists(ready):
-            time.sleep(1.0)
-    gd.init("nccl", dev)                                      # RCCL over xGMI when WORLD_SIZE > 1
+
+def run_config(a, g, gd, torch, ix, fa, wd, B, Q, Ln, dev, rank, world, t_setup):
+    """one flag set on the resident reference + reads: timed steps, ABI leg, parity sample, all-reduce, CPU baseline -> the JSON dict"""
     barrier = gd.barrier
-    barrier()
-    flags = g.GM_INDEX_FULL_SA if a.locate == "full" else 0
-    ix = g.Index(fa, device=local, flags=flags)
-    # the packed reference as 2-bit codes for the read generator
-    pac = np.fromfile(fa + ".gnumap.pac", np.uint8)[: ix.info.l_pac // 4 + 1]
-    pac_t = torch.from_numpy(pac).to(dev)
-    codes_t = torch.stack([(pac_t >> 6) & 3, (pac_t >> 4) & 3, (pac_t >> 2) & 3, pac_t & 3], 1).reshape(-1)[: ix.info.l_pac]
-    del pac_t, pac
-    B, Q, Ln = make_reads(codes_t, a.reads, a.read_len, gd.read_seed(1000, rank), dev)
-    del codes_t
-    torch.cuda.empty_cache()
+    for kv in a.opt:
+        g.set_option(*kv.split("=", 1))
+    kw = dict(mer=a.mer, jump=a.jump, max_kmer_hits=a.max_kmer_hits, nw=0 if a.no_nw else 1, mode=a.mode)
+    key = reference_key(a)
     p = g.Params(**kw)
     batch = g.Batch(ix, a.reads, B.shape[1])
     batch.upload(p, B, Q, Ln)                   # reads resident in HBM from here on
@@ -335,35 +342,67 @@ def main():
         abi = abi_rate(g, ix, p, B, Q, Ln, a.abi_reads, a.abi_block, a.abi_threads, torch)
         log(f"[bench] ABI leg: {abi}")
 
+    # self-check at the bench's own size: a sample of the benchmark reads against the oracle (rank 0, outside the timed region)
+    parity = None
+    if a.parity_sample > 0 and rank == 0:
+        parity = parity_sample(g, ix, p, fa, B, Q, Ln, a.read_len, kw, a.parity_sample, a.abi_block)
+        log(f"[bench] parity sample: {parity}")
+        if parity and parity["mismatches"]:
+            raise SystemExit(f"[bench] PARITY FAILURE: {parity}")
+
     # the one collective of the path: RCCL all-reduce of the device-resident coverage track, IN PLACE on the library's HBM buffer
-    # (once per run, outside the per-step loop, like the reference's MPI Allreduce at end of run: src/Driver.cpp:1660-1672).  A known
-    # per-rank deposit pattern goes in first and is checked afterwards.
+    # (once per run, outside the per-step loop, like the reference's MPI Allreduce at end of run: src/Driver.cpp:1660-1672).  Every
+    # rank first deposits the REAL coverage of one block of its own reads (gm_map_batch + gm_output_batch) plus a known pattern
+    # (one common place, one own place); afterwards the pattern is checked bin by bin and the reduced track's total against the
+    # sum of the per-rank totals.
     allreduce = None
     if world > 1 or os.environ.get("GM_FORCE_DIST") == "1":
+        import torch.distributed as tdist
         ix.coverage_reset(p.bin_size)
+        if p.mode:
+            ix.coverage_enable_nuc()
         bins = ix.coverage_bins()
+        nb = min(a.abi_block, len(B))
+        bt = g.Batch(ix, nb, B.shape[1])
+        res = bt.map(p, B[:nb], Q[:nb], Ln[:nb])
+        recs, _ = bt.output(p, res)
+        bt.destroy()
+        bs = p.bin_size
         common, own = 8000, 800000 * (rank + 1)              # every rank deposits at `common`, and alone at `own`
         ix.coverage_add(np.array([common, own], np.uint64), np.array([64, 64], np.uint32), np.array([rank + 1.0, 1.0], np.float32))
-        cov = gd.DeviceTrack(ix.coverage_device_ptr(), bins).tensor(dev)
+        tracks = [("coverage", gd.DeviceTrack(ix.coverage_device_ptr(), bins).tensor(dev))]
+        if p.mode:
+            tracks.append(("per-nucleotide (5 x bins)", gd.DeviceTrack(ix.coverage_nuc_device_ptr(), 5 * bins).tensor(dev)))
+        cov = tracks[0][1]
+        torch.cuda.synchronize()
+        # what the probed bins and the totals must become: the same sums taken over small copies / scalars
+        probe = [common // bs + t for t in range(64 // bs)] + [800000 * (r + 1) // bs + t for r in range(world) for t in range(64 // bs)]
+        probe_t = torch.tensor(probe, dtype=torch.int64, device=dev)
+        want_probe = cov[probe_t].clone()
+        if tdist.is_initialized():
+            tdist.all_reduce(want_probe)
+        own_totals = [float(t.sum(dtype=torch.float64).item()) for _, t in tracks]
+        want_totals = [gd.sum_over_ranks(v, dev) for v in own_totals]
         torch.cuda.synchronize(); barrier()
         ta = time.perf_counter()
-        gd.allreduce_coverage(cov)
+        for _, t in tracks:
+            gd.allreduce_coverage(t)
         torch.cuda.synchronize()
         dt = gd.max_over_ranks(time.perf_counter() - ta, dev)
-        bs = p.bin_size
-        got_common = cov[common // bs: common // bs + 64 // bs].cpu().numpy()
-        want_common = bs * world * (world + 1) / 2.0
-        ok = bool(np.all(got_common == want_common))
-        for r in range(world):
-            o = 800000 * (r + 1)
-            ok = ok and bool(np.all(cov[o // bs: o // bs + 64 // bs].cpu().numpy() == float(bs)))
-        ok = ok and float(cov.sum().item()) == want_common * (64 // bs) + world * 64.0
+        got_totals = [float(t.sum(dtype=torch.float64).item()) for _, t in tracks]
+        ok = all(abs(gt - wt) <= 1e-5 * max(1.0, abs(wt)) for gt, wt in zip(got_totals, want_totals))
+        got_probe = cov[probe_t]
+        ok = ok and bool(torch.allclose(got_probe, want_probe, rtol=1e-5, atol=1e-6))
+        ok = ok and bool((got_probe[: 64 // bs] >= bs * world * (world + 1) / 2.0 - 1e-3).all()) and bool((got_probe[64 // bs:] >= float(bs) - 1e-3).all())
         if not ok:
-            raise SystemExit(f"[bench] rank {rank}: coverage all-reduce gave a wrong track ({got_common[:4]} vs {want_common})")
-        nbytes = bins * 4
+            raise SystemExit(f"[bench] rank {rank}: coverage all-reduce gave a wrong track (totals {got_totals} vs {want_totals}; probe {got_probe[:4].tolist()} vs {want_probe[:4].tolist()})")
+        nbytes = sum(t.numel() for _, t in tracks) * 4
         allreduce = dict(ms=dt * 1e3, bytes=nbytes, algbw_GBps=nbytes / dt / 1e9, busbw_GBps=nbytes / dt / 1e9 * 2 * (world - 1) / max(world, 1),
-                         in_place=True, checked=True)
+                         in_place=True, checked=True, tracks=[n_ for n_, _ in tracks],
+                         deposit=f"gm_map_batch + gm_output_batch of {nb} reads per rank ({len(recs)} SAM records on rank 0) + a known pattern",
+                         reduced_totals=got_totals, sum_of_rank_totals=want_totals)
 
+    out = None
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         value = world * a.reads * a.steps / elapsed
@@ -377,7 +416,7 @@ def main():
                 per_kernel[k] = dict(ms=ms / n, ms_per_step=ms / a.steps, launches=n, alg_bytes=alg.get(k, 0) / lps,
                                      GBps=alg.get(k, 0) / (ms / a.steps * 1e-3) / 1e9)
         dom = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_step"]) if per_kernel else None
-        traffic = None
+        traffic = None; traffic_source = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         wkey = f"{key}_L{a.read_len}_m{a.mer}_{a.locate}"
         if os.path.exists(pmc):
@@ -386,14 +425,18 @@ def main():
                 # PMC passes are separate rocprofv3 runs of this command at 1 M reads per launch (tools/collect_profiles.sh); traffic scales
                 # linearly with the reads of a launch
                 if j.get("workload_key") == wkey and dom in j.get("kernels", {}):
-                    traffic = int(j["kernels"][dom]["hbm_bytes_per_read"] * a.reads / max(1, per_kernel[dom]["launches"] // a.steps))
+                    lps = max(1, per_kernel[dom]["launches"] // a.steps)
+                    traffic = int(j["kernels"][dom]["hbm_bytes_per_read"] * a.reads / lps)
+                    traffic_source = (f"profiles/pmc_latest.json ({j.get('source', 'rocprofv3 --pmc passes')}: {j['kernels'][dom]['hbm_bytes_per_read']:.0f} B per read at "
+                                      f"{j.get('reads_per_launch', '?')} reads per launch) x {a.reads // lps} reads per launch; NOT measured in this run")
             except Exception:
                 traffic = None
         roof = None
         if dom:
             ach = per_kernel[dom]["GBps"]
             roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5),
-                        traffic=traffic, avg_kernel_ms=round(per_kernel[dom]["ms"], 4), alg_bytes_per_launch=int(per_kernel[dom]["alg_bytes"]))
+                        traffic=traffic, traffic_source=traffic_source, avg_kernel_ms=round(per_kernel[dom]["ms"], 4),
+                        alg_bytes_per_launch=int(per_kernel[dom]["alg_bytes"]))
         cpu = None
         if a.cpu_seconds > 0 and world == 1:         # rank 0 at N = 1 only
             threads = a.cpu_threads or min(16, os.cpu_count() or 1)
@@ -410,17 +453,20 @@ def main():
             shape = "configs[1]"
         else:
             shape = "non-default workload"
+        ref_kind = ("repeat-rich synthetic (10 % of the bases from 1000 families of 300-bp elements, 5 % divergence)" if a.repeats else "synthetic i.i.d.")
         out = {
             "metric": "reads/sec (100 bp, -a 0.9) vs human ref at 1/2/4/8 MI355X; HBM GB/s vs peak",
             "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 ranks + f32 scores", "data": "synthetic",
-            "config": {"workload": f"{shape}: synthetic {a.genome_mbp:g} Mbp reference ({a.contigs} contigs, seed 42) + {a.reads} x {a.read_len} bp reads per GPU, "
+            "config": {"workload": f"{shape}: {ref_kind} {a.genome_mbp:g} Mbp reference ({a.contigs} contigs, seed 42) + {a.reads} x {a.read_len} bp reads per GPU, "
                                    f"-a 0.9 -m {p.mer} -j {p.jump} -k {p.min_seed_hits} -h {p.max_kmer_hits}, {'--no_nw' if a.no_nw else 'NormalScoredSeq NW'}, locate={a.locate}-SA",
-                       "reads_per_gpu": a.reads, "read_len": a.read_len, "genome_mbp": a.genome_mbp, "sharding": f"reads x{world} (no data-path collective)"},
+                       "reads_per_gpu": a.reads, "read_len": a.read_len, "genome_mbp": a.genome_mbp, "repeat_rich": bool(a.repeats),
+                       "sharding": f"reads x{world} (no data-path collective)"},
             "roofline": roof,
             "seed_lookup": "fused into the vote kernel" if fused else "k_seed",
             "cpu_baseline": cpu,
+            "parity_sample": parity,
             "abi_reads_per_s": round(abi["reads_per_s"], 1) if abi else None,
             "abi": abi,
             "kernels": {k: {"ms_per_step": round(v["ms_per_step"], 4), "launches_per_step": v["launches"] // a.steps, "alg_GBps": round(v["GBps"], 2)} for k, v in per_kernel.items()},
@@ -428,7 +474,111 @@ def main():
             "coverage_allreduce": allreduce,
             "pcie_inclusive_reads_per_s": round(pcie_inclusive, 1),
         }
+    batch.destroy()
+    for kv in a.opt:
+        g.set_option(kv.split("=", 1)[0], None)
+    if out is not None and a.opt:
+        out["config"]["options"] = list(a.opt)
+    return out
+
+
+def build_parser():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-mbp", type=float, default=3100.0)
+    ap.add_argument("--contigs", type=int, default=24)
+    ap.add_argument("--repeats", action="store_true", help="repeat-rich reference (SURVEY.md 8d): 10 %% of the bases from 1000 families of 300-bp elements, 5 %% divergence")
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
+    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--mer", type=int, default=14)
+    ap.add_argument("--jump", type=int, default=0, help="0 = mer / 2 (the reference's default)")
+    ap.add_argument("--max-kmer-hits", type=int, default=0)
+    ap.add_argument("--no-nw", action="store_true")
+    ap.add_argument("--mode", type=int, default=0, help="0 normal, 1 -b (bisulfite: bin size 1 and the 5 per-nucleotide tracks, all-reduced too), 2 --b2, 3 -d")
+    ap.add_argument("--locate", choices=["full", "sampled"], default="full")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--cpu-kind", choices=["auto", "reference", "port"], default="auto")
+    ap.add_argument("--abi-reads", type=int, default=4_194_304, help="reads of the gm_map_batch + gm_output_batch leg (0 = skip)")
+    ap.add_argument("--abi-block", type=int, default=262144)
+    ap.add_argument("--abi-threads", type=int, default=2)
+    ap.add_argument("--parity-sample", type=int, default=64, help="reads of the benchmark compared with the oracle outside the timed region (0 = skip)")
+    ap.add_argument("--workdir", default=os.environ.get("GM_BENCH_DIR", "/tmp/gnumap_bench"))
+    ap.add_argument("--opt", action="append", default=[], metavar="GM_X=V", help="library run-time switch for this flag set (gm_set_option), e.g. --opt GM_SEED_FUSED=0")
+    ap.add_argument("--also", action="append", default=[], metavar="FLAGS",
+                    help="further flag sets measured in the same process on the same reference and reads (e.g. --also='--mer 20 --jump 10 "
+                         "--max-kmer-hits 150'); one JSON line each, after the main one")
+    return ap
+
+
+def setup_reference(a, g, gd, torch, local):
+    """reference + index, made once per box by local rank 0 BEFORE the process group exists (no rank waits inside a collective)"""
+    key = reference_key(a)
+    wd = os.path.join(a.workdir, key)
+    fa = os.path.join(wd, "genome.fa")
+    ready = fa + ".index_ready"
+    if local == 0:
+        os.makedirs(wd, exist_ok=True)
+        if not os.path.exists(ready):
+            log(f"[bench] generating {a.genome_mbp:g} Mbp {'repeat-rich ' if a.repeats else ''}reference and building its index (once; untimed)")
+            make_genome(fa, a.genome_mbp, 42, a.contigs, a.repeats)
+            g.index_build(fa)
+            open(ready, "w").write("ok\n")
+    else:
+        while not os.path.exists(ready):
+            time.sleep(1.0)
+    return fa, wd
+
+
+def main():
+    ap = build_parser()
+    a = ap.parse_args()
+
+    import torch
+    import gnumap_amd as g
+    from gnumap_amd import dist as gd
+
+    rank, world, local = gd.env_rank()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libgnumap_hip has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    t_setup = time.time()
+    fa, wd = setup_reference(a, g, gd, torch, local)
+    gd.init("nccl", dev)                                      # RCCL over xGMI when WORLD_SIZE > 1
+    gd.barrier()
+    flags = g.GM_INDEX_FULL_SA if a.locate == "full" else 0
+    ix = g.Index(fa, device=local, flags=flags)
+    # the packed reference as 2-bit codes for the read generator
+    pac = np.fromfile(fa + ".gnumap.pac", np.uint8)[: ix.info.l_pac // 4 + 1]
+    pac_t = torch.from_numpy(pac).to(dev)
+    codes_t = torch.stack([(pac_t >> 6) & 3, (pac_t >> 4) & 3, (pac_t >> 2) & 3, pac_t & 3], 1).reshape(-1)[: ix.info.l_pac]
+    del pac_t, pac
+    B, Q, Ln = make_reads(codes_t, a.reads, a.read_len, gd.read_seed(1000, rank), dev)
+    del codes_t
+    torch.cuda.empty_cache()
+    out = run_config(a, g, gd, torch, ix, fa, wd, B, Q, Ln, dev, rank, world, t_setup)
+    if rank == 0:
         print(json.dumps(out), flush=True)
+    for extra in a.also:                                     # same reference (and its flags), same reads, other mapping flags
+        import shlex
+        base, skip = [], False                               # the main row's flags without its own --opt / --also
+        for x in sys.argv[1:]:
+            if skip:
+                skip = False
+            elif x in ("--opt", "--also"):
+                skip = True
+            elif not (x.startswith("--opt=") or x.startswith("--also=")):
+                base.append(x)
+        a2 = ap.parse_args(base + shlex.split(extra))
+        a2.also = []
+        for fixed in ("genome_mbp", "contigs", "repeats", "reads", "read_len", "locate", "workdir"):
+            setattr(a2, fixed, getattr(a, fixed))
+        o2 = run_config(a2, g, gd, torch, ix, fa, wd, B, Q, Ln, dev, rank, world, time.time())
+        if rank == 0:
+            print(json.dumps(o2), flush=True)
     gd.shutdown()
 
 

@@ -4,8 +4,8 @@ declared in include/gnumap_hip.h.  There is no CPU fallback: compute calls raise
 device (or no built library) is available."""
 from .api import (GnumapError, Index, Batch, Params, lib, load_library, library_path, pack_reads, GM_INDEX_FULL_SA, GM_INDEX_BUILD,
                   GM_INDEX_HOST_ONLY, GM_READ_OK, GM_READ_TOO_MANY, GM_READ_NONE, GM_READ_TOO_SHORT, GM_READ_TOO_POOR,
-                  GM_BUILD_AUTO, GM_BUILD_HOST, GM_BUILD_DEVICE, index_build, version)
+                  GM_BUILD_AUTO, GM_BUILD_HOST, GM_BUILD_DEVICE, index_build, version, set_option)
 
-__all__ = ["GnumapError", "Index", "Batch", "Params", "lib", "load_library", "library_path", "pack_reads", "index_build", "version",
+__all__ = ["GnumapError", "Index", "Batch", "Params", "lib", "load_library", "library_path", "pack_reads", "index_build", "version", "set_option",
            "GM_INDEX_FULL_SA", "GM_INDEX_BUILD", "GM_INDEX_HOST_ONLY", "GM_BUILD_AUTO", "GM_BUILD_HOST", "GM_BUILD_DEVICE",
            "GM_READ_OK", "GM_READ_TOO_MANY", "GM_READ_NONE", "GM_READ_TOO_SHORT", "GM_READ_TOO_POOR"]

@@ -77,9 +77,9 @@ SAM_DTYPE = np.dtype([("read", "<u4"), ("pos", "<u8"), ("contig", "<u4"), ("chr_
                       ("a_score", "<f4"), ("post_prob", "<f4"), ("sim_matches", "<i4"), ("cigar_off", "<u4")], align=True)
 
 # every symbol include/gnumap_hip.h declares
-EXPORTS = ["gm_last_error", "gm_version", "gm_index_build", "gm_index_build_on", "gm_index_open", "gm_index_close", "gm_index_get_info", "gm_index_contig_name",
+EXPORTS = ["gm_last_error", "gm_version", "gm_set_option", "gm_index_build", "gm_index_build_on", "gm_index_open", "gm_index_close", "gm_index_get_info", "gm_index_contig_name",
            "gm_index_contig_offset", "gm_index_window", "gm_params_default", "gm_params_finalize", "gm_params_load_subst", "gm_batch_create", "gm_batch_destroy",
-           "gm_batch_upload", "gm_map_batch_device", "gm_batch_counters", "gm_batch_set_profiling", "gm_batch_kernel_times", "gm_kernel_name",
+           "gm_batch_upload", "gm_map_batch_device", "gm_batch_counters", "gm_batch_path", "gm_batch_set_profiling", "gm_batch_kernel_times", "gm_kernel_name",
            "gm_batch_raw_hits", "gm_stream_create", "gm_stream_destroy", "gm_host_alloc", "gm_host_free", "gm_map_batch", "gm_output_batch",
            "gm_dev_sa_interval", "gm_dev_locate", "gm_dev_nw_score", "gm_dev_traceback", "gm_coverage_reset", "gm_coverage_bins",
            "gm_coverage_device_ptr", "gm_coverage_add", "gm_coverage_download", "gm_coverage_allreduce", "gm_coverage_write_sgr", "gm_coverage_enable_nuc", "gm_coverage_nuc_device_ptr",
@@ -101,6 +101,7 @@ def load_library():
     L = C.CDLL(path)
     L.gm_last_error.restype = C.c_char_p
     L.gm_version.restype = C.c_char_p
+    L.gm_set_option.argtypes = [C.c_char_p, C.c_char_p]
     L.gm_index_build.argtypes = [C.c_char_p]
     L.gm_index_build_on.argtypes = [C.c_char_p, C.c_int, C.c_int]
     L.gm_index_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
@@ -117,6 +118,7 @@ def load_library():
     L.gm_batch_upload.argtypes = [C.c_void_p, C.POINTER(gm_params), C.POINTER(gm_reads), C.c_void_p]
     L.gm_map_batch_device.argtypes = [C.c_void_p, C.POINTER(gm_params), C.c_void_p, C.c_void_p]
     L.gm_batch_counters.argtypes = [C.c_void_p, C.POINTER(gm_counters)]
+    L.gm_batch_path.argtypes = [C.c_void_p]; L.gm_batch_path.restype = C.c_char_p
     L.gm_batch_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.gm_batch_kernel_times.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.gm_kernel_name.argtypes = [C.c_int]; L.gm_kernel_name.restype = C.c_char_p
@@ -158,6 +160,11 @@ def _chk(rc):
 
 def version():
     return lib().gm_version().decode()
+
+
+def set_option(name, value):
+    """gm_set_option: override a GM_* run-time switch for the calls that follow (None: back to the environment)"""
+    _chk(lib().gm_set_option(name.encode(), None if value is None else str(value).encode()))
 
 
 GM_BUILD_AUTO, GM_BUILD_HOST, GM_BUILD_DEVICE = 0, 1, 2
@@ -326,6 +333,10 @@ class Batch:
         c = gm_counters()
         _chk(lib().gm_batch_counters(self.h, C.byref(c)))
         return {n: getattr(c, n) for n, _ in gm_counters._fields_}
+
+    def path(self):
+        """which kernels the last map_device / map chose"""
+        return lib().gm_batch_path(self.h).decode()
 
     def set_profiling(self, on=True):
         _chk(lib().gm_batch_set_profiling(self.h, int(on)))

@@ -15,8 +15,25 @@
 #include <thread>
 
 static thread_local std::string g_err;
-// GM_TRACE=1: one line per phase of the batch calls on stderr (what a long run is doing, with the sizes that explain it)
-static bool gm_trace_on() { static const bool on = [] { const char* e = getenv("GM_TRACE"); return e && atoi(e); }(); return on; }
+// ---- run-time switches: gm_set_option() overrides, else the environment; never latched (see gm_internal.h) ----
+namespace { std::mutex g_opt_mu; std::map<std::string, const char*> g_opts; }      // values are interned (never freed): a reader may still hold one
+const char* gm_opt(const char* name) {
+    const char* v = nullptr; bool have = false;
+    {
+        std::lock_guard<std::mutex> lk(g_opt_mu);
+        auto it = g_opts.find(name);
+        if (it != g_opts.end()) { v = it->second; have = true; }
+    }
+    if (!have) v = getenv(name);
+    return v && *v ? v : nullptr;                              // an empty value counts as unset
+}
+extern "C" int gm_set_option(const char* name, const char* value) {
+    if (!name || strncmp(name, "GM_", 3) != 0) return GM_E_ARG;
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    if (value) g_opts[name] = strdup(value); else g_opts.erase(name);       // null: back to the environment
+    return GM_OK;
+}
+static bool gm_trace_on() { return gm_opt_ll("GM_TRACE", 0) != 0; }
 static double gm_trace_ms() { static const auto t0 = std::chrono::steady_clock::now(); return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 #define GM_TRACE(...) do { if (gm_trace_on()) { fprintf(stderr, "[gm_trace %9.1f ms] ", gm_trace_ms()); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 void gm_set_error(const std::string& s) { g_err = s; }
@@ -92,6 +109,7 @@ struct gm_index {
     std::map<std::vector<float>, DevBuf> ptabs;   // by content
     std::map<int, DevBuf> kmer_tabs;        // memoised backward search of the last T characters of a seed, per T
     std::map<int, DevBuf> kmer_ctabs;       // its compact form (16 B per 8 codes), per T
+    std::map<int, DevBuf> buckets;          // k-mer -> positions records (128 B per code; gm_bucket.hip), per T; empty DevBuf = tried, no room
     std::mutex mu;
     uint64_t hbm_bytes = 0;
 };
@@ -109,6 +127,7 @@ struct gm_batch {
     PinBuf h_top, h_hbegin, h_ord, h_post, h_mapq, h_emit, h_mhit;
     std::vector<double> h_exp;          // exp(score) of every accepted hit of the last gm_map_batch (reused by gm_output_batch)
     uint64_t cache_hits = 0, cache_matches = 0;
+    std::string path;                   // which kernels the last gm_map_batch_device chose (gm_batch_path)
     bool use_pack = false;              // the fused seed lookup is on for this pass (k_prep writes the 2-bit read forms)
     const void* resume_ptr = nullptr;   // set when gm_map_batch returned GM_E_CAPACITY: the next call with the same reads resumes at the copies
     uint32_t cand_cap = 0;
@@ -239,7 +258,8 @@ static void build_lut(float* lut /* 512 x 2 */) {
         }
 }
 
-static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStream_t st) {
+// want_bucket: the caller may use the bucket table of gm_bucket.hip (gm_map_batch_device): built on first use when it applies
+static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStream_t st, bool want_bucket = false) {
     std::vector<float> tab(256 * 4 + 512 * 2);
     memcpy(tab.data(), p->S, sizeof(float) * 1024);
     build_lut(tab.data() + 1024);
@@ -263,17 +283,17 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
     dp.mer = p->mer; dp.jump = p->jump; dp.kmin = p->min_seed_hits; dp.nw = p->nw; dp.fast = p->fast;
     dp.pos_strand = p->pos_strand; dp.neg_strand = p->neg_strand; dp.align_is_fraction = p->align_is_fraction; dp.max_gap = p->max_gap;
     dp.fused = 0; dp.heavy_min = 0xFFFFFFFFu;
-    { const char* e = getenv("GM_DBG"); dp.dbg = e ? atoi(e) : 0; }
+    dp.dbg = (int)gm_opt_ll("GM_DBG", 0);
     // k-mer interval table: the last T characters of every seed are one lookup (GM_KMER_TABLE=0 keeps the pure occ walk;
     // GM_KMER_TABLE=<T> picks another suffix length, at most 16)
-    dp.kmer_tab = nullptr; dp.kmer_T = 0; dp.kmer_ctab = nullptr;
+    dp.kmer_tab = nullptr; dp.kmer_T = 0; dp.kmer_ctab = nullptr; dp.bucket = nullptr;
     {
         // up to 12 characters by default; more for longer seeds on references where the extra occ steps are HBM misses anyway
         // (>= 50 Mbp): 14 characters = 2 GB + 0.5 GB compact,
         // 15 / 16 characters (8.6 + 2.1 GB / 34 + 8.6 GB: what 288 GB of HBM is for) when the seeds are that long: a 16-mer is then
         // ONE random 16-byte probe instead of a probe + two search steps
         int T = std::min(p->mer, ix->h.seq_len >= 50000000ull ? 16 : 12);
-        if (const char* e = getenv("GM_KMER_TABLE")) T = std::min(std::min(atoi(e), p->mer), 16);
+        if (const char* e = gm_opt("GM_KMER_TABLE")) { if (*e) T = std::min(std::min(atoi(e), p->mer), 16); }
         if (T >= 4) {
             std::lock_guard<std::mutex> lk(ix->mu);
             // the 15- / 16-character tables are bought with free HBM: step down while table + previous level + compact form (+ 8 GB
@@ -307,7 +327,7 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
                 ix->hbm_bytes += tb.cap;
             }
             dp.kmer_tab = tb.as<uint2>(); dp.kmer_T = T;
-            static const bool compact = [] { const char* e = getenv("GM_KMER_COMPACT"); return !(e && !strcmp(e, "0")); }();
+            const bool compact = !gm_opt_is("GM_KMER_COMPACT", "0");
             if (compact) {
                 DevBuf& cb = ix->kmer_ctabs[T];
                 if (!cb.p) {
@@ -317,6 +337,29 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
                     ix->hbm_bytes += cb.cap;
                 }
                 dp.kmer_ctab = cb.as<uint4>();
+            }
+            // k-mer -> positions records (gm_bucket.hip): full SA, the table covering the whole seed, a k-mer expected between a
+            // fraction of a time and ~20 times in the reference (a record holds 31 positions; more go through the suffix array),
+            // and 128 bytes per code have to fit beside everything else: -m 14 = 34 GB of the 288.  GM_SEED_BUCKET=0 / 1: never /
+            // whenever the table can be built.
+            const long long bucket_opt = gm_opt_ll("GM_SEED_BUCKET", -1);
+            const double occ = (double)ix->h.seq_len / pow(4.0, (double)std::min(p->mer, 31));
+            if (want_bucket && bucket_opt != 0 && ix->full_sa && T == p->mer && T <= 15 && (bucket_opt > 0 || (occ >= 1.0 && occ <= 20.0))) {
+                auto it = ix->buckets.find(T);
+                if (it == ix->buckets.end()) {
+                    DevBuf bb;
+                    const size_t need = ((size_t)1 << (2 * T)) * 128;
+                    size_t fr = 0, tot = 0;
+                    if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr >= need + ((size_t)24 << 30) && bb.ensure(need) == GM_OK) {
+                        const auto t0 = std::chrono::steady_clock::now();
+                        KCHK(gmk_build_bucket(tb.as<uint2>(), ix->d_full.as<uint32_t>(), bb.as<uint4>(), T, st));
+                        HIPCHK(hipStreamSynchronize(st));
+                        ix->hbm_bytes += bb.cap;
+                        GM_TRACE("bucket table: %d-mers, %.1f GB, built in %.0f ms", T, need / 1e9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+                    }
+                    it = ix->buckets.emplace(T, bb).first;     // an empty entry = does not fit: not tried again
+                }
+                dp.bucket = it->second.as<uint4>();
             }
         }
     }
@@ -418,6 +461,7 @@ extern "C" void gm_index_close(gm_index* ix) {
         for (auto& kv : ix->ptabs) kv.second.release();
         for (auto& kv : ix->kmer_tabs) kv.second.release();
         for (auto& kv : ix->kmer_ctabs) kv.second.release();
+        for (auto& kv : ix->buckets) kv.second.release();
     }
     delete ix;
 }
@@ -684,7 +728,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
     HIPCHK(hipSetDevice(ix->device));
     hipStream_t st = S_(stream);
     GmDevParams dp;
-    int rc = sync_params(ix, p, dp, st);
+    int rc = sync_params(ix, p, dp, st, true);
     if (rc) return rc;
     b->mapped = false;
     if (b->n == 0) { b->n_cands = 0; b->n_raw = 0; b->mapped = true; memset(b->counters_host, 0, sizeof b->counters_host); return GM_OK; }
@@ -708,15 +752,15 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         const double groups_exp = ns * ceil((per_seed + 3.0 * sqrt(per_seed) + 1.0) / 16.0);
         if (dense == 1 && p->min_seed_hits >= 2 && e_exp + 4.0 * sqrt(e_exp) <= 230.0 && groups_exp <= 28.0) slots_hint = 0;
         else if (dense == 1 && p->min_seed_hits >= 2 && e_exp + 4.0 * sqrt(e_exp) <= 350.0 && groups_exp <= 56.0) slots_hint = -1;      // k_vote_tiny2
-        if (const char* ev = getenv("GM_VOTE_SLOTS")) slots_hint = atoi(ev);
-        if (const char* ev = getenv("GM_VOTE")) dense = !strcmp(ev, "block") ? 1 : !strcmp(ev, "big") ? 2 : !strcmp(ev, "rounds") ? 3 : !strcmp(ev, "wave") ? 0 : dense;
+        if (const char* ev = gm_opt("GM_VOTE_SLOTS")) { if (*ev) slots_hint = atoi(ev); }
+        if (const char* ev = gm_opt("GM_VOTE")) dense = !strcmp(ev, "block") ? 1 : !strcmp(ev, "big") ? 2 : !strcmp(ev, "rounds") ? 3 : !strcmp(ev, "wave") ? 0 : dense;
     }
     b->counters_on_host = false;
     {   // optional sub-batch pipeline over several streams for large full-SA batches (GM_PIPELINE=<sub-batch size>).  Measured
         // +4 % at configs[1]: three vote kernels end up sharing the LDS rather than hiding seed / NW work, and per-kernel
         // timings stop being attributable, so it is off by default.
         uint32_t sub_n = 0;
-        if (const char* ev = getenv("GM_PIPELINE")) sub_n = (uint32_t)atoi(ev);
+        sub_n = (uint32_t)gm_opt_ll("GM_PIPELINE", 0);
         if (use_full && sub_n >= 4096 && b->n >= 3 * (uint64_t)sub_n) {
             int prc = map_pipelined(ix, p, dp, b, st, dense, slots_hint, sub_n);
             if (prc <= 0) return prc;                    // done, or a real error
@@ -724,9 +768,10 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
     }
     // read x strands with very many SA hits (repeat seeds without -h) leave the ordinary vote kernels before they start: sorted-key
     // path of gm_heavy.hip, routed by the seed search's own hit count.  GM_HEAVY_MIN / GM_HEAVY_BUDGET (keys per chunk) are test switches.
-    static const uint32_t heavy_min = [] { const char* e = getenv("GM_HEAVY_MIN"); return e ? (uint32_t)atoll(e) : 16384u; }();
-    static const uint64_t heavy_budget = [] { const char* e = getenv("GM_HEAVY_BUDGET"); return e ? (uint64_t)atoll(e) : (uint64_t)1 << 27; }();
+    const uint32_t heavy_min = (uint32_t)gm_opt_ll("GM_HEAVY_MIN", 16384);
+    const uint64_t heavy_budget = (uint64_t)gm_opt_ll("GM_HEAVY_BUDGET", 1ll << 27);
     dp.heavy_min = heavy_min;
+    bool use_bucket = false; uint32_t bucket_reg = 0;
     // seed lookup inside the vote kernels that take one read x strand per wave / workgroup (full SA, the k-mer table covering the
     // whole seed): no k_seed launch, no seed rows through HBM.  A k-mer that does not occur changes the positions of all later ones;
     // the wave then walks again round by round (gm_seed_rewalk_ool), one probe round trip per failing k-mer.  That stays rare while
@@ -735,21 +780,36 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
     // characters before its end, the walk creeps past the error in ~9 rounds, 207 against 29.5 ms - k_seed amortises those serial
     // steps over 64 lanes).  GM_SEED_FUSED=0 / 1: never / whenever possible.
     {
-        static const int fused_env = [] { const char* e = getenv("GM_SEED_FUSED"); return e ? atoi(e) : -1; }();
+        const int fused_env = (int)gm_opt_ll("GM_SEED_FUSED", -1);
         const double occ = (double)ix->h.seq_len / pow(4.0, (double)std::min(p->mer, 31));
         // -h: on a real reference the k-mers of repeats exceed any cap, and each of them makes the walk slide base by base (:213-217) in
         // one lane - not measurable on the synthetic references of bench.py, so a capped run keeps k_seed unless forced
         const bool pays = occ >= 4.0 && p->max_kmer_hits == 0;
-        dp.fused = (fused_env < 0 ? pays : fused_env != 0) && use_full && (dense == 1 || dense == 2) && !getenv("GM_VOTE_KERNEL") && b->max_seeds <= 64 && dp.kmer_tab &&
+        dp.fused = (fused_env < 0 ? pays : fused_env != 0) && use_full && (dense == 1 || dense == 2) && !gm_opt("GM_VOTE_KERNEL") && b->max_seeds <= 64 && dp.kmer_tab &&
                    dp.kmer_ctab && dp.kmer_T == p->mer && p->mer <= 16 && p->jump >= 1 && !(dp.dbg & 128);
+        // ... or in the bucket table (one read per wave, both strands; handles -h and k-mers that do not occur by walking again):
+        // every seed is ONE random line
+        const uint32_t lastmax = b->stride > (uint32_t)p->mer ? b->stride - (uint32_t)p->mer : 0;
+        const uint32_t max_reg = (lastmax + (uint32_t)p->jump - 1) / (uint32_t)p->jump;
+        use_bucket = dp.bucket && use_full && dp.kmer_tab && dp.kmer_T == p->mer && p->min_seed_hits >= 2 && max_reg <= 32 && b->max_seeds <= 34 && !gm_opt("GM_VOTE_KERNEL") &&
+                     !gm_opt("GM_VOTE") && gm_opt_ll("GM_PIPELINE", 0) == 0 && !(dp.dbg & 128) && fused_env != 0;
+        if (use_bucket) { dp.fused = 1; bucket_reg = max_reg; } else dp.bucket = nullptr;
         b->use_pack = dp.fused != 0;
         if (b->use_pack && b->pack.ensure((size_t)b->n * gm_pack_words(b->stride) * 4 + 64)) return GM_E_NOMEM;
     }
     // the one-wave vote kernels leave their candidates in per read x strand slots (no bump counter on the wave's critical path)
     {
-        static const bool fixed_ok = [] { const char* e = getenv("GM_VOTE_FIXED"); return !(e && !strcmp(e, "0")); }();
-        b->use_fixed = fixed_ok && (dense == 1 || dense == 2) && !getenv("GM_VOTE_KERNEL");      // k_vote_tiny*, k_vote_slots (all forms)
+        const bool fixed_ok = !gm_opt_is("GM_VOTE_FIXED", "0");
+        b->use_fixed = fixed_ok && (use_bucket || ((dense == 1 || dense == 2) && !gm_opt("GM_VOTE_KERNEL")));      // k_vote_bucket, k_vote_tiny*, k_vote_slots (all forms)
         if (b->use_fixed && (b->fixed_cands.ensure(2 * (size_t)b->n * GM_FIXED_C * sizeof(GmCand)) || b->fixed_cnt.ensure(2 * (size_t)b->n + 64))) return GM_E_NOMEM;
+    }
+    {
+        char buf[160];
+        snprintf(buf, sizeof buf, "seeds=%s vote=%s locate=%s", use_bucket ? "bucket-table (in the vote kernel)" : dp.fused ? "k-mer table (in the vote kernel)" : "k_seed",
+                 use_bucket ? (bucket_reg <= 16 ? "k_vote_bucket<4>" : bucket_reg <= 24 ? "k_vote_bucket<6>" : "k_vote_bucket<8>")
+                            : dense == 0 ? "sparse" : dense == 3 ? "k_vote_block" : dense == 2 ? "k_vote_slots<64>" : slots_hint == 0 ? "k_vote_tiny" : slots_hint < 0 ? "k_vote_tiny2" : "k_vote_slots",
+                 use_full ? "full-SA" : "sampled-SA");
+        b->path = buf;
     }
     fill_dev_batch(b);
     HIPCHK(hipMemsetAsync(b->counters.p, 0, GMK_N * 8, st));
@@ -827,7 +887,12 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
             HIPCHK(hipMemsetAsync(b->counters.as<unsigned long long>() + GMK_KMERS, 0, 4 * 8, st));            // KMERS, OCC, SEEDS, SA_HITS
             HIPCHK(hipMemsetAsync(b->counters.as<unsigned long long>() + GMK_OCC_BLOCKS, 0, 2 * 8, st));       // OCC_BLOCKS, TAB_LOOKUPS
         }
-        { KTimer t(b, GM_K_VOTE, st); KCHK(gmk_vote(ix->dev, dp, b->dev, use_full, dense, slots_hint, st)); KCHK(gmk_cand_gather(b->dev, st)); }
+        {
+            KTimer t(b, GM_K_VOTE, st);
+            if (use_bucket) { KCHK(gmk_vote_bucket(ix->dev, dp, b->dev, bucket_reg, st)); KCHK(gmk_vote_list(ix->dev, dp, b->dev, use_full, st)); }
+            else KCHK(gmk_vote(ix->dev, dp, b->dev, use_full, dense, slots_hint, st));
+            KCHK(gmk_cand_gather(b->dev, st));
+        }
         if (dp.fused) { heavy.clear(); rc = collect_heavy(); if (rc) return rc; }
         uint32_t small[2];
         HIPCHK(hipMemcpyAsync(small, b->small.p, 8, hipMemcpyDeviceToHost, st));
@@ -845,7 +910,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         uint32_t n_retry = small[1];
         if (n_retry && mx <= b->dev.cand_region) {
             size_t slots = (size_t)ctr[GMK_HEAVY_SLOTS];
-            static const size_t budget = [] { const char* e = getenv("GM_RETRY_BUDGET"); return e ? (size_t)atoll(e) : (size_t)1 << 28; }();   // table slots per launch (2 GB of keys + counts; the switch is for tests)
+            const size_t budget = (size_t)gm_opt_ll("GM_RETRY_BUDGET", 1ll << 28);   // table slots per launch (2 GB of keys + counts; the switch is for tests)
             if (slots <= budget) {
                 if (b->gtab_keys.ensure(slots * 4) || b->gtab_vals.ensure(slots * 4)) return GM_E_NOMEM;
                 fill_dev_batch(b);
@@ -926,6 +991,8 @@ extern "C" int gm_batch_counters(gm_batch* b, gm_counters* o) {
     o->vote_retries = c[GMK_OVERFLOW_RS]; o->table_lookups = c[GMK_TAB_LOOKUPS];
     return GM_OK;
 }
+
+extern "C" const char* gm_batch_path(gm_batch* b) { return b ? b->path.c_str() : ""; }
 
 extern "C" const char* gm_kernel_name(int which) {
     static const char* names[GM_K_COUNT] = { "k_prep", "k_seed", "k_locate_sampled", "k_vote", "k_vote_retry", "k_nw", "k_compact(scan+scatter)" };
@@ -1010,7 +1077,7 @@ extern "C" int gm_batch_raw_hits(gm_batch* b, gm_raw_hit* out, uint64_t cap, uin
 // calling them from several threads with different batches)
 static unsigned host_threads() {
     static const unsigned n = [] {
-        const char* e = getenv("GM_HOST_THREADS");
+        const char* e = getenv("GM_HOST_THREADS");               // sizes thread pools once per process
         unsigned v = e ? (unsigned)atoi(e) : std::min(16u, std::thread::hardware_concurrency());
         return std::max(1u, v);
     }();
@@ -1030,7 +1097,7 @@ template <class F> static unsigned parallel_chunks(uint32_t n, uint32_t grain, u
 
 struct PhaseClock {                         // GM_TIMING=1: host-side phase times of the two batch calls on stderr
     bool on; const char* what; std::chrono::steady_clock::time_point t0; std::string line;
-    explicit PhaseClock(const char* w) : on(getenv("GM_TIMING") && atoi(getenv("GM_TIMING"))), what(w), t0(std::chrono::steady_clock::now()) {}
+    explicit PhaseClock(const char* w) : on(gm_opt_ll("GM_TIMING", 0) != 0), what(w), t0(std::chrono::steady_clock::now()) {}
     void lap(const char* name) {
         if (!on) return;
         auto t1 = std::chrono::steady_clock::now();
@@ -1085,7 +1152,7 @@ extern "C" int gm_map_batch(gm_index* ix, const gm_params* p, gm_batch* b, const
     hipStream_t st = S_(stream);
     int rc;
     {   // test switch: behave as if blocks above this size outgrew a launch (exercises the callers' halving)
-        static const uint32_t test_max = [] { const char* e = getenv("GM_TEST_MAX_BLOCK"); return e ? (uint32_t)atoi(e) : 0u; }();
+        const uint32_t test_max = (uint32_t)gm_opt_ll("GM_TEST_MAX_BLOCK", 0);
         if (test_max && reads->n > test_max) { gm_set_error("GM_TEST_MAX_BLOCK: block treated as too large"); return GM_E_BATCH_TOO_LARGE; }
     }
     // a call repeated with larger output buffers after GM_E_CAPACITY picks up where the first one stopped: the block is still mapped

@@ -3,6 +3,8 @@
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
 
 // ---- HBM-resident index, passed to kernels by value -------------------------------------------------
 // bwt      : the occ-interleaved BWT exactly as <fa>.gnumap.bwt stores it: one 64-byte block per 128 bases
@@ -41,6 +43,7 @@ struct GmDevParams {
     int kmer_T;
     const uint4* kmer_ctab;         // compact form of kmer_tab, 16 B per 8 consecutive codes: {first SA rank, 8 x u8 hit counts (2 words), escape flag}; null = not built
     const float2* lut;              // [0..255] Phred+33, [256..511] Phred+64: (p, (1-p)/3) as fp32; p = NaN when negative
+    const uint4* bucket;            // direct-addressed k-mer -> positions table (gm_bucket.hip): 128 bytes per mer-mer code, or null
 };
 
 struct GmSeed { uint32_t k, l, pos; };
@@ -148,6 +151,11 @@ struct GmDevGroup {
 // Launchers (gm_kernels.hip, gm_output.hip).  All asynchronous on `stream`; they return a hipError_t cast to int.
 #ifdef __cplusplus
 extern "C++" {
+// run-time switches (GM_*): the value set with gm_set_option(), else the environment variable, else null.  Read on EVERY call:
+// a long-lived host (and one test process) can change a choice between two batches.  Defined in gm_api.cpp.
+const char* gm_opt(const char* name);
+inline long long gm_opt_ll(const char* name, long long dflt) { const char* e = gm_opt(name); return e && *e ? atoll(e) : dflt; }
+inline bool gm_opt_is(const char* name, const char* value) { const char* e = gm_opt(name); return e && !strcmp(e, value); }
 int gmk_expand_full_sa(const GmDevIndex& ix, uint32_t* full_sa, void* stream);
 int gmk_build_occ_planes(const GmDevIndex& ix, uint4* planes, uint32_t nblk, void* stream);
 int gmk_build_kmer_table(const GmDevIndex& ix, uint2* tab, int T, void* stream);
@@ -159,6 +167,10 @@ int gmk_scan_entries(const GmDevBatch& b, void* stream);
 int gmk_locate_sampled(const GmDevIndex& ix, const GmDevBatch& b, void* stream);
 int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, int dense, int slots_hint, void* stream);
 int gmk_cand_gather(const GmDevBatch& b, void* stream);
+// gm_bucket.hip: the bucket table and the one-wave-per-read vote kernel that looks its seeds up in it
+int gmk_build_bucket(const uint2* tab, const uint32_t* full_sa, uint4* bucket, int T, void* stream);
+int gmk_vote_bucket(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint32_t max_reg, void* stream);
+int gmk_vote_list(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, void* stream);     // k_vote_fast_list over b.big_list
 // gm_heavy.hip: read x strands with more than heavy_min SA hits (sorted-key vote path)
 int gmk_heavy_collect(const GmDevBatch& b, uint32_t heavy_min, uint32_t* n_heavy, uint32_t* heavy_list /* {rs, n_seeds, SA hits} triples */, int sum_counters, void* stream);
 inline uint32_t gm_pack_w2(uint32_t stride) { return (stride + 15u) / 16u; }

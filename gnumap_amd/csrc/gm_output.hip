@@ -648,7 +648,7 @@ static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b -
 
 int gmk_group_count(const GmDevIndex& ix, const GmDevBatch& b, const GmDevGroup& g, int nw, int unique_only, uint32_t max_matches, void* stream) {
     if (b.n == 0) return 0;
-    static const uint32_t big_min = [] { const char* e = getenv("GM_GROUP_BIG_MIN"); return e ? (uint32_t)atoi(e) : (uint32_t)GM_GROUP_BIG; }();     // test switch
+    const uint32_t big_min = (uint32_t)gm_opt_ll("GM_GROUP_BIG_MIN", GM_GROUP_BIG);     // test switch
     hipLaunchKernelGGL(k_group_single, dim3(cdiv(b.n, 256)), dim3(256), 0, S_(stream), b, g, nw, max_matches, big_min);
     {   // reads with many accepted hits first: what this kernel cannot finish goes to the all-pairs kernel's list
         const size_t lds = (size_t)GO_SET_SLOTS * 16 + (size_t)GO_SET_LIMIT * 4 + 64;

@@ -161,6 +161,10 @@ enum { GM_K_PREP = 0, GM_K_SEED, GM_K_LOCATE, GM_K_VOTE, GM_K_VOTE_RETRY, GM_K_N
 
 const char* gm_last_error(void);
 const char* gm_version(void);
+/* run-time switches of the library (the GM_* names documented in DESIGN.md: kernel choices, test switches).  Every switch is read
+ * on each call that uses it - from this table first, then from the environment - so a long-lived host can change a choice
+ * between two batches.  value = NULL removes the override (back to the environment); "" hides an environment variable. */
+int gm_set_option(const char* name, const char* value);
 
 /* ---- index ---- */
 int gm_index_build(const char* fasta_path);                      /* writes <fa>.gnumap.{pac,ann,amb,bwt,sa}; = gm_index_build_on(fa, GM_BUILD_AUTO, 0) */
@@ -197,6 +201,9 @@ int gm_batch_counters(gm_batch*, gm_counters* out);
 int gm_batch_set_profiling(gm_batch*, int on);
 int gm_batch_kernel_times(gm_batch*, double* ms /* GM_K_COUNT */, uint64_t* launches /* GM_K_COUNT */);
 const char* gm_kernel_name(int which);
+/* which seed lookup / vote kernel / locate form the last gm_map_batch_device on this batch chose, e.g.
+ * "seeds=bucket-table (in the vote kernel) vote=k_vote_bucket<4> locate=full-SA" (valid until the next call on the batch) */
+const char* gm_batch_path(gm_batch*);
 /* raw device results (accepted candidates), for tests and for callers that post-process themselves */
 typedef struct { uint32_t read; uint32_t pos; float score; uint16_t step; uint8_t strand; uint8_t pad; } gm_raw_hit;
 int gm_batch_raw_hits(gm_batch*, gm_raw_hit* out, uint64_t cap, uint64_t* n_out,
