@@ -339,12 +339,12 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
                 dp.kmer_ctab = cb.as<uint4>();
             }
             // k-mer -> positions records (gm_bucket.hip): full SA, the table covering the whole seed, a k-mer expected between a
-            // fraction of a time and ~20 times in the reference (a record holds 31 positions; more go through the suffix array),
+            // fraction of a time and ~20 times in the reference (a record holds 28 positions; more go through the suffix array),
             // and 128 bytes per code have to fit beside everything else: -m 14 = 34 GB of the 288.  GM_SEED_BUCKET=0 / 1: never /
             // whenever the table can be built.
             const long long bucket_opt = gm_opt_ll("GM_SEED_BUCKET", -1);
             const double occ = (double)ix->h.seq_len / pow(4.0, (double)std::min(p->mer, 31));
-            if (want_bucket && bucket_opt != 0 && ix->full_sa && T == p->mer && T <= 15 && (bucket_opt > 0 || (occ >= 1.0 && occ <= 20.0))) {
+            if (want_bucket && bucket_opt != 0 && ix->full_sa && T == p->mer && T <= 15 && ix->h.seq_len < 0xFFFFE000ull && (bucket_opt > 0 || (occ >= 1.0 && occ <= 20.0))) {
                 auto it = ix->buckets.find(T);
                 if (it == ix->buckets.end()) {
                     DevBuf bb;

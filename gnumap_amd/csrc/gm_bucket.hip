@@ -6,41 +6,38 @@
 // bwt_sa of every SA hit, locs[b]++): in k_vote_tiny a seed costs a probe of the compact k-mer table (one random 128-byte line for 16
 // bytes) and, dependent on it, its run of the suffix array (~48 bytes in 1.37 lines).  The measured price of a random fetch on MI355X
 // is the LINE, whatever part of it is used (tools/ubench/gather.hip: 47-48 G records/s for 16-, 32-, 64- and 128-byte records alike,
-// = 6 TB/s only when the whole line is wanted).  So the table holds, per mer-mer CODE, one 128-byte record = the hit count + up to 31
+// = 6 TB/s only when the whole line is wanted).  So the table holds, per mer-mer CODE, one 128-byte record = the hit count + up to 28
 // TEXT POSITIONS (the suffix-array values of its interval): one line and ONE round trip per seed, 26 lines per 100-bp read instead
 // of ~65.
 //
-// Record of code c, 32 words.  Logical word w sits at physical word 4 (w % 8) + w / 8, so that lane q of the 8 lanes that fetch a
-// record with one 16-byte load each holds logical words q, 8 + q, 16 + q, 24 + q: register j of ALL lanes covers words 8j .. 8j + 7,
-// and a register whose words are beyond every count of the wave is skipped with one scalar branch (counts >= 24: almost never).
-//   word 0         header: 1 .. 31 = hit count, positions in words 1 .. count, 0xFFFFFFFF in the rest
-//                          0x40000000 | d = the k-mer does not occur, its backward search died after d characters (what the adaptive
-//                                           walk needs to slide on, :213-226); all other words 0xFFFFFFFF
-//                          0x80000000     = more than 31 hits: word 8 = first SA rank, word 16 = hit count (both in lane 0's load),
-//                                           all other words 0xFFFFFFFF; the hits are read from the suffix array as before
-// Positions of one k-mer may be taken in any order: a vote is locs[c - i]++ per position c (:262-274).
-//
 // One wavefront = one read: lanes 0-31 the + strand, lanes 32-63 the - strand (two independent vote problems side by side: every
-// vector instruction works for both), step st of a half fetches the records of seeds 4 st .. 4 st + 3 (8 lanes each).
-// While every k-mer at i = 0, jump, 2 jump .. occurs (and stays within -h) that is the adaptive walk; otherwise the half walks again
-// (gm_bucket_rewalk: a regular round finds the first failing k-mer, a round over CONSECUTIVE positions the next one that does not
-// fail - two round trips per failing seed however far the walk has to slide).  Votes: 4096 x 2-bit "seen / seen again" filter per
-// strand, the hits whose slot was seen again compacted into a list, exact table, candidates - as in k_vote_tiny.  Read x strands that
-// do not fit (too many hits, too many overflow seeds, a non-ACGT base) get their seed rows written and go to the list / retry /
-// heavy kernels exactly as from k_vote_tiny.
+// vector instruction works for both), step st of a half fetches the records of seeds 4 st .. 4 st + 3 (8 lanes each; record layout
+// at k_build_bucket).  While every k-mer at i = 0, jump, 2 jump .. occurs (and stays within -h) that is the adaptive walk; otherwise
+// the half walks again (gm_bucket_rewalk: a regular round finds the first failing k-mer, a round over CONSECUTIVE positions the next
+// one that does not fail - two round trips per failing seed however far the walk has to slide).  Votes: see k_vote_bucket.  Read x
+// strands that do not fit (too many hits, a record with an early position, a non-ACGT base) get their seed rows written and go to
+// the list / heavy kernels exactly as from k_vote_tiny.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include "gm_internal.h"
 #include "gm_device.h"
 
-#define GMB_C 31                         // positions per record
-#define GMB_TSZ 128                      // exact-table slots per strand
-#define GMB_LCAP 128                     // "seen again" hits per strand that go through the table
-#define GMB_ECAP 448                     // SA hits per strand voted on here; more -> the list kernel
+#define GMB_C 28                         // positions per record
+#define GMB_EARLY 4096u                  // a record with a position below this may vote for the clamped window start b = 0 (:267): list kernel
+#define GMB_LCAP 32                      // second-or-later arrivals in a filter slot per strand (the keys of the sweeps)
+#define GMB_ECAP 384                     // SA hits per strand voted on here; more -> the list kernel
 #define GMB_OV 16                        // seeds with more than GMB_C hits per strand handled here
 #define GMB_MAXS 32                      // seeds per strand (one step tag bit each)
+#define GMB_FWORDS 512                   // filter words per strand: 16384 one-bit slots
 
 // ---- table construction: 8 lanes per code, one 16-byte store each -----------------------------------------------------------------
+// Record of code c, 32 words, as the 8 lanes that fetch it with one 16-byte load each see it:
+//   lane 0       { header, first SA rank, hit count, 0 }   (rank and count only when the hits do not fit)
+//   lane q = 1..7, register j = 0..3: text position p = 7 j + q - 1 of the k-mer's SA interval, stored as position + 1; 0 = none
+// header: bits 0-15 hit count (1 .. 28) when the positions are in the record; 0x80000000 = more hits than that (lane 0 has rank and
+// count, all position words 0); 0x40000000 | d = the k-mer does not occur, its backward search died after d characters;
+// 0x20000000 = one of its positions is below GMB_EARLY (a vote for the clamped b = 0 is possible: the list kernel counts those).
+// Register j of ALL lanes covers positions 7j .. 7j + 6: a register beyond every count of the wave is skipped with one scalar branch.
 __global__ void __launch_bounds__(256) k_build_bucket(const uint2* __restrict__ tab, const uint32_t* __restrict__ full_sa, uint4* __restrict__ bucket,
                                                       unsigned long long n_codes) {
     for (unsigned long long t = (unsigned long long)blockIdx.x * 256 + threadIdx.x; t < n_codes * 8ull; t += (unsigned long long)gridDim.x * 256) {
@@ -49,15 +46,24 @@ __global__ void __launch_bounds__(256) k_build_bucket(const uint2* __restrict__ 
         const uint2 iv = tab[code];
         const bool empty = iv.x == 0xFFFFFFFFu;
         const uint32_t cnt = empty ? 0u : iv.y - iv.x + 1u;
-        uint32_t w[4];
+        const bool inl = !empty && cnt <= GMB_C;
+        uint32_t w[4] = { 0u, 0u, 0u, 0u };
+        bool early = false;
+        if (inl) {
 #pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) {
-            const uint32_t lw = 8u * j + q;
-            uint32_t v = 0xFFFFFFFFu;
-            if (lw == 0u) v = empty ? (0x40000000u | iv.y) : cnt <= GMB_C ? cnt : 0x80000000u;
-            else if (!empty && cnt <= GMB_C) { if (lw <= cnt) v = full_sa[iv.x + lw - 1u]; }
-            else if (!empty) { if (lw == 8u) v = iv.x; else if (lw == 16u) v = cnt; }
-            w[j] = v;
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t pi = 7u * j + q - 1u;                             // lane 0: wraps, never < cnt
+                if (q != 0u && pi < cnt) w[j] = full_sa[iv.x + pi] + 1u;
+            }
+        }
+        // the early flag: any position of the interval below GMB_EARLY (lane q looks at positions q, q + 8, .. - every lane the same answer)
+        if (!empty) {
+            if (cnt <= 4096u) { for (uint32_t i = 0; i < cnt; ++i) early |= full_sa[iv.x + i] < GMB_EARLY; }
+            else early = true;                                                   // not worth a scan: read x strands with such seeds leave this kernel anyway
+        }
+        if (q == 0u) {
+            w[0] = empty ? (0x40000000u | iv.y) : ((inl ? cnt : 0x80000000u) | (early ? 0x20000000u : 0u));
+            if (!empty && !inl) { w[1] = iv.x; w[2] = cnt; }
         }
         bucket[t] = make_uint4(w[0], w[1], w[2], w[3]);
     }
@@ -65,19 +71,16 @@ __global__ void __launch_bounds__(256) k_build_bucket(const uint2* __restrict__ 
 
 // ---- per-wave LDS -------------------------------------------------------------------------------------------------------------------
 struct GmBucketLds {
-    uint4 zero[(2 * 256 + 3 * 2 * GMB_TSZ + 2 * 32) / 4];      // filter | keys | vals | step masks | b = 0 counts: zeroed by every wave
-    uint32_t lb[2][GMB_LCAP];
-    uint8_t lt[2][GMB_LCAP];
+    uint4 zero[(2 * GMB_FWORDS + 2 * GMB_LCAP + 8) / 4];         // filter [2][512] | dup keys [2][32] | tag masks [2] + pad: zeroed by every wave
     uint32_t s_code[2][GMB_MAXS];                                // seeds of a half that walked again
     uint16_t s_pos[2][GMB_MAXS];
-    uint32_t ov_k[2][GMB_OV], ov_n[2][GMB_OV], ov_ot[2][GMB_OV]; // seeds with more than GMB_C hits: first SA rank, count, read offset | tag << 16
+    uint32_t ov_k[2][GMB_OV], ov_n[2][GMB_OV], ov_ot[2][GMB_OV]; // seeds with more than GMB_C hits: first SA rank, count, (read offset + 1) | tag << 16
 };
 
 __device__ __forceinline__ uint32_t gmb_half_bits(unsigned long long m, uint32_t h) { return h ? (uint32_t)(m >> 32) : (uint32_t)m; }
 // number of set bits of the lane's own half of m below the lane
 __device__ __forceinline__ uint32_t gmb_half_prefix(unsigned long long m, uint32_t h) {
-    const uint32_t all = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    return all - (h ? (uint32_t)__popc((uint32_t)m) : 0u);
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo(h ? 0u : (uint32_t)m, 0u));
 }
 __device__ __forceinline__ uint32_t gmb_pick(uint32_t h, uint32_t a0, uint32_t a1) { return h ? a1 : a0; }
 
@@ -113,11 +116,11 @@ static __device__ __attribute__((noinline)) uint32_t gm_bucket_rewalk(const GmKA
         uint32_t code = 0, hd = 0x40000000u, big_cnt = 0;
         if (act) {
             code = gmb_code_at(form, w2, m, i, cmask);
-            const uint4 rec = bucket[(size_t)code * 8u];                         // header, word 8, word 16, word 24
+            const uint4 rec = bucket[(size_t)code * 8u];                         // lane 0's part: header, first SA rank, count
             hd = rec.x; big_cnt = rec.z;
         }
         const bool empty = (hd & 0x40000000u) != 0u;
-        const uint32_t cnt = (hd & 0x80000000u) ? big_cnt : hd;
+        const uint32_t cnt = (hd & 0x80000000u) ? big_cnt : (hd & 0xFFFFu);
         const bool capped = !empty && p.hcap > 0 && cnt > p.hcap;
         const bool ok = act && !empty && !capped;
         const uint32_t bh = gmb_half_bits(__builtin_amdgcn_ballot_w64(act && !ok), h), ah = gmb_half_bits(__builtin_amdgcn_ballot_w64(act), h),
@@ -156,14 +159,22 @@ __device__ __forceinline__ uint32_t gmb_half_scan_incl(uint32_t x) {
     return v;
 }
 
+// Votes (the part of the kernel that is bound by vector issue: written for few instructions per hit).
+//   pass 1   every hit sets the bit of its window start in a 16384-bit filter of its strand with ONE returning atomic; a hit that finds
+//            the bit set (a second or later arrival: the true locus' hits but for the first, and chance collisions) leaves its window
+//            start in the strand's key list.  Nothing else per hit.
+//   sweeps   per distinct key of the list: every hit of the strand is compared with the key (subtract + compare per hit; the lane
+//            masks of a step are OR-ed in scalar registers), the lanes that match OR their seed's tag bit into the key's tag mask
+//            in LDS.  A window start's votes ARE the seeds that hold it (one hit per seed can: a seed's positions are distinct, and
+//            the clamped b = 0 never occurs here - records with an early position go to the list kernel), so
+//            votes = popcount(tag mask), NW step = its -k-th lowest bit (inc/align_seq2_raw.cpp:262-274, process_hits :28-40).
+// A strand without a second arrival has no candidate with -k >= 2: the wrong strand of a read ends after pass 1.
 template <int STEPS>
-__global__ void __launch_bounds__(64, 4) k_vote_bucket(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
+__global__ void __launch_bounds__(64, STEPS <= 4 ? 6 : 4) k_vote_bucket(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
     __shared__ GmBucketLds S;
-    uint32_t* const s_filt = reinterpret_cast<uint32_t*>(S.zero);          // [2][256]
-    uint32_t* const s_keys = s_filt + 2 * 256;                               // [2][GMB_TSZ]
-    uint32_t* const s_vals = s_keys + 2 * GMB_TSZ;
-    uint32_t* const s_mlo = s_vals + 2 * GMB_TSZ;
-    uint32_t* const s_cnt0 = s_mlo + 2 * GMB_TSZ;                            // [2][32]
+    uint32_t* const s_filt = reinterpret_cast<uint32_t*>(S.zero);          // [2][GMB_FWORDS]
+    uint32_t* const s_keys = s_filt + 2 * GMB_FWORDS;                        // [2][GMB_LCAP]
+    uint32_t* const s_tagm = s_keys + 2 * GMB_LCAP;                          // [2]
     const uint32_t r = blockIdx.x;                     // grid = n reads
     const int lane = threadIdx.x;
     const uint32_t h = (uint32_t)lane >> 5, jj = (uint32_t)lane & 31u, g = jj >> 3, q = (uint32_t)lane & 7u;
@@ -178,7 +189,7 @@ __global__ void __launch_bounds__(64, 4) k_vote_bucket(GmDevIndex ix, GmDevParam
     const uint32_t i_reg = jj * jump;
     const bool inrow = i_reg + m <= 16u * w2;
     const uint32_t o = inrow ? 2u * (16u * w2 - i_reg - m) : 0u;
-    const uint32_t hdr = row[0], f0 = form[o >> 5], f1 = form[(o >> 5) + 1u];
+    const uint32_t hdr_v = row[0], f0 = form[o >> 5], f1 = form[(o >> 5) + 1u];
     asm volatile("" :: "v"(f0), "v"(f1));
     // the LDS structures are zeroed under that trip
     {
@@ -186,6 +197,7 @@ __global__ void __launch_bounds__(64, 4) k_vote_bucket(GmDevIndex ix, GmDevParam
 #pragma unroll
         for (int k = 0; k < (NZ + 63) / 64; ++k) if (lane + 64 * k < NZ) S.zero[lane + 64 * k] = make_uint4(0u, 0u, 0u, 0u);
     }
+    const uint32_t hdr = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr_v);           // the same word in every lane: scalar from here on
     const uint32_t L = hdr & 0xFFFFu;
     const bool strand_on = h ? (p.neg_strand != 0) : (p.pos_strand != 0);
     if ((hdr >> 17) & 1u) {                           // status != 0 (too short / too poor): nothing to look up, on either strand
@@ -195,9 +207,10 @@ __global__ void __launch_bounds__(64, 4) k_vote_bucket(GmDevIndex ix, GmDevParam
     const uint32_t last = L - m;
     uint32_t ns_h;                                    // seeds of this lane's half
     bool listed = false;                              // the half's seed row is in HBM (serial walk of a read with a non-ACGT base)
-    uint32_t cd[STEPS], of[STEPS], cnt[STEPS];
+    uint32_t cd[STEPS], of1[STEPS];                   // code and read offset + 1 of the seed whose record this lane's group fetches in step st
     uint4 rc[STEPS];
-    bool sv[STEPS];
+    uint4 hd4 = make_uint4(0u, 0u, 0u, 0u);           // lanes q < STEPS: lane 0's part of the record of seed 4 q + g {header, first SA rank, count, -}
+    uint32_t hcode = 0, hof1 = 0;                     // ... its code and read offset + 1
     if ((hdr >> 16) & 1u) {
         // a base that is not ACGT: the 2-bit forms cannot say where.  Lane 0 walks each strand like k_seed does, into the read x
         // strand's row in HBM, and the list kernel votes.
@@ -210,9 +223,10 @@ __global__ void __launch_bounds__(64, 4) k_vote_bucket(GmDevIndex ix, GmDevParam
         n0 = (uint32_t)__builtin_amdgcn_readlane((int)n0, 0); n1 = (uint32_t)__builtin_amdgcn_readlane((int)n1, 0);
         ns_h = h ? n1 : n0;
         if (ns_h > b.max_seeds) ns_h = b.max_seeds;
+        if (ns_h > 32u) ns_h = 32u;
         listed = true;
 #pragma unroll
-        for (int st = 0; st < STEPS; ++st) { sv[st] = false; cd[st] = 0; of[st] = 0; cnt[st] = 0; rc[st] = make_uint4(~0u, ~0u, ~0u, ~0u); }
+        for (int st = 0; st < STEPS; ++st) { cd[st] = 0; of1[st] = 0; rc[st] = make_uint4(0u, 0u, 0u, 0u); }
     } else {
         const bool act = strand_on && i_reg < last;
         const uint32_t code = act ? (uint32_t)((((unsigned long long)f1 << 32) | f0) >> (o & 31u)) & cmask : 0u;
@@ -220,37 +234,40 @@ __global__ void __launch_bounds__(64, 4) k_vote_bucket(GmDevIndex ix, GmDevParam
         if (ns_h > 4u * STEPS) ns_h = 4u * STEPS;                                // (the host launches a form with enough slots)
         bool walked = false;
         for (int attempt = 0; attempt < 2; ++attempt) {
-            // records of the half's seeds: step st, group g -> seed 4 st + g, its code from the lane that computed it (or from the walk)
+            // records of the half's seeds: step st, group g -> seed 4 st + g, its code from the lane that computed it (or from the walk);
+            // lanes q < STEPS also fetch lane 0's part of the record of seed 4 q + g: all headers of a half are looked at ONCE
+            const uint32_t hslot = 4u * q + g;
+            if (attempt == 0) {
 #pragma unroll
-            for (int st = 0; st < STEPS; ++st) {
-                const uint32_t slot = 4u * st + g;
-                if (attempt == 0) {
+                for (int st = 0; st < STEPS; ++st) {
+                    const uint32_t slot = 4u * st + g;
                     cd[st] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane & 32u) + slot) << 2, (int)code);
-                    of[st] = slot * jump;
-                    sv[st] = slot < ns_h;
-                } else if (walked) {
-                    sv[st] = slot < ns_h;
-                    cd[st] = sv[st] ? S.s_code[h][slot] : 0u;
-                    of[st] = sv[st] ? S.s_pos[h][slot] : 0u;
+                    of1[st] = slot * jump + 1u;
                 }
-            }
+                hcode = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane & 32u) + (hslot & 31u)) << 2, (int)code);
+                hof1 = hslot * jump + 1u;
+            } else if (walked) {
 #pragma unroll
-            for (int st = 0; st < STEPS; ++st) {
-                if (attempt == 0 || walked) {
-                    if (sv[st]) rc[st] = bucket[(size_t)cd[st] * 8u + q];
-                    else rc[st] = make_uint4(~0u, ~0u, ~0u, ~0u);
+                for (int st = 0; st < STEPS; ++st) {
+                    const uint32_t slot = 4u * st + g;
+                    cd[st] = slot < ns_h ? S.s_code[h][slot] : 0u;
+                    of1[st] = slot < ns_h ? S.s_pos[h][slot] + 1u : 0u;
                 }
+                hcode = (q < (uint32_t)STEPS && hslot < ns_h) ? S.s_code[h][hslot] : 0u;
+                hof1 = (q < (uint32_t)STEPS && hslot < ns_h) ? S.s_pos[h][hslot] + 1u : 0u;
             }
-            // headers (lane q = 0 of each group): hit count, or what makes the walk slide
-            bool fail = false;
+            if (attempt == 0 || walked) {
 #pragma unroll
-            for (int st = 0; st < STEPS; ++st) {
-                const uint32_t hd = rc[st].x;
-                const bool head = q == 0u && sv[st];
-                const bool big = (hd & 0x80000000u) != 0u, empty = (hd & 0x40000000u) != 0u;
-                cnt[st] = head ? (big ? rc[st].z : empty ? 0u : hd) : 0u;
-                fail |= head && (empty || (p.hcap > 0 && cnt[st] > p.hcap));
+                for (int st = 0; st < STEPS; ++st) {
+                    if (4u * st + g < ns_h && q != 0u) rc[st] = bucket[(size_t)cd[st] * 8u + q];
+                    else rc[st] = make_uint4(0u, 0u, 0u, 0u);
+                }
+                if (q < (uint32_t)STEPS && hslot < ns_h) hd4 = bucket[(size_t)hcode * 8u];
+                else hd4 = make_uint4(0u, 0u, 0u, 0u);
             }
+            const bool empty = (hd4.x & 0x40000000u) != 0u;
+            const uint32_t hc = (hd4.x & 0x80000000u) ? hd4.z : (hd4.x & 0xFFFFu);
+            const bool fail = empty || (p.hcap > 0 && hc > p.hcap);
             const unsigned long long fm = __builtin_amdgcn_ballot_w64(fail);
             if (attempt == 1 || fm == 0ull) break;
             walked = gmb_half_bits(fm, h) != 0u;
@@ -259,19 +276,14 @@ __global__ void __launch_bounds__(64, 4) k_vote_bucket(GmDevIndex ix, GmDevParam
         }
     }
     // ---- seeds and SA hits of the two read x strands (k_heavy_collect sums them into the work counters and routes the heavy ones) ----
-    uint32_t c_lane = 0;
-    bool huge = false;
-    GmSeed sd_list; sd_list.k = 0; sd_list.l = 0; sd_list.pos = 0;
+    uint32_t c_lane;
     if (listed) {
-        if (jj < ns_h) sd_list = b.seeds[(size_t)rs * b.max_seeds + jj];
-        c_lane = jj < ns_h ? sd_list.l - sd_list.k + 1u : 0u;
-        huge = c_lane > (1u << 24);
-    } else {
-#pragma unroll
-        for (int st = 0; st < STEPS; ++st) { c_lane += cnt[st]; huge |= cnt[st] > (1u << 24); }
-    }
+        GmSeed sd; sd.k = 1; sd.l = 0;
+        if (jj < ns_h) sd = b.seeds[(size_t)rs * b.max_seeds + jj];
+        c_lane = sd.l - sd.k + 1u;
+    } else c_lane = (hd4.x & 0x40000000u) ? 0u : (hd4.x & 0x80000000u) ? hd4.z : (hd4.x & 0xFFFFu);
     uint32_t E0, E1;
-    if (__builtin_amdgcn_ballot_w64(huge) != 0ull) {  // the 32-bit sums could overflow: saturate like k_seed
+    if (__builtin_amdgcn_ballot_w64(c_lane > (1u << 24)) != 0ull) {               // the 32-bit sums could overflow: saturate like k_seed
         unsigned long long e64 = c_lane;
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) e64 += __shfl_xor(e64, off);
@@ -292,208 +304,143 @@ __global__ void __launch_bounds__(64, 4) k_vote_bucket(GmDevIndex ix, GmDevParam
     const uint32_t E_h = gmb_pick(h, E0, E1);
     const bool heavy_h = ns_h != 0u && E_h > p.heavy_min;                         // sorted-key path (gm_heavy.hip), routed by k_heavy_collect
     const bool cut = p.nw && p.fast;                                             // --fast: only the first seed is looked at (:309-312)
-    uint32_t n_ov_h = 0;
-    uint32_t Ev_h = E_h;                                                          // hits this half would vote on
+    bool hvalid = !listed && q < (uint32_t)STEPS && 4u * q + g < ns_h;            // this lane holds a seed's header
+    uint32_t Ev_h = E_h, n_ov_h = 0;
+    bool early_h = false;
     if (!listed) {
-        if (cut) {
-#pragma unroll
-            for (int st = 0; st < STEPS; ++st) { if (st > 0 || g != 0u) { sv[st] = false; cnt[st] = 0u; rc[st] = make_uint4(~0u, ~0u, ~0u, ~0u); } }
-            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cnt[0], 0), c1 = (uint32_t)__builtin_amdgcn_readlane((int)cnt[0], 32);
+        if (cut) {                                    // seed 0 of each half only: step 0, group 0
+            hvalid = hvalid && q == 0u && g == 0u;
+            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)c_lane, 0), c1 = (uint32_t)__builtin_amdgcn_readlane((int)c_lane, 32);
             Ev_h = gmb_pick(h, c0, c1);
-        }
-        // seeds with more than GMB_C hits: descriptors in LDS, their hits come from the suffix array
 #pragma unroll
-        for (int st = 0; st < STEPS; ++st) {
-            const bool ov = q == 0u && sv[st] && (rc[st].x & 0x80000000u) != 0u;
-            const unsigned long long om = __builtin_amdgcn_ballot_w64(ov);
-            if (om != 0ull) {                         // wave-uniform
-                const uint32_t at = n_ov_h + gmb_half_prefix(om, h);
-                if (ov && at < GMB_OV) { S.ov_k[h][at] = rc[st].y; S.ov_n[h][at] = cnt[st]; S.ov_ot[h][at] = of[st] | ((4u * st + g) << 16); }
-                n_ov_h += (uint32_t)__popc(gmb_half_bits(om, h));
-            }
-            if (q == 0u) { rc[st].x = ~0u; if (ov) { rc[st].y = ~0u; rc[st].z = ~0u; } }      // header words are not positions
+            for (int st = 0; st < STEPS; ++st) if (st > 0 || g != 0u) rc[st] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        early_h = gmb_half_bits(__builtin_amdgcn_ballot_w64(hvalid && (hd4.x & 0x20000000u) != 0u), h) != 0u;
+        // seeds with more than GMB_C hits: descriptors in LDS, their hits come from the suffix array
+        const bool ov = hvalid && (hd4.x & 0x80000000u) != 0u;
+        const unsigned long long om = __builtin_amdgcn_ballot_w64(ov);
+        if (om != 0ull) {                             // wave-uniform
+            const uint32_t at = gmb_half_prefix(om, h);
+            if (ov && at < GMB_OV) { S.ov_k[h][at] = hd4.y; S.ov_n[h][at] = hd4.z; S.ov_ot[h][at] = hof1 | ((4u * q + g) << 16); }
+            n_ov_h = (uint32_t)__popc(gmb_half_bits(om, h));
         }
     }
-    const bool big_h = ns_h != 0u && !heavy_h && (listed || Ev_h > GMB_ECAP || n_ov_h > GMB_OV);
+    const bool big_h = ns_h != 0u && !heavy_h && (listed || early_h || Ev_h > GMB_ECAP || n_ov_h > GMB_OV);
     bool vote_h = ns_h != 0u && !heavy_h && !big_h;
     // halves that leave: their seed rows {first SA rank, last SA rank, read offset} for the kernel they go to
     auto write_rows = [&](const bool which) {
-        if (listed) return;
-#pragma unroll
-        for (int st = 0; st < STEPS; ++st) {
-            const uint32_t slot = 4u * st + g;
-            if (which && q == 0u && slot < ns_h && slot < b.max_seeds) {
-                const uint2 iv = p.kmer_tab[cd[st]];
-                GmSeed sd; sd.k = iv.x; sd.l = iv.y; sd.pos = of[st];
-                b.seeds[(size_t)rs * b.max_seeds + slot] = sd;
-            }
+        if (which && !listed && q < (uint32_t)STEPS && 4u * q + g < ns_h && 4u * q + g < b.max_seeds) {
+            const uint2 iv = p.kmer_tab[hcode];
+            GmSeed sd; sd.k = iv.x; sd.l = iv.y; sd.pos = hof1 - 1u;
+            b.seeds[(size_t)rs * b.max_seeds + 4u * q + g] = sd;
         }
     };
     if (__builtin_amdgcn_ballot_w64(heavy_h || big_h) != 0ull) {
         write_rows(heavy_h || big_h);
         if (jj == 0u && big_h) { const uint32_t at = atomicAdd(b.n_big, 1u); b.big_list[at] = rs; }
     }
-    if (__builtin_amdgcn_ballot_w64(vote_h) == 0ull) return;
+    const unsigned long long vmask = __builtin_amdgcn_ballot_w64(vote_h);
+    if (vmask == 0ull) return;
     const uint32_t no0 = (uint32_t)__builtin_amdgcn_readlane((int)(vote_h ? n_ov_h : 0u), 0), no1 = (uint32_t)__builtin_amdgcn_readlane((int)(vote_h ? n_ov_h : 0u), 32);
     const uint32_t no_max = no0 > no1 ? no0 : no1;
     __syncthreads();                                  // zeroed structures + descriptors (one wave: a wait, not a rendezvous)
 
-    uint32_t* const filt = s_filt + h * 256;
-    uint32_t* const cnt0 = s_cnt0 + h * 32;
-    const uint32_t thr = (uint32_t)(p.kmin < 1 ? 1 : p.kmin);
-    const uint32_t need = thr >= 2u ? 2u : 1u;
-    // ---- pass 1: every hit sets "seen", or "seen again" when it finds "seen" set; b = 0 votes are counted per seed ----
-    auto pass1 = [&](const uint32_t v, const uint32_t off, const uint32_t tag, const bool en) {
-        const bool valid = en && v != 0xFFFFFFFFu;
-        const uint32_t bp = __builtin_elementwise_sub_sat(v, off);                // :267
-        if (valid && bp == 0u) atomicAdd(&cnt0[tag], 1u);
-        if (valid && bp != 0u) {
-            const uint32_t h2 = __umul24(bp, 0x9E3779u) >> 12, sh = (h2 >> 8 & 15u) << 1;
-            const uint32_t old = atomicOr(&filt[h2 & 255u], 1u << sh);
-            if ((old >> sh) & 1u) atomicOr(&filt[h2 & 255u], 2u << sh);
+    uint32_t* const filt = s_filt + h * GMB_FWORDS;
+    uint32_t* const keys = s_keys + h * GMB_LCAP;
+    // ---- pass 1 ----
+    uint32_t lc_h = 0;                                // second-or-later arrivals of this half so far
+    auto pass1 = [&](const uint32_t v, const uint32_t off1) {
+        const uint32_t bp = v - off1;                 // window start (:267; never clamped here: v > off1 for every position of a voting half)
+        bool dup = false;
+        if (vote_h && v != 0u) {
+            const uint32_t pr = __umul24(bp, 0x9E3779u);
+            const uint32_t old = atomicOr(&filt[pr >> 23], 1u << ((pr >> 18) & 31u));
+            dup = ((old >> ((pr >> 18) & 31u)) & 1u) != 0u;
+        }
+        const unsigned long long dm = __builtin_amdgcn_ballot_w64(dup);
+        if (dm != 0ull) {                             // wave-uniform
+            const uint32_t at = lc_h + gmb_half_prefix(dm, h);
+            if (dup && at < GMB_LCAP) keys[at] = bp;
+            lc_h += (uint32_t)__popc(gmb_half_bits(dm, h));
         }
     };
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
-        const uint32_t tag = 4u * st + g;
-        pass1(rc[st].x, of[st], tag, vote_h);
-        pass1(rc[st].y, of[st], tag, vote_h);
-        if (__builtin_amdgcn_ballot_w64(vote_h && rc[st].z != 0xFFFFFFFFu) != 0ull) pass1(rc[st].z, of[st], tag, vote_h);      // counts >= 16
-        if (__builtin_amdgcn_ballot_w64(vote_h && rc[st].w != 0xFFFFFFFFu) != 0ull) pass1(rc[st].w, of[st], tag, vote_h);      // counts >= 24
+        pass1(rc[st].x, of1[st]);
+        if (__builtin_amdgcn_ballot_w64(rc[st].y != 0u) != 0ull) pass1(rc[st].y, of1[st]);      // counts >= 8
+        if (__builtin_amdgcn_ballot_w64(rc[st].z != 0u) != 0ull) pass1(rc[st].z, of1[st]);      // counts >= 15
+        if (__builtin_amdgcn_ballot_w64(rc[st].w != 0u) != 0ull) pass1(rc[st].w, of1[st]);      // counts >= 22
     }
     for (uint32_t d = 0; d < no_max; ++d) {           // seeds with more than GMB_C hits: 32 ranks of the suffix array per half and round
         const bool en = vote_h && d < n_ov_h;
         const uint32_t k = en ? S.ov_k[h][d] : 0u, n = en ? S.ov_n[h][d] : 0u, ot = en ? S.ov_ot[h][d] : 0u;
         for (uint32_t c = 0; __builtin_amdgcn_ballot_w64(32u * c < n) != 0ull; ++c) {
             const uint32_t idx = 32u * c + jj;
-            const uint32_t v = idx < n ? ix.full_sa[k + idx] : 0xFFFFFFFFu;
-            pass1(v, ot & 0xFFFFu, ot >> 16, en);
+            pass1(idx < n ? ix.full_sa[k + idx] + 1u : 0u, ot & 0xFFFFu);
         }
     }
+    const unsigned long long anyd = __builtin_amdgcn_ballot_w64(lc_h != 0u);
+    if (anyd == 0ull) return;                         // no second arrival on either strand: no window start with two votes
     __syncthreads();
-    // ---- pass 2: the hits whose slot holds "seen again" (or "seen" with -k 1), compacted into the half's list ----
-    uint32_t lc_h = 0;
-    auto pass2 = [&](const uint32_t v, const uint32_t off, const uint32_t tag, const bool en) {
-        const bool valid = en && v != 0xFFFFFFFFu;
-        const uint32_t bp = __builtin_elementwise_sub_sat(v, off);
-        const uint32_t h2 = __umul24(bp, 0x9E3779u) >> 12, sh = (h2 >> 8 & 15u) << 1;
-        const bool reached = valid && bp != 0u && ((filt[h2 & 255u] >> sh) & need) != 0u;
-        const unsigned long long rm = __builtin_amdgcn_ballot_w64(reached);
-        if (rm != 0ull) {                             // wave-uniform
-            const uint32_t at = lc_h + gmb_half_prefix(rm, h);
-            if (reached && at < GMB_LCAP) { S.lb[h][at] = bp; S.lt[h][at] = (uint8_t)tag; }
-            lc_h += (uint32_t)__popc(gmb_half_bits(rm, h));
-        }
-    };
+    if (__builtin_amdgcn_ballot_w64(vote_h && lc_h > GMB_LCAP) != 0ull) {
+        // more second arrivals than the key list holds (a repeat-rich read): the half goes to the list kernel after all
+        const bool over_h = vote_h && lc_h > GMB_LCAP;
+        write_rows(over_h);
+        if (jj == 0u && over_h) { const uint32_t at = atomicAdd(b.n_big, 1u); b.big_list[at] = rs; }
+        if (over_h) { vote_h = false; lc_h = 0; }
+        if (__builtin_amdgcn_ballot_w64(lc_h != 0u) == 0ull) return;
+    }
+    // ---- sweeps: one per distinct key of a half's list (both halves in the same instructions) ----
+    uint32_t mykey = jj < lc_h ? keys[jj] : 0u;       // lane jj holds list entry jj of its half; 0 = none / done
+    uint32_t n_em_h = 0;                              // candidates of this half so far
+    const uint32_t shard = (2u * blockIdx.x + h) & (GM_NSHARD - 1);
+    for (;;) {
+        const unsigned long long rem = __builtin_amdgcn_ballot_w64(mykey != 0u);
+        if (rem == 0ull) break;
+        // the key of each half: its first remaining entry
+        const uint32_t r0 = (uint32_t)rem, r1 = (uint32_t)(rem >> 32);
+        const uint32_t k0 = r0 ? (uint32_t)__builtin_amdgcn_readlane((int)mykey, __builtin_ctz(r0)) : 0u;
+        const uint32_t k1 = r1 ? (uint32_t)__builtin_amdgcn_readlane((int)mykey, 32 + __builtin_ctz(r1)) : 0u;
+        const uint32_t key = gmb_pick(h, k0, k1);     // 0: this half has no key left (no hit has window start 0 here)
+        if (mykey == key) mykey = 0u;                 // every list entry with this key is done
 #pragma unroll
-    for (int st = 0; st < STEPS; ++st) {
-        const uint32_t tag = 4u * st + g;
-        pass2(rc[st].x, of[st], tag, vote_h);
-        pass2(rc[st].y, of[st], tag, vote_h);
-        if (__builtin_amdgcn_ballot_w64(vote_h && rc[st].z != 0xFFFFFFFFu) != 0ull) pass2(rc[st].z, of[st], tag, vote_h);
-        if (__builtin_amdgcn_ballot_w64(vote_h && rc[st].w != 0xFFFFFFFFu) != 0ull) pass2(rc[st].w, of[st], tag, vote_h);
-    }
-    for (uint32_t d = 0; d < no_max; ++d) {
-        const bool en = vote_h && d < n_ov_h;
-        const uint32_t k = en ? S.ov_k[h][d] : 0u, n = en ? S.ov_n[h][d] : 0u, ot = en ? S.ov_ot[h][d] : 0u;
-        for (uint32_t c = 0; __builtin_amdgcn_ballot_w64(32u * c < n) != 0ull; ++c) {
-            const uint32_t idx = 32u * c + jj;
-            const uint32_t v = idx < n ? ix.full_sa[k + idx] : 0xFFFFFFFFu;
-            pass2(v, ot & 0xFFFFu, ot >> 16, en);
+        for (int st = 0; st < STEPS; ++st) {
+            bool mt = (rc[st].x - of1[st]) == key;
+            mt |= (rc[st].y - of1[st]) == key;
+            if (__builtin_amdgcn_ballot_w64(rc[st].z != 0u) != 0ull) { mt |= (rc[st].z - of1[st]) == key; mt |= (rc[st].w - of1[st]) == key; }
+            if (mt && key != 0u) atomicOr(&s_tagm[h], 1u << (4u * st + g));
         }
-    }
-    __syncthreads();
-    // ---- the list through the exact table of the half ----
-    uint32_t* const keys = s_keys + h * GMB_TSZ; uint32_t* const vals = s_vals + h * GMB_TSZ; uint32_t* const mlo = s_mlo + h * GMB_TSZ;
-    bool full = lc_h > GMB_LCAP;
-    uint32_t nkeys_h = 0;
-    const uint32_t lc0 = (uint32_t)__builtin_amdgcn_readlane((int)lc_h, 0), lc1 = (uint32_t)__builtin_amdgcn_readlane((int)lc_h, 32);
-    const uint32_t lc_max = (lc0 > lc1 ? lc0 : lc1) > GMB_LCAP ? GMB_LCAP : (lc0 > lc1 ? lc0 : lc1);
-    for (uint32_t c = 0; 32u * c < lc_max; ++c) {
-        const uint32_t idx = 32u * c + jj;
-        bool fresh = false;
-        if (vote_h && idx < lc_h && idx < GMB_LCAP) {
-            const uint32_t bp = S.lb[h][idx], t = S.lt[h][idx];
-            uint32_t slot = (bp * 0x9E3779B1u) >> 25;
-            uint32_t old;
-            int probes = 0;
-            while ((old = atomicCAS(&keys[slot], 0u, bp)) != 0u && old != bp && ++probes < GMB_TSZ) slot = (slot + 1) & (GMB_TSZ - 1);
-            fresh = old == 0u;
-            if (!(old == 0u || old == bp)) full = true;
-            else { atomicAdd(&vals[slot], 1u); atomicOr(&mlo[slot], 1u << t); }
-        }
-        nkeys_h += (uint32_t)__popc(gmb_half_bits(__builtin_amdgcn_ballot_w64(fresh), h));
-    }
-    __syncthreads();
-    {   // a half whose list or table filled up goes to the global-table kernel (its seed row first)
-        const unsigned long long fmask = __builtin_amdgcn_ballot_w64(vote_h && (full || nkeys_h > (uint32_t)(GMB_TSZ * 3 / 4)));
-        if (fmask != 0ull) {
-            const bool over_h = gmb_half_bits(fmask, h) != 0u;
-            write_rows(over_h);
-            if (over_h && jj == 0u) {
-                b.rs_overflow[rs] = 1;
-                const uint32_t j = atomicAdd(b.n_retry, 1u);
-                const uint32_t want = 2 * Ev_h; uint32_t sz = 1024; while (sz < want && sz < 0x80000000u) sz <<= 1;
-                const unsigned long long off = atomicAdd(&b.counters[GMK_HEAVY_SLOTS], (unsigned long long)sz);
-                b.retry_list[j] = rs;
-                b.retry_off[j] = off;
-                atomicAdd(&b.counters[GMK_OVERFLOW_RS], 1ull);
+        for (uint32_t d = 0; d < no_max; ++d) {
+            const bool en = vote_h && d < n_ov_h;
+            const uint32_t k = en ? S.ov_k[h][d] : 0u, n = en ? S.ov_n[h][d] : 0u, ot = en ? S.ov_ot[h][d] : 0u;
+            for (uint32_t c = 0; __builtin_amdgcn_ballot_w64(32u * c < n) != 0ull; ++c) {
+                const uint32_t idx = 32u * c + jj;
+                const uint32_t v = idx < n ? ix.full_sa[k + idx] + 1u : 0u;
+                if (v != 0u && key != 0u && v - (ot & 0xFFFFu) == key) atomicOr(&s_tagm[h], 1u << (ot >> 16));
             }
-            if (over_h) vote_h = false;
-            if (__builtin_amdgcn_ballot_w64(vote_h) == 0ull) return;
         }
-    }
-    // ---- candidates: four table slots per lane; a half with at most GM_FIXED_C of them stores into its own slots ----
-    {
-        bool em[4]; uint32_t ky[4], stp[4];
-        uint32_t n_h = 0, before[4];
-        unsigned long long ms[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t slot = (uint32_t)(u * 32) + jj;
-            const uint32_t key = keys[slot], v = vals[slot];
-            em[u] = vote_h && key != 0u && v >= (uint32_t)p.kmin;
-            ky[u] = key; stp[u] = 0;
-            if (em[u]) {
-                if (p.nw) {
-                    uint32_t mm = mlo[slot];
-                    for (int rr = 1; rr < p.kmin; ++rr) mm &= mm - 1;
-                    stp[u] = mm ? (uint32_t)(__ffs((int)mm) - 1) : 0u;
-                } else stp[u] = v > 65535u ? 65535u : v;
+        __syncthreads();
+        // the key's votes = the seeds that hold it
+        const uint32_t tm = s_tagm[h];
+        const uint32_t votes = (uint32_t)__popc(tm);
+        const bool em = jj == 0u && key != 0u && votes >= (uint32_t)p.kmin;
+        if (jj == 0u) s_tagm[h] = 0u;
+        if (__builtin_amdgcn_ballot_w64(em) != 0ull) {
+            uint32_t step;
+            if (p.nw) { uint32_t mm = tm; for (int rr = 1; rr < p.kmin; ++rr) mm &= mm - 1; step = mm ? (uint32_t)(__ffs((int)mm) - 1) : 0u; }
+            else step = votes;
+            GmCand c;
+            c.rs = rs; c.b = key; c.step = (uint16_t)step; c.flags = 4; c.pad = 0; c.score = 0.0f;           // key = (position + 1) - (read offset + 1): the window start
+            if (em && b.fixed_cands != nullptr && n_em_h < GM_FIXED_C) b.fixed_cands[(size_t)rs * GM_FIXED_C + n_em_h] = c;
+            else if (em) {                            // more candidates than own slots (or no own slots): the shared list
+                const uint32_t at = atomicAdd(&b.shard_cnt[shard * GM_SHARD_STRIDE], 1u);
+                if (at < b.cand_region) b.cands[(size_t)shard * b.cand_region + at] = c;
             }
-            ms[u] = __builtin_amdgcn_ballot_w64(em[u]);
-            before[u] = n_h + gmb_half_prefix(ms[u], h);
-            n_h += (uint32_t)__popc(gmb_half_bits(ms[u], h));
+            if (em) ++n_em_h;
         }
-        const bool fixed_h = b.fixed_cands != nullptr && n_h <= GM_FIXED_C;
-        const unsigned long long shm = __builtin_amdgcn_ballot_w64(n_h != 0u && !fixed_h);
-        uint32_t base = 0;
-        const uint32_t shard = (2u * blockIdx.x + h) & (GM_NSHARD - 1);
-        if (shm != 0ull) {                            // wave-uniform: some half needs the shared list
-            if (jj == 0u && n_h != 0u && !fixed_h) base = atomicAdd(&b.shard_cnt[shard * GM_SHARD_STRIDE], n_h);
-            base = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((uint32_t)lane & 32u) << 2, (int)base);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (em[u]) {
-                GmCand c;
-                c.rs = rs; c.b = ky[u]; c.step = (uint16_t)stp[u]; c.flags = 4; c.pad = 0; c.score = 0.0f;
-                if (fixed_h) b.fixed_cands[(size_t)rs * GM_FIXED_C + before[u]] = c;
-                else if (base + before[u] < b.cand_region) b.cands[(size_t)shard * b.cand_region + base + before[u]] = c;
-            }
-        if (jj == 0u && fixed_h && n_h != 0u) b.fixed_cnt[rs] = (uint8_t)n_h;
+        __syncthreads();
     }
-    {   // b = 0: cumulative per-seed counts (a position at the very start of the reference)
-        const uint32_t c0 = vote_h ? cnt0[jj] : 0u;
-        if (__builtin_amdgcn_ballot_w64(c0 != 0u) != 0ull) {
-            const uint32_t run = gmb_half_scan_incl(c0);
-            const uint32_t total = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane & 32u) + 31u) << 2, (int)run);
-            const uint32_t reached = gmb_half_bits(__builtin_amdgcn_ballot_w64(run >= (uint32_t)p.kmin), h);
-            const bool emit = jj == 0u && total >= (uint32_t)p.kmin;
-            const uint32_t step = p.nw ? (reached ? (uint32_t)(__ffs((int)reached) - 1) : 0u) : (total > 65535u ? 65535u : total);
-            gm_emit<GmLdsTable>(b, emit, rs, 0u, step, 4);
-        }
-    }
+    if (jj == 0u && b.fixed_cands != nullptr && n_em_h != 0u) b.fixed_cnt[rs] = (uint8_t)(n_em_h < GM_FIXED_C ? n_em_h : GM_FIXED_C);
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------------------------------------
