@@ -1275,10 +1275,27 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
     if (n_m64 > 0x7FFFFFFFull) { gm_set_error("too many matches in one batch; map the block in smaller pieces"); return GM_E_BATCH_TOO_LARGE; }
     const uint32_t n_m = (uint32_t)n_m64;
     // ---- device, part 1: everything that does not depend on the posteriors is enqueued BEFORE the host pass and runs under it ----
+    // `hits` may have been edited by the caller: everything the kernels index with is checked HERE, before the first enqueue (a match
+    // of another read would make k_traceback read rows that do not exist, a position range beyond the buffer would make k_out_items
+    // write past o_posmatch)
     uint64_t n_p = 0;
-    if (b->cache_matches == n_m64 && b->cache_hits <= hits->positions_cap) n_p = b->cache_hits;     // the result of this batch's gm_map_batch: positions share the hit CSR
-    else for (uint64_t m = 0; m < n_m64; ++m) n_p = std::max<uint64_t>(n_p, hits->matches[m].pos_end);
-    if (n_p > hits->positions_cap) { gm_set_error("gm_hits: positions out of range"); return GM_E_ARG; }
+    {
+        if (hits->match_begin[0] != 0) { gm_set_error("gm_hits: match_begin[0] must be 0"); return GM_E_ARG; }
+        bool bad = false;
+        for (uint32_t i = 0; i < n && !bad; ++i) {
+            const uint64_t m0 = hits->match_begin[i], m1 = hits->match_begin[i + 1];
+            if (m1 < m0 || m1 > n_m64) { bad = true; break; }
+            for (uint64_t m = m0; m < m1; ++m) {
+                const gm_match& mm = hits->matches[m];
+                if (mm.read != i || mm.pos_end < mm.pos_begin || mm.pos_end > hits->positions_cap || mm.first_strand > 1 || mm.first_pos >= ix->h.l_pac) { bad = true; break; }
+                n_p = std::max<uint64_t>(n_p, mm.pos_end);
+            }
+        }
+        if (bad) { gm_set_error("gm_hits: a match does not belong to its read, or its positions / first position are out of range"); return GM_E_ARG; }
+        if (b->cache_matches == n_m64 && b->cache_hits <= hits->positions_cap && b->cache_hits >= n_p) n_p = b->cache_hits;     // this batch's own gm_map_batch result: positions share the hit CSR
+        for (uint64_t q = 0; q < n_p; ++q) if (hits->positions[q].strand > 1 || hits->positions[q].pos >= ix->h.l_pac) { bad = true; break; }
+        if (bad) { gm_set_error("gm_hits: a position is outside the reference"); return GM_E_ARG; }
+    }
     const uint32_t ops_words = gm_ops_words(b->stride), codes_stride = 32u * ops_words;
     const bool nuc = p->mode != GM_MODE_NORMAL && ix->nuc_on;
     if (b->g_matches.ensure((size_t)n_m * sizeof(GmDevMatch)) || b->g_positions.ensure((size_t)(n_p + 1) * sizeof(GmDevPos)) ||
@@ -1312,7 +1329,6 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
     const int all = p->print_all_sam;
     const uint64_t cached_m = b->cache_matches, cached_h = b->cache_hits;
     const uint32_t* mhit = b->h_mhit.as<uint32_t>(); const float* ord = b->h_ord.as<float>(); const double* hexp = b->h_exp.data();
-    bool bad_hits = false;
     for (uint32_t i = 0; i < n; ++i) {
         const uint64_t m0 = hits->match_begin[i], m1 = hits->match_begin[i + 1];
         if (m0 == m1) continue;
@@ -1322,7 +1338,6 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
         double best_log = e_m1, best_total = 0;
         for (uint64_t m = m0; m < m1; ++m) {
             const gm_match& mm = hits->matches[m];
-            if (mm.read != i || mm.pos_end < mm.pos_begin || mm.pos_end > n_p) bad_hits = true;
             // exp(align_score): the value gm_map_batch already computed for the hit that gave this match its score, when the caller has
             // left the match as it was (exp is a function of the score alone, so equal score bits are all that has to hold)
             double lg;
@@ -1339,7 +1354,6 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
             mapq[best] = mapq_of(best_total);
         }
     }
-    if (bad_hits) { HIPCHK(hipStreamSynchronize(st)); gm_set_error("gm_hits: a match does not belong to its read (or its positions are out of range)"); return GM_E_ARG; }
     pc.lap("fp64");
     // ---- device, part 2 ----
     HIPCHK(hipMemcpyAsync(b->o_post.p, post, (size_t)n_m * 4, hipMemcpyHostToDevice, st));

@@ -275,6 +275,13 @@ __global__ void __launch_bounds__(64, STEPS <= 4 ? 6 : 4) k_vote_bucket(GmDevInd
             if (walked) ns_h = nw;
         }
     }
+    if (p.dbg & 256) {                                // timing experiment (GM_DBG): stop when the records have arrived
+        uint32_t acc = hd4.x;
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) acc ^= rc[st].x ^ rc[st].y ^ rc[st].z ^ rc[st].w;
+        if (acc == 0x12345u) b.counters[GMK_DBG0] = acc;
+        return;
+    }
     // ---- seeds and SA hits of the two read x strands (k_heavy_collect sums them into the work counters and routes the heavy ones) ----
     uint32_t c_lane;
     if (listed) {
@@ -340,7 +347,7 @@ __global__ void __launch_bounds__(64, STEPS <= 4 ? 6 : 4) k_vote_bucket(GmDevInd
         if (jj == 0u && big_h) { const uint32_t at = atomicAdd(b.n_big, 1u); b.big_list[at] = rs; }
     }
     const unsigned long long vmask = __builtin_amdgcn_ballot_w64(vote_h);
-    if (vmask == 0ull) return;
+    if (vmask == 0ull || (p.dbg & 512)) return;      // (GM_DBG 512: timing experiment, stop before the votes)
     const uint32_t no0 = (uint32_t)__builtin_amdgcn_readlane((int)(vote_h ? n_ov_h : 0u), 0), no1 = (uint32_t)__builtin_amdgcn_readlane((int)(vote_h ? n_ov_h : 0u), 32);
     const uint32_t no_max = no0 > no1 ? no0 : no1;
     __syncthreads();                                  // zeroed structures + descriptors (one wave: a wait, not a rendezvous)
@@ -348,20 +355,25 @@ __global__ void __launch_bounds__(64, STEPS <= 4 ? 6 : 4) k_vote_bucket(GmDevInd
     uint32_t* const filt = s_filt + h * GMB_FWORDS;
     uint32_t* const keys = s_keys + h * GMB_LCAP;
     // ---- pass 1 ----
-    uint32_t lc_h = 0;                                // second-or-later arrivals of this half so far
+    uint32_t lc_h = 0;                                // keys in this half's list so far
+    uint32_t known = 0;                               // the half's most recent key: the true locus' hits arrive one after the other, only the first is listed
     auto pass1 = [&](const uint32_t v, const uint32_t off1) {
         const uint32_t bp = v - off1;                 // window start (:267; never clamped here: v > off1 for every position of a voting half)
         bool dup = false;
-        if (vote_h && v != 0u) {
-            const uint32_t pr = __umul24(bp, 0x9E3779u);
-            const uint32_t old = atomicOr(&filt[pr >> 23], 1u << ((pr >> 18) & 31u));
-            dup = ((old >> ((pr >> 18) & 31u)) & 1u) != 0u;
+        if (vote_h && v != 0u) {                      // filter slot = the low 14 bits of the window start (chance hits are uniform, equal window starts meet)
+            const uint32_t old = atomicOr(&filt[(bp >> 5) & (GMB_FWORDS - 1)], 1u << (bp & 31u));
+            dup = ((old >> (bp & 31u)) & 1u) != 0u && bp != known;
         }
         const unsigned long long dm = __builtin_amdgcn_ballot_w64(dup);
-        if (dm != 0ull) {                             // wave-uniform
+        if (dm != 0ull) {                             // wave-uniform; rare: once per distinct window start that is met again
             const uint32_t at = lc_h + gmb_half_prefix(dm, h);
             if (dup && at < GMB_LCAP) keys[at] = bp;
             lc_h += (uint32_t)__popc(gmb_half_bits(dm, h));
+            const uint32_t d0 = (uint32_t)dm, d1 = (uint32_t)(dm >> 32);
+            const uint32_t n0 = d0 ? (uint32_t)__builtin_amdgcn_readlane((int)bp, __builtin_ctz(d0)) : 0u;
+            const uint32_t n1 = d1 ? (uint32_t)__builtin_amdgcn_readlane((int)bp, 32 + __builtin_ctz(d1)) : 0u;
+            const uint32_t nk = gmb_pick(h, n0, n1);
+            if (nk != 0u) known = nk;
         }
     };
 #pragma unroll
@@ -380,7 +392,7 @@ __global__ void __launch_bounds__(64, STEPS <= 4 ? 6 : 4) k_vote_bucket(GmDevInd
         }
     }
     const unsigned long long anyd = __builtin_amdgcn_ballot_w64(lc_h != 0u);
-    if (anyd == 0ull) return;                         // no second arrival on either strand: no window start with two votes
+    if (anyd == 0ull || (p.dbg & 1024)) return;      // (GM_DBG 1024: timing experiment, stop after pass 1)                         // no second arrival on either strand: no window start with two votes
     __syncthreads();
     if (__builtin_amdgcn_ballot_w64(vote_h && lc_h > GMB_LCAP) != 0ull) {
         // more second arrivals than the key list holds (a repeat-rich read): the half goes to the list kernel after all

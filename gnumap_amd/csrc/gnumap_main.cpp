@@ -22,6 +22,7 @@
 #include <fstream>
 #include <iostream>
 #include <map>
+#include <set>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -194,7 +195,7 @@ struct Block {
     PinVec<gm_sam_rec> recs; PinVec<char> pool; uint64_t n_recs = 0;
     int gpu = 0;
     size_t text_lo = 0, text_hi = 0; bool lazy = false;   // chunk mode: the byte range of the FASTQ text a worker still has to cut into records
-    bool malformed = false;                 // a malformed record ended this block: later blocks are dropped (the reference's parser stops there)
+    bool malformed = false;                 // chunk mode: a malformed record ended this block; the rest of the input is read again in file order with the reference's recovery
     int illumina = 0;                       // --illumina still in force when this block starts (the fallback is sticky, SeqReader.cpp:1171-1180)
     std::vector<std::string> text;          // SAM text, one piece per formatter thread
     bool failed = false;
@@ -243,8 +244,11 @@ struct FastqScanner {
         p = s; len = (size_t)(e - s); at = (size_t)(e - base) + 1;
         return true;
     }
-    // cut base[cur, limit) into records until max_reads (thread-safe: no scanner state); `stop` = a malformed record ended the input
-    static bool parse_range(const char* base, size_t& cur, size_t limit, Block& b, uint32_t max_reads, bool* stop) {
+    // Chunk mode: cut base[cur, limit) into records until max_reads (thread-safe: no scanner state).  Only well-formed records are
+    // taken here; at the first one that is not, `stop` is set and `bad_at` is where its name line starts: the driver then reads the rest
+    // of the input again from there in file order (parse_resync), because what the reference does with a malformed record depends on
+    // the lines that follow it.  `too_long` = a read longer than the kernels take (this implementation's limit, not the reference's).
+    static bool parse_range(const char* base, size_t& cur, size_t limit, Block& b, uint32_t max_reads, bool* stop, size_t* bad_at, bool* too_long) {
         b.n = 0; b.maxlen = 0;
         b.name.clear(); b.seq.clear(); b.qual.clear(); b.name_len.clear(); b.qual_len.clear(); b.len.clear();
         auto line = [&](const char*& p, size_t& len) -> bool {       // one line without its newline; false at the end of the range
@@ -261,15 +265,10 @@ struct FastqScanner {
             bool eof = false;
             while (nl == 0) { if (!line(nm, nl)) { eof = true; break; } }
             if (eof) break;
-            if (!line(sq, sl)) { sq = ""; sl = 0; }
-            if (!line(pl, pll)) { pl = ""; pll = 0; }
-            if (!line(ql, qll)) { ql = ""; qll = 0; }
-            if (nm[0] != '@' || pll == 0 || pl[0] != '+' || sl > qll) {
-                fprintf(stderr, "--ERROR at sequence %.*s (malformed FASTQ record); stopping here\n", (int)std::min<size_t>(nl, 200), nm);
-                *stop = true;
-                break;
-            }
-            if (sl > 2048) { fprintf(stderr, "read %.*s longer than 2048 bases\n", (int)std::min<size_t>(nl, 200), nm); *stop = true; break; }
+            const size_t rec_at = (size_t)(nm - base);
+            const bool l2 = line(sq, sl), l3 = line(pl, pll), l4 = line(ql, qll);
+            if (!l2 || !l3 || !l4 || nm[0] != '@' || pll == 0 || pl[0] != '+' || sl > qll) { *stop = true; *bad_at = rec_at; break; }
+            if (sl > 2048) { fprintf(stderr, "ERROR: read %.*s is longer than 2048 bases\n", (int)std::min<size_t>(nl, 200), nm); *too_long = true; break; }
             b.name.push_back(nm + 1); b.name_len.push_back((uint32_t)(nl - 1));
             b.seq.push_back(sq); b.len.push_back((uint16_t)sl);
             b.qual.push_back(ql); b.qual_len.push_back((uint32_t)qll);
@@ -279,12 +278,62 @@ struct FastqScanner {
         b.stride = std::max<uint32_t>(8, (b.maxlen + 7u) & ~7u);
         return b.n > 0;
     }
-    bool next(Block& b, uint32_t max_reads) {               // sequential mode: blocks of exactly max_reads reads
+    // File order, with the recovery of SeqReader::get_more_fastq (src/SeqReader.cpp:1060-1150): four lines are read; while the first does
+    // not start with '@' or the third not with '+', the lines are shifted up by one and one more is read; a quality line shorter than
+    // its sequence makes the reader take the next four lines instead.  The lines come from std::getline on an ifstream, whose end-of-input
+    // behaviour decides what happens to a record the input ends in: a stream that is no longer good fails WITHOUT touching the string,
+    // the end of input empties the string and sets eofbit + failbit, a last line without a newline is delivered and sets eofbit; every
+    // end-of-input test inside the recovery ends the input (a record completed by a line without a newline is lost there).
+    struct Line { const char* p = ""; size_t n = 0; char first() const { return n ? p[0] : 0; } };
+    bool rs_eof = false, rs_fail = false;
+    void rs_getline(Line& s) {
+        if (rs_eof || rs_fail) { rs_fail = true; return; }
+        if (at >= size) { s = Line(); rs_eof = rs_fail = true; return; }
+        const char* s0 = base + at;
+        const char* e = (const char*)memchr(s0, '\n', size - at);
+        s.p = s0;
+        if (e) { s.n = (size_t)(e - s0); at = (size_t)(e - base) + 1; } else { s.n = size - at; at = size; rs_eof = true; }
+    }
+    bool parse_resync(Block& b, uint32_t max_reads, bool* too_long) {
+        b.n = 0; b.maxlen = 0;
+        b.name.clear(); b.seq.clear(); b.qual.clear(); b.name_len.clear(); b.qual_len.clear(); b.len.clear();
+        Line name, seq, plus, qual;
+        while (b.n < max_reads) {
+            if (rs_eof) { done = true; break; }                                               // :1061
+            rs_getline(name);
+            while (name.n == 0 && !rs_eof) rs_getline(name);                                  // blank lines before a name :1076-1079
+            if (rs_eof) { done = true; break; }                                               // :1082
+            rs_getline(seq); rs_getline(plus); rs_getline(qual);
+            while (name.first() != '@' || plus.first() != '+' || seq.n > qual.n) {            // :1095
+                fprintf(stderr, "--Found error...atteming to resolve...\n");
+                if (name.first() != '@' || plus.first() != '+') {
+                    fprintf(stderr, "--ERROR at sequence %.*s (name[s] formatted incorrectly)\n\tTrying to recover...\n", (int)std::min<size_t>(name.n, 200), name.p);
+                    while ((name.first() != '@' || plus.first() != '+') && !rs_eof) {         // :1101-1115
+                        name = seq; seq = plus; plus = qual; rs_getline(qual);
+                        if (rs_eof) { done = true; break; }
+                    }
+                    if (done || rs_eof) { done = true; break; }
+                }
+                if (seq.n > qual.n) {                                                         // :1128-1142
+                    fprintf(stderr, "--ERROR at sequence %.*s (length of fastq and sequence not equal)\n\tTrying to recover...\n", (int)std::min<size_t>(name.n, 200), name.p);
+                    rs_getline(name); rs_getline(seq); rs_getline(plus); rs_getline(qual);
+                    if (rs_eof) { done = true; break; }
+                }
+            }
+            if (done) break;
+            if (seq.n > 2048) { fprintf(stderr, "ERROR: read %.*s is longer than 2048 bases\n", (int)std::min<size_t>(name.n, 200), name.p); *too_long = true; done = true; break; }
+            b.name.push_back(name.p + 1); b.name_len.push_back((uint32_t)(name.n - 1));
+            b.seq.push_back(seq.p); b.len.push_back((uint16_t)seq.n);
+            b.qual.push_back(qual.p); b.qual_len.push_back((uint32_t)qual.n);
+            b.maxlen = std::max<uint32_t>(b.maxlen, (uint32_t)seq.n);
+            ++b.n;
+        }
+        b.stride = std::max<uint32_t>(8, (b.maxlen + 7u) & ~7u);
+        return b.n > 0;
+    }
+    bool next(Block& b, uint32_t max_reads, bool* too_long) {    // file-order mode: blocks of exactly max_reads reads
         if (done) return false;
-        bool stop = false;
-        const bool got = parse_range(base, at, size, b, max_reads, &stop);
-        if (stop || at >= size || !got) done = true;
-        return got;
+        return parse_resync(b, max_reads, too_long);
     }
     // chunk mode: the start of the first record at or after `off` (a line starting with '@' whose next-but-one line starts with
     // '+': a quality line may start with '@' too, but then the line two below is a sequence, never '+')
@@ -554,124 +603,153 @@ int main(int argc, char** argv) {
     auto t_pipe0 = std::chrono::steady_clock::now();
     FastqScanner fq;
     if (!fq.open(o.reads)) { fprintf(stderr, "ERROR: cannot open %s\n", o.reads.c_str()); return 1; }
-    const size_t n_blocks = workers.size() * 2 + 4;                    // blocks in flight
-    std::vector<Block> blocks(n_blocks);
-    Queue<Block*> free_q, map_q, fmt_q;
-    for (auto& b : blocks) free_q.push(&b);
     std::atomic<int> failed{ 0 };
-    std::atomic<uint64_t> stop_block{ ~0ull };         // chunk mode: first block that ended in a malformed record; later blocks are dropped
     double t_scan = 0, t_fmt = 0, t_write = 0;
-    std::mutex fmt_mu;
-
-    std::thread scanner([&] {
-        uint64_t idx = 0;
-        int ill_state = o.p.illumina;
-        Block* b;
-        while (!failed && free_q.pop(b)) {
-            auto s0 = std::chrono::steady_clock::now();
-            b->lazy = false; b->malformed = false;
-            // --batch=N or --illumina (its fallback is a property of the reads in file order): blocks of N reads cut here;
-            // otherwise byte-range chunks of about that many records, cut into records by the workers in parallel
-            const bool more = (o.batch_set || o.p.illumina) ? fq.next(*b, o.batch) : fq.next_chunk(*b, o.batch);
-            t_scan += secs_since(s0);
-            if (!more) { free_q.push(b); break; }
-            b->index = idx++; b->failed = false;
-            b->illumina = ill_state;
-            if (ill_state)                              // gILLUMINA is cleared for the rest of the run by the first quality below '@'
-                for (uint32_t i = 0; i < b->n && ill_state; ++i)
-                    for (uint32_t t = 0; t < b->len[i]; ++t) if ((unsigned char)b->qual[i][t] < 64) { ill_state = 0; break; }
-            map_q.push(b);
-        }
-        map_q.close();
-    });
-    std::vector<std::thread> wth;
-    std::atomic<int> live_workers{ (int)workers.size() };
-    for (size_t k = 0; k < workers.size(); ++k)
-        wth.emplace_back([&, k] {
-            Worker& w = workers[k];
-            Block* b;
-            while (map_q.pop(b)) {
-                if (b->lazy) {                              // chunk mode: this worker cuts its byte range into records
-                    auto s0 = std::chrono::steady_clock::now();
-                    size_t cur = b->text_lo; bool stop = false;
-                    FastqScanner::parse_range(fq.base, cur, b->text_hi, *b, 16000000u, &stop);
-                    if (stop) { b->malformed = true; uint64_t cur_min = stop_block.load(); while (b->index < cur_min && !stop_block.compare_exchange_weak(cur_min, b->index)) {} }
-                    w.t_scan += secs_since(s0);
-                }
-                if (b->n == 0) { b->n_recs = 0; fmt_q.push(b); continue; }
-                if (!failed && process_block_split(w, o, *b, 0) != GM_OK) { failed = 1; }
-                if (failed) { b->failed = true; b->n_recs = 0; }
-                fmt_q.push(b);
-            }
-            if (--live_workers == 0) fmt_q.close();
-        });
-    // formatters: a block is cut into slices of records, one string each; the writer emits blocks in index order
-    std::mutex wr_mu; std::condition_variable wr_cv; std::map<uint64_t, Block*> ready; bool fmt_done = false;
-    const int n_fmt = 2;
-    std::atomic<int> live_fmt{ n_fmt };
-    std::vector<std::thread> fth;
-    for (int f = 0; f < n_fmt; ++f)
-        fth.emplace_back([&] {
-            Block* b;
-            while (fmt_q.pop(b)) {
-                auto f0 = std::chrono::steady_clock::now();
-                const gm_index* ix = gpu_ix[(size_t)b->gpu];
-                const uint32_t nr = (uint32_t)b->n_recs;
-                const int T = o.fmt_threads;
-                if ((int)b->text.size() < T) b->text.resize((size_t)T);
-                for (auto& s : b->text) s.clear();
-                run_slices(nr, T, 4096, [&](int s, uint32_t lo, uint32_t hi) {
-                    std::string& out = b->text[(size_t)s];
-                    out.reserve((size_t)(hi - lo) * 300);
-                    for (uint32_t k = lo; k < hi; ++k) { const gm_sam_rec& r = b->recs[k]; format_sam(out, ix, o.p, r, b->pool.data() + r.cigar_off, *b); }
-                });
-                { std::lock_guard<std::mutex> lk(fmt_mu); t_fmt += secs_since(f0); }
-                { std::lock_guard<std::mutex> lk(wr_mu); ready[b->index] = b; }
-                wr_cv.notify_all();
-            }
-            if (--live_fmt == 0) { { std::lock_guard<std::mutex> lk(wr_mu); fmt_done = true; } wr_cv.notify_all(); }
-        });
-    // the writer only hands out file offsets in block order; the text pieces of a block (one per formatter slice) are written by
-    // pwrite() from a few threads at once (a single write() stream tops out at ~8 GB/s of page-cache copies)
     uint64_t file_off = 0;
     { struct stat hs; if (fstat(ofd, &hs) == 0) file_off = (uint64_t)lseek(ofd, 0, SEEK_CUR); }
     auto pwrite_all = [&](const char* p, size_t n, uint64_t off) {
         while (n) { ssize_t k = ::pwrite(ofd, p, n, (off_t)off); if (k <= 0) return false; p += k; n -= (size_t)k; off += (uint64_t)k; }
         return true;
     };
-    std::thread writer([&] {
-        uint64_t next = 0;
-        for (;;) {
-            Block* b = nullptr;
-            {
-                std::unique_lock<std::mutex> lk(wr_mu);
-                wr_cv.wait(lk, [&] { return (!ready.empty() && ready.begin()->first == next) || (fmt_done && ready.empty()) || (fmt_done && failed); });
-                if (ready.empty() || ready.begin()->first != next) break;
-                b = ready.begin()->second; ready.erase(ready.begin());
+    const size_t npos = ~(size_t)0;
+    // One pass of the pipeline over the FASTQ text from fq.at on.  chunks = byte ranges cut into records by the workers in parallel
+    // (well-formed records only); returns where a malformed record starts (npos: none) - everything before it has been mapped and
+    // written, nothing after it has touched the SAM file or the coverage track: a block is mapped only once every block before it is
+    // known to be well-formed.  !chunks = file order with the reference's recovery from malformed records (--batch=N, --illumina - its
+    // fallback is a property of the reads in file order -, and the rest of an input in which a malformed record was found).
+    auto run_pass = [&](const bool chunks) -> size_t {
+        const size_t n_blocks = workers.size() * 2 + 4;                    // blocks in flight
+        std::vector<Block> blocks(n_blocks);
+        Queue<Block*> free_q, map_q, fmt_q;
+        for (auto& b : blocks) free_q.push(&b);
+        std::mutex fmt_mu;
+        // the gate of chunk mode: `parsed` = every block below it has been cut into records; `stop` = first block with a malformed record
+        struct { std::mutex mu; std::condition_variable cv; uint64_t parsed = 0; std::set<uint64_t> done; uint64_t stop = ~0ull; size_t bad_at = ~(size_t)0; } gate;
+        std::atomic<uint64_t> stop_block{ ~0ull };
+
+        std::thread scanner([&] {
+            uint64_t idx = 0;
+            int ill_state = o.p.illumina;
+            Block* b;
+            while (!failed && stop_block.load() == ~0ull && free_q.pop(b)) {
+                auto s0 = std::chrono::steady_clock::now();
+                b->lazy = false; b->malformed = false;
+                bool too_long = false;
+                const bool more = chunks ? fq.next_chunk(*b, o.batch) : fq.next(*b, o.batch, &too_long);
+                t_scan += secs_since(s0);
+                if (too_long) failed = 1;
+                if (!more || failed) { free_q.push(b); break; }
+                b->index = idx++; b->failed = false;
+                b->illumina = ill_state;
+                if (ill_state)                              // gILLUMINA is cleared for the rest of the run by the first quality below '@'
+                    for (uint32_t i = 0; i < b->n && ill_state; ++i)
+                        for (uint32_t t = 0; t < b->len[i]; ++t) if ((unsigned char)b->qual[i][t] < 64) { ill_state = 0; break; }
+                map_q.push(b);
             }
-            auto w0 = std::chrono::steady_clock::now();
-            if (!b->failed && b->index <= stop_block.load()) {
-                std::vector<uint64_t> offs(b->text.size());
-                for (size_t k = 0; k < b->text.size(); ++k) { offs[k] = file_off; file_off += b->text[k].size(); }
-                const int nt = (int)std::min<size_t>(8, b->text.size());
-                std::atomic<size_t> nextp{ 0 }; std::atomic<int> bad{ 0 };
-                auto job = [&] { for (size_t k; (k = nextp++) < b->text.size();) if (!b->text[k].empty() && !pwrite_all(b->text[k].data(), b->text[k].size(), offs[k])) bad = 1; };
-                std::vector<std::thread> ws;
-                for (int t = 1; t < nt; ++t) ws.emplace_back(job);
-                job();
-                for (auto& x : ws) x.join();
-                if (bad) { fprintf(stderr, "ERROR: write failed\n"); failed = 1; }
+            map_q.close();
+        });
+        std::vector<std::thread> wth;
+        std::atomic<int> live_workers{ (int)workers.size() };
+        for (size_t k = 0; k < workers.size(); ++k)
+            wth.emplace_back([&, k] {
+                Worker& w = workers[k];
+                Block* b;
+                while (map_q.pop(b)) {
+                    if (b->lazy) {                              // chunk mode: this worker cuts its byte range into records
+                        auto s0 = std::chrono::steady_clock::now();
+                        size_t cur = b->text_lo, bad_at = npos; bool stop = false, too_long = false;
+                        FastqScanner::parse_range(fq.base, cur, b->text_hi, *b, 16000000u, &stop, &bad_at, &too_long);
+                        if (too_long) failed = 1;
+                        w.t_scan += secs_since(s0);
+                        bool drop;
+                        {
+                            std::unique_lock<std::mutex> lk(gate.mu);
+                            if (stop && b->index < gate.stop) { gate.stop = b->index; gate.bad_at = bad_at; stop_block = b->index; b->malformed = true; }
+                            gate.done.insert(b->index);
+                            while (gate.done.count(gate.parsed)) { gate.done.erase(gate.parsed); ++gate.parsed; }
+                            gate.cv.notify_all();
+                            // nothing of this block reaches the GPU before every block below it is known to be well-formed
+                            gate.cv.wait(lk, [&] { return gate.parsed >= b->index || gate.stop < b->index || failed.load(); });
+                            drop = gate.stop < b->index;
+                        }
+                        if (drop) b->n = 0;
+                    }
+                    if (b->n == 0) { b->n_recs = 0; fmt_q.push(b); continue; }
+                    if (!failed && process_block_split(w, o, *b, 0) != GM_OK) { failed = 1; gate.cv.notify_all(); }
+                    if (failed) { b->failed = true; b->n_recs = 0; }
+                    fmt_q.push(b);
+                }
+                if (--live_workers == 0) fmt_q.close();
+            });
+        // formatters: a block is cut into slices of records, one string each; the writer emits blocks in index order
+        std::mutex wr_mu; std::condition_variable wr_cv; std::map<uint64_t, Block*> ready; bool fmt_done = false;
+        const int n_fmt = 2;
+        std::atomic<int> live_fmt{ n_fmt };
+        std::vector<std::thread> fth;
+        for (int f = 0; f < n_fmt; ++f)
+            fth.emplace_back([&] {
+                Block* b;
+                while (fmt_q.pop(b)) {
+                    auto f0 = std::chrono::steady_clock::now();
+                    const gm_index* ix = gpu_ix[(size_t)b->gpu];
+                    const uint32_t nr = (uint32_t)b->n_recs;
+                    const int T = o.fmt_threads;
+                    if ((int)b->text.size() < T) b->text.resize((size_t)T);
+                    for (auto& s : b->text) s.clear();
+                    run_slices(nr, T, 4096, [&](int s, uint32_t lo, uint32_t hi) {
+                        std::string& out = b->text[(size_t)s];
+                        out.reserve((size_t)(hi - lo) * 300);
+                        for (uint32_t k = lo; k < hi; ++k) { const gm_sam_rec& r = b->recs[k]; format_sam(out, ix, o.p, r, b->pool.data() + r.cigar_off, *b); }
+                    });
+                    { std::lock_guard<std::mutex> lk(fmt_mu); t_fmt += secs_since(f0); }
+                    { std::lock_guard<std::mutex> lk(wr_mu); ready[b->index] = b; }
+                    wr_cv.notify_all();
+                }
+                if (--live_fmt == 0) { { std::lock_guard<std::mutex> lk(wr_mu); fmt_done = true; } wr_cv.notify_all(); }
+            });
+        // the writer only hands out file offsets in block order; the text pieces of a block (one per formatter slice) are written by
+        // pwrite() from a few threads at once (a single write() stream tops out at ~8 GB/s of page-cache copies)
+        std::thread writer([&] {
+            uint64_t next = 0;
+            for (;;) {
+                Block* b = nullptr;
+                {
+                    std::unique_lock<std::mutex> lk(wr_mu);
+                    wr_cv.wait(lk, [&] { return (!ready.empty() && ready.begin()->first == next) || (fmt_done && ready.empty()) || (fmt_done && failed); });
+                    if (ready.empty() || ready.begin()->first != next) break;
+                    b = ready.begin()->second; ready.erase(ready.begin());
+                }
+                auto w0 = std::chrono::steady_clock::now();
+                if (!b->failed && b->n_recs) {
+                    std::vector<uint64_t> offs(b->text.size());
+                    for (size_t k = 0; k < b->text.size(); ++k) { offs[k] = file_off; file_off += b->text[k].size(); }
+                    const int nt = (int)std::min<size_t>(8, b->text.size());
+                    std::atomic<size_t> nextp{ 0 }; std::atomic<int> bad{ 0 };
+                    auto job = [&] { for (size_t k; (k = nextp++) < b->text.size();) if (!b->text[k].empty() && !pwrite_all(b->text[k].data(), b->text[k].size(), offs[k])) bad = 1; };
+                    std::vector<std::thread> ws;
+                    for (int t = 1; t < nt; ++t) ws.emplace_back(job);
+                    job();
+                    for (auto& x : ws) x.join();
+                    if (bad) { fprintf(stderr, "ERROR: write failed\n"); failed = 1; }
+                }
+                t_write += secs_since(w0);
+                ++next;
+                free_q.push(b);
             }
-            t_write += secs_since(w0);
-            ++next;
-            free_q.push(b);
-        }
-        free_q.close();
-    });
-    scanner.join();
-    for (auto& x : wth) x.join();
-    for (auto& x : fth) x.join();
-    writer.join();
+            free_q.close();
+        });
+        scanner.join();
+        for (auto& x : wth) x.join();
+        for (auto& x : fth) x.join();
+        writer.join();
+        return gate.bad_at;
+    };
+    const bool file_order = o.batch_set || o.p.illumina;
+    const size_t bad_at = run_pass(!file_order);
+    if (!failed && bad_at != npos) {                   // a malformed record: the reference's recovery needs the lines in file order from there on
+        fq.at = bad_at; fq.done = false;
+        run_pass(false);
+    }
     ::close(ofd);
     if (failed) return 1;
     const double t_pipe = secs_since(t_pipe0);

@@ -842,12 +842,18 @@ static void* worker(void* arg) {
     return NULL;
 }
 
-static char* read_line(FILE* f) {
+/* std::getline on an ifstream, as SeqReader::get_more_fastq uses it (SeqReader.cpp:1073-1141): a stream that is no longer good
+ * fails WITHOUT touching the string; at the end of input the string is emptied and eofbit + failbit are set; a last line without a
+ * newline is delivered and sets eofbit.  in.eof() is eofbit. */
+typedef struct { FILE* f; int eofbit, failbit; } fq_in;
+static void fq_getline(fq_in* in, char** s) {
+    if (in->eofbit || in->failbit) { in->failbit = 1; return; }
     char* line = NULL; size_t cap = 0;
-    ssize_t n = getline(&line, &cap, f);
-    if (n < 0) { free(line); return NULL; }
-    if (n > 0 && line[n - 1] == '\n') line[n - 1] = 0;
-    return line;
+    ssize_t n = getline(&line, &cap, in->f);
+    free(*s);
+    if (n < 0) { free(line); *s = strdup(""); in->eofbit = 1; in->failbit = 1; return; }
+    if (n > 0 && line[n - 1] == '\n') line[n - 1] = 0; else in->eofbit = 1;
+    *s = line;
 }
 
 int gmo_run(const gmo_index* ix, const gmo_params* p, const char* fastq, const char* out_prefix, int threads,
@@ -856,21 +862,36 @@ int gmo_run(const gmo_index* ix, const gmo_params* p, const char* fastq, const c
     FILE* f = fopen(fastq, "r");
     if (!f) return -1;
     fq_rec* recs = NULL; uint64_t n = 0, cap = 0;
-    for (;;) {                                        /* get_more_fastq SeqReader.cpp:1060-1082, well-formed records only */
+    fq_in in = { f, 0, 0 };
+    char* name = strdup(""); char* seq = strdup(""); char* plus = strdup(""); char* qual = strdup("");
+    for (;;) {                                        /* get_more_fastq SeqReader.cpp:1060-1150, incl. its recovery from malformed records */
         if (max_reads && n >= max_reads) break;
-        char* name = read_line(f);
-        while (name && name[0] == 0) { free(name); name = read_line(f); }
-        if (!name) break;
-        char* seq = read_line(f); char* plus = read_line(f); char* qual = read_line(f);
-        if (!seq || !plus || !qual || name[0] != '@' || plus[0] != '+' || strlen(seq) > strlen(qual)) {
-            free(name); free(seq); free(plus); free(qual);
-            break;
+        if (in.eofbit) break;                         /* :1061 */
+        fq_getline(&in, &name);
+        while (name[0] == 0 && !in.eofbit) fq_getline(&in, &name);      /* blank lines before a name :1076-1079 */
+        if (in.eofbit) break;                         /* :1082 */
+        fq_getline(&in, &seq); fq_getline(&in, &plus); fq_getline(&in, &qual);
+        int ended = 0;
+        while (name[0] != '@' || plus[0] != '+' || strlen(seq) > strlen(qual)) {       /* :1095 */
+            if (name[0] != '@' || plus[0] != '+') {
+                while ((name[0] != '@' || plus[0] != '+') && !in.eofbit) {             /* shift the four lines by one :1101-1115 */
+                    char* t = name; name = seq; seq = plus; plus = qual; qual = t;     /* the old name is dropped: the stream is good here, getline replaces it */
+                    fq_getline(&in, &qual);
+                    if (in.eofbit) { ended = 1; break; }
+                }
+                if (ended || in.eofbit) { ended = 1; break; }
+            }
+            if (strlen(seq) > strlen(qual)) {         /* a quality line shorter than its sequence: take the next four lines :1128-1142 */
+                fq_getline(&in, &name); fq_getline(&in, &seq); fq_getline(&in, &plus); fq_getline(&in, &qual);
+                if (in.eofbit) { ended = 1; break; }
+            }
         }
+        if (ended) break;
         if (n == cap) { cap = cap ? cap * 2 : 1024; recs = (fq_rec*)realloc(recs, sizeof(fq_rec) * cap); }
-        recs[n].name = strdup(name + 1); recs[n].seq = seq; recs[n].qual = qual; recs[n].L = (int)strlen(seq);
-        free(name); free(plus);
+        recs[n].name = strdup(name + 1); recs[n].seq = strdup(seq); recs[n].qual = strdup(qual); recs[n].L = (int)strlen(seq);
         n++;
     }
+    free(name); free(seq); free(plus); free(qual);
     fclose(f);
     /* --illumina falls back to Phred+33 at the first negative quality and STAYS there for every later read of the run
      * (gILLUMINA is a global cleared at SeqReader.cpp:1174; reads are parsed in file order under read_lock) */

@@ -66,6 +66,9 @@ MODES = {
     "M5_all":         (["-M", "5", "-a", "0.8", "--print_all_sam"], dict(max_gap=5, align_score=0.8, print_all_sam=1), "syn.fq"),
     "M7_bs":          (["--max_gap=7", "-b"], dict(max_gap=7, mode=1), "syn.fq"),
     "M4_ill":         (["-M", "4", "--illumina"], dict(max_gap=4, illumina=1), "syn_ill.fq"),
+    # malformed FASTQ records: the reader shifts lines until it is back in step and goes on (SeqReader.cpp:1091-1144)
+    "malformed":      ([], {}, "syn_bad.fq"),
+    "malformed_tail": (["--no_nw"], dict(nw=0), "syn_bad2.fq"),               # ... and an input that ends inside a record, without a final newline
 }
 
 
@@ -90,19 +93,66 @@ def make_illumina_fastq(src, dst):
             f.write(name + seq + b"+\n" + bytes(q) + b"\n")
 
 
+def make_malformed_fastq(src, dst, dst2):
+    """syn_bad.fq: 150 reads of syn.fq with broken records in between - a '+' line that is something else, a quality line shorter than
+    its sequence, a name line without '@', a stray line between two records, blank lines, a record cut after its sequence, a quality
+    line LONGER than its sequence (accepted as it is), a quality line starting with '@'.  syn_bad2.fq: 40 reads, a broken record near
+    the end, the last record cut inside its quality line's predecessor and no newline at the end of the file."""
+    recs = []
+    with open(src, "rb") as f:
+        while True:
+            name = f.readline()
+            if not name:
+                break
+            seq = f.readline().rstrip(b"\n"); f.readline(); qual = f.readline().rstrip(b"\n")
+            recs.append((name.rstrip(b"\n"), seq, qual))
+    out = []
+    for i, (name, seq, qual) in enumerate(recs[:150]):
+        plus = b"+"
+        if i == 10: plus = b"-"                                   # the '+' line is not one
+        if i == 25: qual = qual[: len(qual) // 2]                 # quality shorter than the sequence
+        if i == 40: name = name[1:]                               # no '@'
+        if i == 55: out.append(b"this line does not belong here")
+        if i == 56: out.append(b"")                               # blank line before a name
+        if i == 70: qual = qual + b"IIII"                         # quality longer than the sequence
+        if i == 85: qual = b"@" + qual[1:]                        # a quality line that starts with '@'
+        if i == 100:                                              # a record cut after its sequence line
+            out += [name, seq]
+            continue
+        if i == 120: plus = b"+" + name[1:]                       # '+' followed by the name again: fine
+        if i == 130: out += [b"", b""]
+        out += [name, seq, plus, qual]
+    open(dst, "wb").write(b"\n".join(out) + b"\n")
+    out = []
+    for i, (name, seq, qual) in enumerate(recs[200:240]):
+        plus = b"+"
+        if i == 30: plus = b"plus"
+        if i == 39:
+            out += [name, seq, plus]                              # the last record has no quality line ...
+            continue
+        out += [name, seq, plus, qual]
+    open(dst2, "wb").write(b"\n".join(out))                       # ... and the file no final newline
+
+
 def main():
     assert os.path.exists(REFBIN), "make -C oracle refbin first"
     os.makedirs(OUT, exist_ok=True)
     ill = os.path.join(HERE, "syn_ill.fq")
     make_illumina_fastq(os.path.join(HERE, "syn.fq"), ill)
+    make_malformed_fastq(os.path.join(HERE, "syn.fq"), os.path.join(HERE, "syn_bad.fq"), os.path.join(HERE, "syn_bad2.fq"))
     work = tempfile.mkdtemp()
     for f in os.listdir(HERE):
         if f.startswith("syn."):
             shutil.copy(os.path.join(HERE, f), work)
     shutil.copy(ill, work)
+    for f in ("syn_bad.fq", "syn_bad2.fq"):
+        shutil.copy(os.path.join(HERE, f), work)
+    only = set(sys.argv[1:])                                       # regenerate just these modes (the others keep their committed files)
     shutil.copy(os.path.join(HERE, "subst.txt"), work)
-    manifest = {}
+    manifest = json.load(open(os.path.join(OUT, "manifest.json"))) if only else {}
     for name, (args, kw, fq) in MODES.items():
+        if only and name not in only:
+            continue
         argv = ["-g", "syn.fa", "-o", name, "-a", "0.9"] + args + [fq]
         r = subprocess.run([REFBIN] + argv, cwd=work, capture_output=True, text=True)
         assert r.returncode == 0, (name, r.stderr[-2000:])
