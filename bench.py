@@ -222,28 +222,43 @@ def cpu_baseline_port(fa, B, Q, L, kw, target_s, threads):
                        f"index preloaded, sampled-SA LF-walk locate as in the reference), {st.map_seconds:.1f} s")
 
 
-def abi_rate(g, ix, p, B, Q, Ln, n_reads, block, n_threads, torch):
-    """gm_map_batch + gm_output_batch on page-locked HOST buffers, `n_threads` host threads with one gm_batch + one stream each"""
+def abi_rate(g, ix, p, B, Q, Ln, n_reads, block, n_threads, torch, in_flight=3):
+    """gm_map_batch + gm_output_batch on page-locked HOST buffers: `n_threads` caller threads, each keeping `in_flight` blocks queued
+    through the enqueue / wait forms of the two calls (gm_map_batch_enqueue, gm_output_batch_enqueue, gm_batch_wait) on as many
+    gm_batch + HIP stream pairs; in_flight = 1: the synchronous calls"""
     n_reads = min(n_reads, len(B)) // block * block
     if n_reads == 0:
         return None
     Bp = g.api.pinned_empty((n_reads, B.shape[1]), np.uint8); Qp = g.api.pinned_empty((n_reads, B.shape[1]), np.uint8)
     Bp[:] = B[:n_reads]; Qp[:] = Q[:n_reads]
     Lp = g.api.pinned_empty(n_reads, np.uint16); Lp[:] = Ln[:n_reads]
-    streams = [torch.cuda.Stream() for _ in range(n_threads)]
-    runners = [g.api.BlockRunner(ix, p, block, B.shape[1], stream=s.cuda_stream) for s in streams]
+    streams = [[torch.cuda.Stream() for _ in range(in_flight)] for _ in range(n_threads)]
+    runners = [[g.api.BlockRunner(ix, p, block, B.shape[1], stream=s.cuda_stream) for s in ss] for ss in streams]
     blocks = list(range(0, n_reads, block))
-    for r in runners:                                           # warm-up: buffers sized, workspaces allocated
-        r.run(Bp[:block], Qp[:block], Lp[:block])
+    for rr in runners:                                          # warm-up: buffers sized, workspaces allocated
+        for r in rr:
+            r.run(Bp[:block], Qp[:block], Lp[:block])
     torch.cuda.synchronize()
     totals = [[0, 0] for _ in runners]
     err = []
 
     def work(k):
         try:
-            for s in blocks[k::n_threads]:
-                m, nr = runners[k].run(Bp[s:s + block], Qp[s:s + block], Lp[s:s + block])
-                totals[k][0] += m; totals[k][1] += nr
+            mine = blocks[k::n_threads]
+            if in_flight == 1:
+                for s in mine:
+                    m, nr = runners[k][0].run(Bp[s:s + block], Qp[s:s + block], Lp[s:s + block])
+                    totals[k][0] += m; totals[k][1] += nr
+                return
+            pending = [None] * in_flight
+            for i, s in enumerate(mine):
+                q = i % in_flight
+                if pending[q] is not None:
+                    m, nr = runners[k][q].wait(); totals[k][0] += m; totals[k][1] += nr
+                runners[k][q].run_async(Bp[s:s + block], Qp[s:s + block], Lp[s:s + block]); pending[q] = s
+            for q in range(in_flight):
+                if pending[q] is not None:
+                    m, nr = runners[k][q].wait(); totals[k][0] += m; totals[k][1] += nr
         except Exception as e:                                  # pragma: no cover
             err.append(e)
 
@@ -257,7 +272,7 @@ def abi_rate(g, ix, p, B, Q, Ln, n_reads, block, n_threads, torch):
     dt = time.perf_counter() - t0
     if err:
         raise err[0]
-    return dict(reads_per_s=n_reads / dt, reads=n_reads, block=block, host_threads=n_threads, seconds=dt,
+    return dict(reads_per_s=n_reads / dt, reads=n_reads, block=block, host_threads=n_threads, blocks_in_flight_per_thread=in_flight, seconds=dt,
                 matches=sum(t[0] for t in totals), sam_records=sum(t[1] for t in totals))
 
 
@@ -339,7 +354,7 @@ def run_config(a, g, gd, torch, ix, fa, wd, B, Q, Ln, dev, rank, world, t_setup)
     # the path the ABI exports to a host driver (N = 1 only: it is a per-GPU figure and the host is shared)
     abi = None
     if a.abi_reads > 0 and world == 1:
-        abi = abi_rate(g, ix, p, B, Q, Ln, a.abi_reads, a.abi_block, a.abi_threads, torch)
+        abi = abi_rate(g, ix, p, B, Q, Ln, a.abi_reads, a.abi_block, a.abi_threads, torch, a.abi_in_flight)
         log(f"[bench] ABI leg: {abi}")
 
     # self-check at the bench's own size: a sample of the benchmark reads against the oracle (rank 0, outside the timed region)
@@ -504,6 +519,7 @@ def build_parser():
     ap.add_argument("--abi-reads", type=int, default=4_194_304, help="reads of the gm_map_batch + gm_output_batch leg (0 = skip)")
     ap.add_argument("--abi-block", type=int, default=262144)
     ap.add_argument("--abi-threads", type=int, default=2)
+    ap.add_argument("--abi-in-flight", type=int, default=3, help="blocks each caller thread keeps queued (enqueue / wait forms); 1 = the synchronous calls")
     ap.add_argument("--parity-sample", type=int, default=64, help="reads of the benchmark compared with the oracle outside the timed region (0 = skip)")
     ap.add_argument("--workdir", default=os.environ.get("GM_BENCH_DIR", "/tmp/gnumap_bench"))
     ap.add_argument("--opt", action="append", default=[], metavar="GM_X=V", help="library run-time switch for this flag set (gm_set_option), e.g. --opt GM_SEED_FUSED=0")

@@ -81,6 +81,7 @@ EXPORTS = ["gm_last_error", "gm_version", "gm_set_option", "gm_index_build", "gm
            "gm_index_contig_offset", "gm_index_window", "gm_params_default", "gm_params_finalize", "gm_params_load_subst", "gm_batch_create", "gm_batch_destroy",
            "gm_batch_upload", "gm_map_batch_device", "gm_batch_counters", "gm_batch_path", "gm_batch_set_profiling", "gm_batch_kernel_times", "gm_kernel_name",
            "gm_batch_raw_hits", "gm_stream_create", "gm_stream_destroy", "gm_host_alloc", "gm_host_free", "gm_map_batch", "gm_output_batch",
+           "gm_map_batch_enqueue", "gm_output_batch_enqueue", "gm_batch_wait",
            "gm_dev_sa_interval", "gm_dev_locate", "gm_dev_nw_score", "gm_dev_traceback", "gm_coverage_reset", "gm_coverage_bins",
            "gm_coverage_device_ptr", "gm_coverage_add", "gm_coverage_download", "gm_coverage_allreduce", "gm_coverage_write_sgr", "gm_coverage_enable_nuc", "gm_coverage_nuc_device_ptr",
            "gm_coverage_download_nuc", "gm_coverage_write_gmp"]
@@ -119,6 +120,9 @@ def load_library():
     L.gm_map_batch_device.argtypes = [C.c_void_p, C.POINTER(gm_params), C.c_void_p, C.c_void_p]
     L.gm_batch_counters.argtypes = [C.c_void_p, C.POINTER(gm_counters)]
     L.gm_batch_path.argtypes = [C.c_void_p]; L.gm_batch_path.restype = C.c_char_p
+    L.gm_map_batch_enqueue.argtypes = [C.c_void_p, C.POINTER(gm_params), C.c_void_p, C.POINTER(gm_reads), C.POINTER(gm_hits), C.c_void_p]
+    L.gm_output_batch_enqueue.argtypes = [C.c_void_p, C.POINTER(gm_params), C.c_void_p, C.POINTER(gm_reads), C.POINTER(gm_hits), C.POINTER(gm_sam_out), C.c_void_p]
+    L.gm_batch_wait.argtypes = [C.c_void_p]
     L.gm_batch_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.gm_batch_kernel_times.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.gm_kernel_name.argtypes = [C.c_int]; L.gm_kernel_name.restype = C.c_char_p
@@ -465,3 +469,29 @@ class BlockRunner:
             _chk(rc)
             break
         return int(self.mbegin[n]), int(so.n_recs)
+
+    def run_async(self, B, Q, Ln):
+        """queue gm_map_batch + gm_output_batch of this block on the batch's service thread (gm_*_enqueue) and return at once; wait()
+        gives (n_matches, n_records).  The buffers must have room (a first synchronous run() sizes them)."""
+        n = B.shape[0]
+        self._n = n
+        self._r = _reads_struct(B, Q, Ln); self._keep = (B, Q, Ln)
+        h = self._h = gm_hits()
+        h.n = n; h.status = self.status.ctypes.data; h.self_score = self.self_score.ctypes.data; h.top_score = self.top.ctypes.data
+        h.denominator = self.den.ctypes.data; h.match_begin = self.mbegin.ctypes.data
+        h.matches = self.matches.ctypes.data; h.matches_cap = len(self.matches)
+        h.positions = self.positions.ctypes.data; h.positions_cap = len(self.positions)
+        so = self._so = gm_sam_out()
+        so.recs = self.recs.ctypes.data; so.recs_cap = len(self.recs); so.cigar_pool = self.pool.ctypes.data; so.cigar_cap = len(self.pool)
+        L = lib()
+        _chk(L.gm_map_batch_enqueue(self.index.h, C.byref(self.params.c), self.batch.h, C.byref(self._r), C.byref(h), self.stream))
+        _chk(L.gm_output_batch_enqueue(self.index.h, C.byref(self.params.c), self.batch.h, C.byref(self._r), C.byref(h), C.byref(so), self.stream))
+
+    def wait(self):
+        rc = lib().gm_batch_wait(self.batch.h)
+        if rc == GM_E_CAPACITY:                      # the buffers were too small after all: size them and run the block synchronously
+            self._alloc_hits(max(int(self._h.matches_cap), len(self.matches)) + 64, max(int(self._h.positions_cap), len(self.positions)) + 64)
+            self._alloc_out(max(int(self._so.recs_cap), len(self.recs)) + 64, max(int(self._so.cigar_cap), len(self.pool)) + 64)
+            return self.run(*self._keep)
+        _chk(rc)
+        return int(self.mbegin[self._n]), int(self._so.n_recs)

@@ -11,6 +11,10 @@
 #include <chrono>
 #include <map>
 #include <mutex>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <set>
 #include <thread>
 
@@ -128,6 +132,13 @@ struct gm_batch {
     std::vector<double> h_exp;          // exp(score) of every accepted hit of the last gm_map_batch (reused by gm_output_batch)
     uint64_t cache_hits = 0, cache_matches = 0;
     std::string path;                   // which kernels the last gm_map_batch_device chose (gm_batch_path)
+    // gm_*_enqueue / gm_batch_wait: the batch's own service thread runs the queued calls in order, the caller goes on
+    struct Service {
+        std::thread th; std::mutex mu; std::condition_variable cv;
+        std::deque<std::function<int()>> q;
+        bool busy = false, quit = false;
+        int rc = GM_OK; std::string err;
+    } svc;
     bool use_pack = false;              // the fused seed lookup is on for this pass (k_prep writes the 2-bit read forms)
     const void* resume_ptr = nullptr;   // set when gm_map_batch returned GM_E_CAPACITY: the next call with the same reads resumes at the copies
     uint32_t cand_cap = 0;
@@ -348,7 +359,7 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
                 auto it = ix->buckets.find(T);
                 if (it == ix->buckets.end()) {
                     DevBuf bb;
-                    const size_t need = ((size_t)1 << (2 * T)) * 128;
+                    const size_t need = (((size_t)1 << (2 * T)) + 1) * 128;            // + the all-zero record behind the last code
                     size_t fr = 0, tot = 0;
                     if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr >= need + ((size_t)24 << 30) && bb.ensure(need) == GM_OK) {
                         const auto t0 = std::chrono::steady_clock::now();
@@ -530,6 +541,11 @@ extern "C" int gm_batch_create(gm_index* ix, uint32_t max_reads, uint32_t max_le
 
 extern "C" void gm_batch_destroy(gm_batch* b) {
     if (!b) return;
+    if (b->svc.th.joinable()) {
+        { std::lock_guard<std::mutex> lk(b->svc.mu); b->svc.quit = true; }
+        b->svc.cv.notify_all();
+        b->svc.th.join();
+    }
     (void)hipSetDevice(b->ix->device);
     DevBuf* all[] = { &b->bases, &b->quals, &b->len, &b->status, &b->self_score, &b->min_score, &b->top_score, &b->seeds, &b->n_seeds,
                       &b->n_entries, &b->entry_off, &b->coords, &b->rs_overflow, &b->retry_list, &b->retry_off, &b->gtab_keys, &b->gtab_vals,
@@ -1073,8 +1089,7 @@ extern "C" int gm_batch_raw_hits(gm_batch* b, gm_raw_hit* out, uint64_t cap, uin
 }
 
 // host-side bookkeeping that is independent per item: cut into contiguous chunks, one host thread each (GM_HOST_THREADS; used by
-// the track writers.  The two batch calls below run their fp64 pass on the CALLING thread only: a driver gets its parallelism from
-// calling them from several threads with different batches)
+// the track writers: threads made per call) ...
 static unsigned host_threads() {
     static const unsigned n = [] {
         const char* e = getenv("GM_HOST_THREADS");               // sizes thread pools once per process
@@ -1094,6 +1109,63 @@ template <class F> static unsigned parallel_chunks(uint32_t n, uint32_t grain, u
     for (auto& x : th) x.join();
     return T;
 }
+
+// ... and the two fp64 passes of the batch calls (denominator += exp(score); posterior / winner / MAPQ): every read's sum is its own,
+// in its own order, so the READS of a block are cut into slices that helper threads of a process-wide pool take beside the calling
+// thread (GM_PASS_THREADS helpers, default 3 per process; 0 = the calling thread alone).  The pool is shared by every batch of the
+// process: a slice is a queue entry, callers of different batches interleave.
+namespace {
+struct PassPool {
+    std::mutex mu; std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    std::vector<std::thread> th;
+    bool stop = false;
+    unsigned n = 0;
+    void start(unsigned helpers) {
+        n = helpers;
+        for (unsigned i = 0; i < helpers; ++i)
+            th.emplace_back([this] {
+                for (;;) {
+                    std::function<void()> job;
+                    { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || !q.empty(); }); if (q.empty()) return; job = std::move(q.front()); q.pop_front(); }
+                    job();
+                }
+            });
+    }
+    ~PassPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto& t : th) t.join(); }
+};
+PassPool& pass_pool() {
+    static PassPool* pool = [] { auto* p = new PassPool(); const char* e = getenv("GM_PASS_THREADS"); p->start(e ? (unsigned)std::max(0, atoi(e)) : 3u); return p; }();
+    return *pool;
+}
+// fn(lo, hi) over [0, n) in slices of at least `grain` items: the helpers take slices from the queue, the caller takes the rest
+template <class F> void pass_parallel(uint32_t n, uint32_t grain, F&& fn) {
+    PassPool& pool = pass_pool();
+    const unsigned parts = (unsigned)std::min<uint64_t>(pool.n + 1, std::max<uint32_t>(1, n / std::max<uint32_t>(1, grain)));
+    if (parts <= 1) { fn(0u, n); return; }
+    const uint64_t per = (n + parts - 1) / parts;
+    std::atomic<unsigned> left{ parts - 1 };
+    std::mutex done_mu; std::condition_variable done_cv;
+    {
+        std::lock_guard<std::mutex> lk(pool.mu);
+        for (unsigned c = 1; c < parts; ++c)
+            pool.q.emplace_back([&, c] {
+                fn((uint32_t)std::min<uint64_t>(n, c * per), (uint32_t)std::min<uint64_t>(n, (c + 1) * per));
+                if (left.fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk2(done_mu); done_cv.notify_one(); }
+            });
+    }
+    pool.cv.notify_all();
+    fn(0u, (uint32_t)std::min<uint64_t>(n, per));
+    // a slice nobody has taken yet is run here rather than waited for
+    for (;;) {
+        std::function<void()> job;
+        { std::lock_guard<std::mutex> lk(pool.mu); if (pool.q.empty()) break; job = std::move(pool.q.front()); pool.q.pop_front(); }
+        job();
+    }
+    std::unique_lock<std::mutex> lk(done_mu);
+    done_cv.wait(lk, [&] { return left.load() == 0; });
+}
+}  // namespace
 
 struct PhaseClock {                         // GM_TIMING=1: host-side phase times of the two batch calls on stderr
     bool on; const char* what; std::chrono::steady_clock::time_point t0; std::string line;
@@ -1230,22 +1302,24 @@ extern "C" int gm_map_batch(gm_index* ix, const gm_params* p, gm_batch* b, const
     const float* top = b->h_top.as<float>(); const uint64_t* hb = b->h_hbegin.as<uint64_t>(); const float* ord = b->h_ord.as<float>();
     b->h_exp.resize((size_t)n_hits + 1);
     double* hexp = b->h_exp.data();
-    for (uint32_t i = 0; i < n; ++i) {
-        const int8_t s = out->status[i];
-        double den = 0.0, tp = 0.0;
-        if (s == GM_READ_OK) {
-            for (uint64_t h = hb[i]; h < hb[i + 1]; ++h) {
-                const float sc = ord[h];
-                const double e = sc != -INFINITY ? exp((double)sc) : 0.0;
-                hexp[h] = e;
-                if (sc != -INFINITY) den += e;
-            }
-            tp = (double)top[i];
-        } else if (s == GM_READ_TOO_SHORT) tp = -2.0;
-        else if (s == GM_READ_TOO_POOR) tp = -3.0;
-        else if (s == GM_READ_TOO_MANY) tp = 999999.0;
-        out->denominator[i] = den; out->top_score[i] = tp;
-    }
+    pass_parallel(n, 16384, [&](uint32_t lo, uint32_t hi) {
+        for (uint32_t i = lo; i < hi; ++i) {
+            const int8_t s = out->status[i];
+            double den = 0.0, tp = 0.0;
+            if (s == GM_READ_OK) {
+                for (uint64_t h = hb[i]; h < hb[i + 1]; ++h) {
+                    const float sc = ord[h];
+                    const double e = sc != -INFINITY ? exp((double)sc) : 0.0;
+                    hexp[h] = e;
+                    if (sc != -INFINITY) den += e;
+                }
+                tp = (double)top[i];
+            } else if (s == GM_READ_TOO_SHORT) tp = -2.0;
+            else if (s == GM_READ_TOO_POOR) tp = -3.0;
+            else if (s == GM_READ_TOO_MANY) tp = 999999.0;
+            out->denominator[i] = den; out->top_score[i] = tp;
+        }
+    });
     pc.lap("exp");
     HIPCHK(hipStreamSynchronize(st));
     b->cache_hits = n_hits; b->cache_matches = n_m;          // h_exp / h_ord / h_mhit describe this result
@@ -1329,31 +1403,33 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
     const int all = p->print_all_sam;
     const uint64_t cached_m = b->cache_matches, cached_h = b->cache_hits;
     const uint32_t* mhit = b->h_mhit.as<uint32_t>(); const float* ord = b->h_ord.as<float>(); const double* hexp = b->h_exp.data();
-    for (uint32_t i = 0; i < n; ++i) {
-        const uint64_t m0 = hits->match_begin[i], m1 = hits->match_begin[i + 1];
-        if (m0 == m1) continue;
-        if (hits->status[i] != GM_READ_OK) { for (uint64_t m = m0; m < m1; ++m) { post[m] = 0; mapq[m] = 0; emit[m] = 0; } continue; }
-        const double den = hits->denominator[i], top = hits->top_score[i];
-        int64_t best = -1;
-        double best_log = e_m1, best_total = 0;
-        for (uint64_t m = m0; m < m1; ++m) {
-            const gm_match& mm = hits->matches[m];
-            // exp(align_score): the value gm_map_batch already computed for the hit that gave this match its score, when the caller has
-            // left the match as it was (exp is a function of the score alone, so equal score bits are all that has to hold)
-            double lg;
-            if (m < cached_m && mhit[m] < cached_h && memcmp(&ord[mhit[m]], &mm.score, 4) == 0) lg = hexp[mhit[m]];
-            else lg = exp((double)mm.score);
-            const double total = lg / den;                             // ScoredSeq.h:300
-            post[m] = (float)total;                                    // AddScore(const float& amt), NormalScoredSeq.cpp:70
-            emit[m] = (uint8_t)all;
-            mapq[m] = all ? mapq_of(total) : 0;
-            if (lg > best_log) { best = (int64_t)m; best_log = lg; best_total = total; }   // is_greater: strict, first in key order wins
+    pass_parallel(n, 16384, [&](uint32_t lo, uint32_t hi) {
+        for (uint32_t i = lo; i < hi; ++i) {
+            const uint64_t m0 = hits->match_begin[i], m1 = hits->match_begin[i + 1];
+            if (m0 == m1) continue;
+            if (hits->status[i] != GM_READ_OK) { for (uint64_t m = m0; m < m1; ++m) { post[m] = 0; mapq[m] = 0; emit[m] = 0; } continue; }
+            const double den = hits->denominator[i], top = hits->top_score[i];
+            int64_t best = -1;
+            double best_log = e_m1, best_total = 0;
+            for (uint64_t m = m0; m < m1; ++m) {
+                const gm_match& mm = hits->matches[m];
+                // exp(align_score): the value gm_map_batch already computed for the hit that gave this match its score, when the caller has
+                // left the match as it was (exp is a function of the score alone, so equal score bits are all that has to hold)
+                double lg;
+                if (m < cached_m && mhit[m] < cached_h && memcmp(&ord[mhit[m]], &mm.score, 4) == 0) lg = hexp[mhit[m]];
+                else lg = exp((double)mm.score);
+                const double total = lg / den;                             // ScoredSeq.h:300
+                post[m] = (float)total;                                    // AddScore(const float& amt), NormalScoredSeq.cpp:70
+                emit[m] = (uint8_t)all;
+                mapq[m] = all ? mapq_of(total) : 0;
+                if (lg > best_log) { best = (int64_t)m; best_log = lg; best_total = total; }   // is_greater: strict, first in key order wins
+            }
+            if (!all && best >= 0 && (double)hits->matches[best].score > top - 0.00001) {      // Driver.cpp:695
+                emit[best] = 1;
+                mapq[best] = mapq_of(best_total);
+            }
         }
-        if (!all && best >= 0 && (double)hits->matches[best].score > top - 0.00001) {      // Driver.cpp:695
-            emit[best] = 1;
-            mapq[best] = mapq_of(best_total);
-        }
-    }
+    });
     pc.lap("fp64");
     // ---- device, part 2 ----
     HIPCHK(hipMemcpyAsync(b->o_post.p, post, (size_t)n_m * 4, hipMemcpyHostToDevice, st));
@@ -1392,6 +1468,67 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
     HIPCHK(hipStreamSynchronize(st));
     pc.lap("records+coverage");
     return GM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// enqueue / wait forms of the two batch calls: a caller thread hands a block to the batch's service thread and goes on with the next
+// block on another batch; uploads, device work and the fp64 passes of different batches overlap without one caller thread per batch.
+// Calls queued on one batch run in the order they were queued; after a failing call the rest of that batch's queue is skipped.
+// ------------------------------------------------------------------------------------------------
+static void svc_post(gm_batch* b, std::function<int()> job) {
+    gm_batch::Service& sv = b->svc;
+    std::lock_guard<std::mutex> lk(sv.mu);
+    if (!sv.th.joinable())
+        sv.th = std::thread([b] {
+            gm_batch::Service& v = b->svc;
+            for (;;) {
+                std::function<int()> j;
+                {
+                    std::unique_lock<std::mutex> lk2(v.mu);
+                    v.cv.wait(lk2, [&] { return v.quit || !v.q.empty(); });
+                    if (v.q.empty()) return;
+                    j = std::move(v.q.front()); v.q.pop_front();
+                    v.busy = true;
+                }
+                int rc = GM_OK; std::string err;
+                bool skip;
+                { std::lock_guard<std::mutex> lk2(v.mu); skip = v.rc != GM_OK; }
+                if (!skip) { rc = j(); if (rc != GM_OK) err = gm_last_error(); }
+                {
+                    std::lock_guard<std::mutex> lk2(v.mu);
+                    if (rc != GM_OK && v.rc == GM_OK) { v.rc = rc; v.err = err; }
+                    v.busy = false;
+                }
+                v.cv.notify_all();
+            }
+        });
+    sv.q.push_back(std::move(job));
+    sv.cv.notify_all();
+}
+
+extern "C" int gm_map_batch_enqueue(gm_index* ix, const gm_params* p, gm_batch* b, const gm_reads* reads, gm_hits* out, void* stream) {
+    if (!ix || !p || !b || !reads || !out) return GM_E_ARG;
+    const gm_params pc = *p; const gm_reads rc = *reads;           // the structs are copied; the arrays they point to stay the caller's until gm_batch_wait
+    svc_post(b, [=]() { return gm_map_batch(ix, &pc, b, &rc, out, stream); });
+    return GM_OK;
+}
+
+extern "C" int gm_output_batch_enqueue(gm_index* ix, const gm_params* p, gm_batch* b, const gm_reads* reads, const gm_hits* hits, gm_sam_out* out, void* stream) {
+    if (!ix || !p || !b || !reads || !hits || !out) return GM_E_ARG;
+    const gm_params pc = *p; const gm_reads rc = *reads;
+    svc_post(b, [=]() { return gm_output_batch(ix, &pc, b, &rc, hits, out, stream); });     // `hits` is read when the call runs: the gm_hits a queued gm_map_batch fills
+    return GM_OK;
+}
+
+extern "C" int gm_batch_wait(gm_batch* b) {
+    if (!b) return GM_E_ARG;
+    gm_batch::Service& sv = b->svc;
+    std::unique_lock<std::mutex> lk(sv.mu);
+    sv.cv.wait(lk, [&] { return sv.q.empty() && !sv.busy; });
+    const int rc = sv.rc;
+    if (rc != GM_OK) gm_set_error(sv.err);
+    sv.rc = GM_OK; sv.err.clear();
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------

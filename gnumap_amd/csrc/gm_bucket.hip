@@ -40,9 +40,11 @@
 // Register j of ALL lanes covers positions 7j .. 7j + 6: a register beyond every count of the wave is skipped with one scalar branch.
 __global__ void __launch_bounds__(256) k_build_bucket(const uint2* __restrict__ tab, const uint32_t* __restrict__ full_sa, uint4* __restrict__ bucket,
                                                       unsigned long long n_codes) {
-    for (unsigned long long t = (unsigned long long)blockIdx.x * 256 + threadIdx.x; t < n_codes * 8ull; t += (unsigned long long)gridDim.x * 256) {
+    // (one more record behind the last code, all zero: where the lanes of a seed slot that is not in use load from)
+    for (unsigned long long t = (unsigned long long)blockIdx.x * 256 + threadIdx.x; t < (n_codes + 1ull) * 8ull; t += (unsigned long long)gridDim.x * 256) {
         const unsigned long long code = t >> 3;
         const uint32_t q = (uint32_t)t & 7u;
+        if (code == n_codes) { bucket[t] = make_uint4(0u, 0u, 0u, 0u); continue; }
         const uint2 iv = tab[code];
         const bool empty = iv.x == 0xFFFFFFFFu;
         const uint32_t cnt = empty ? 0u : iv.y - iv.x + 1u;
@@ -71,7 +73,8 @@ __global__ void __launch_bounds__(256) k_build_bucket(const uint2* __restrict__ 
 
 // ---- per-wave LDS -------------------------------------------------------------------------------------------------------------------
 struct GmBucketLds {
-    uint4 zero[(2 * GMB_FWORDS + 2 * GMB_LCAP + 8) / 4];         // filter [2][512] | dup keys [2][32] | tag masks [2] + pad: zeroed by every wave
+    uint4 filt[2 * GMB_FWORDS / 4];                              // filter [2][512 words]: 4 x 16 bytes per lane, zeroed by every wave
+    uint4 small[(2 * GMB_LCAP + 8) / 4];                         // dup keys [2][32] | tag masks [2] + pad: zeroed too
     uint32_t s_code[2][GMB_MAXS];                                // seeds of a half that walked again
     uint16_t s_pos[2][GMB_MAXS];
     uint32_t ov_k[2][GMB_OV], ov_n[2][GMB_OV], ov_ot[2][GMB_OV]; // seeds with more than GMB_C hits: first SA rank, count, (read offset + 1) | tag << 16
@@ -170,10 +173,10 @@ __device__ __forceinline__ uint32_t gmb_half_scan_incl(uint32_t x) {
 //            votes = popcount(tag mask), NW step = its -k-th lowest bit (inc/align_seq2_raw.cpp:262-274, process_hits :28-40).
 // A strand without a second arrival has no candidate with -k >= 2: the wrong strand of a read ends after pass 1.
 template <int STEPS>
-__global__ void __launch_bounds__(64, STEPS <= 4 ? 6 : 4) k_vote_bucket(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
+__global__ void __launch_bounds__(64, STEPS <= 4 ? 7 : 4) k_vote_bucket(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
     __shared__ GmBucketLds S;
-    uint32_t* const s_filt = reinterpret_cast<uint32_t*>(S.zero);          // [2][GMB_FWORDS]
-    uint32_t* const s_keys = s_filt + 2 * GMB_FWORDS;                        // [2][GMB_LCAP]
+    uint32_t* const s_filt = reinterpret_cast<uint32_t*>(S.filt);          // [2][GMB_FWORDS]
+    uint32_t* const s_keys = reinterpret_cast<uint32_t*>(S.small);         // [2][GMB_LCAP]
     uint32_t* const s_tagm = s_keys + 2 * GMB_LCAP;                          // [2]
     const uint32_t r = blockIdx.x;                     // grid = n reads
     const int lane = threadIdx.x;
@@ -181,6 +184,7 @@ __global__ void __launch_bounds__(64, STEPS <= 4 ? 6 : 4) k_vote_bucket(GmDevInd
     const uint32_t rs = 2u * r + h;
     const uint32_t m = (uint32_t)p.mer, jump = (uint32_t)p.jump, w2 = b.pack_w2;
     const uint32_t cmask = m >= 16u ? 0xFFFFFFFFu : ((1u << (2u * m)) - 1u);
+    const uint32_t zero_code = cmask + 1u;             // the all-zero record behind the table (mer <= 15)
     const uint4* const bucket = reinterpret_cast<const uint4*>(p.bucket);
 
     // ---- the read's header and the two words that hold lane jj's regular k-mer: one round trip ----
@@ -190,12 +194,13 @@ __global__ void __launch_bounds__(64, STEPS <= 4 ? 6 : 4) k_vote_bucket(GmDevInd
     const bool inrow = i_reg + m <= 16u * w2;
     const uint32_t o = inrow ? 2u * (16u * w2 - i_reg - m) : 0u;
     const uint32_t hdr_v = row[0], f0 = form[o >> 5], f1 = form[(o >> 5) + 1u];
-    asm volatile("" :: "v"(f0), "v"(f1));
     // the LDS structures are zeroed under that trip
     {
-        constexpr int NZ = (int)(sizeof(S.zero) / 16);
+        static_assert(sizeof(S.filt) == 4 * 64 * 16 && sizeof(S.small) <= 64 * 16, "one wave zeroes the filter with four stores per lane");
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-        for (int k = 0; k < (NZ + 63) / 64; ++k) if (lane + 64 * k < NZ) S.zero[lane + 64 * k] = make_uint4(0u, 0u, 0u, 0u);
+        for (int k = 0; k < 4; ++k) S.filt[lane + 64 * k] = z;
+        if (lane < (int)(sizeof(S.small) / 16)) S.small[lane] = z;
     }
     const uint32_t hdr = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr_v);           // the same word in every lane: scalar from here on
     const uint32_t L = hdr & 0xFFFFu;
@@ -238,13 +243,14 @@ __global__ void __launch_bounds__(64, STEPS <= 4 ? 6 : 4) k_vote_bucket(GmDevInd
             // lanes q < STEPS also fetch lane 0's part of the record of seed 4 q + g: all headers of a half are looked at ONCE
             const uint32_t hslot = 4u * q + g;
             if (attempt == 0) {
+                const int bp_base = (int)((((uint32_t)lane & 32u) + g) << 2);      // lane that computed the code of seed g of this half, x 4
+                const uint32_t of_g = g * jump + 1u, of_step = 4u * jump;
 #pragma unroll
                 for (int st = 0; st < STEPS; ++st) {
-                    const uint32_t slot = 4u * st + g;
-                    cd[st] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane & 32u) + slot) << 2, (int)code);
-                    of1[st] = slot * jump + 1u;
+                    cd[st] = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_base + 16 * st, (int)code);
+                    of1[st] = of_g + (uint32_t)st * of_step;
                 }
-                hcode = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane & 32u) + (hslot & 31u)) << 2, (int)code);
+                hcode = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_base + (int)(q << 4), (int)code);
                 hof1 = hslot * jump + 1u;
             } else if (walked) {
 #pragma unroll
@@ -256,14 +262,10 @@ __global__ void __launch_bounds__(64, STEPS <= 4 ? 6 : 4) k_vote_bucket(GmDevInd
                 hcode = (q < (uint32_t)STEPS && hslot < ns_h) ? S.s_code[h][hslot] : 0u;
                 hof1 = (q < (uint32_t)STEPS && hslot < ns_h) ? S.s_pos[h][hslot] + 1u : 0u;
             }
-            if (attempt == 0 || walked) {
+            if (attempt == 0 || walked) {          // every lane loads: a slot that is not in use (and lane 0 of a group) reads the zero record
 #pragma unroll
-                for (int st = 0; st < STEPS; ++st) {
-                    if (4u * st + g < ns_h && q != 0u) rc[st] = bucket[(size_t)cd[st] * 8u + q];
-                    else rc[st] = make_uint4(0u, 0u, 0u, 0u);
-                }
-                if (q < (uint32_t)STEPS && hslot < ns_h) hd4 = bucket[(size_t)hcode * 8u];
-                else hd4 = make_uint4(0u, 0u, 0u, 0u);
+                for (int st = 0; st < STEPS; ++st) rc[st] = bucket[(size_t)((4u * st + g < ns_h && q != 0u) ? cd[st] : zero_code) * 8u + q];
+                hd4 = bucket[(size_t)((q < (uint32_t)STEPS && hslot < ns_h) ? hcode : zero_code) * 8u];
             }
             const bool empty = (hd4.x & 0x40000000u) != 0u;
             const uint32_t hc = (hd4.x & 0x80000000u) ? hd4.z : (hd4.x & 0xFFFFu);
@@ -357,13 +359,16 @@ __global__ void __launch_bounds__(64, STEPS <= 4 ? 6 : 4) k_vote_bucket(GmDevInd
     // ---- pass 1 ----
     uint32_t lc_h = 0;                                // keys in this half's list so far
     uint32_t known = 0;                               // the half's most recent key: the true locus' hits arrive one after the other, only the first is listed
-    auto pass1 = [&](const uint32_t v, const uint32_t off1) {
-        const uint32_t bp = v - off1;                 // window start (:267; never clamped here: v > off1 for every position of a voting half)
-        bool dup = false;
-        if (vote_h && v != 0u) {                      // filter slot = the low 14 bits of the window start (chance hits are uniform, equal window starts meet)
-            const uint32_t old = atomicOr(&filt[(bp >> 5) & (GMB_FWORDS - 1)], 1u << (bp & 31u));
-            dup = ((old >> (bp & 31u)) & 1u) != 0u && bp != known;
-        }
+    // the filter atomic of a hit: slot = the low 14 bits of its window start (chance hits are uniform, equal window starts meet)
+    auto arrive = [&](const uint32_t v, const uint32_t bp) -> uint32_t {
+        uint32_t old = 0;
+        if (vote_h && v != 0u) old = atomicOr(&filt[__builtin_amdgcn_ubfe(bp, 5, 9)], 1u << (bp & 31u));
+        return old;
+    };
+    // what its answer means: the bit was set before -> a second or later arrival; its window start goes to the key list unless it
+    // is the half's most recent key (the true locus' hits arrive one after the other: listed once)
+    auto settle = [&](const uint32_t bp, const uint32_t old) {
+        const bool dup = (old >> (bp & 31u) & 1u) != 0u && bp != known;
         const unsigned long long dm = __builtin_amdgcn_ballot_w64(dup);
         if (dm != 0ull) {                             // wave-uniform; rare: once per distinct window start that is met again
             const uint32_t at = lc_h + gmb_half_prefix(dm, h);
@@ -376,10 +381,19 @@ __global__ void __launch_bounds__(64, STEPS <= 4 ? 6 : 4) k_vote_bucket(GmDevInd
             if (nk != 0u) known = nk;
         }
     };
+    auto pass1 = [&](const uint32_t v, const uint32_t off1) { const uint32_t bp = v - off1; settle(bp, arrive(v, bp)); };
+    {   // registers 0 and 1 of every step (positions 0 .. 13 of a record: nearly always there): the eight atomics are issued together,
+        // one wait for all of them instead of one LDS round trip per hit
+        uint32_t bx[STEPS], by[STEPS], ox[STEPS], oy[STEPS];
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) { bx[st] = rc[st].x - of1[st]; by[st] = rc[st].y - of1[st]; }
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) { ox[st] = arrive(rc[st].x, bx[st]); oy[st] = arrive(rc[st].y, by[st]); }
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) { settle(bx[st], ox[st]); settle(by[st], oy[st]); }
+    }
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
-        pass1(rc[st].x, of1[st]);
-        if (__builtin_amdgcn_ballot_w64(rc[st].y != 0u) != 0ull) pass1(rc[st].y, of1[st]);      // counts >= 8
         if (__builtin_amdgcn_ballot_w64(rc[st].z != 0u) != 0ull) pass1(rc[st].z, of1[st]);      // counts >= 15
         if (__builtin_amdgcn_ballot_w64(rc[st].w != 0u) != 0ull) pass1(rc[st].w, of1[st]);      // counts >= 22
     }
@@ -443,7 +457,8 @@ __global__ void __launch_bounds__(64, STEPS <= 4 ? 6 : 4) k_vote_bucket(GmDevInd
             else step = votes;
             GmCand c;
             c.rs = rs; c.b = key; c.step = (uint16_t)step; c.flags = 4; c.pad = 0; c.score = 0.0f;           // key = (position + 1) - (read offset + 1): the window start
-            if (em && b.fixed_cands != nullptr && n_em_h < GM_FIXED_C) b.fixed_cands[(size_t)rs * GM_FIXED_C + n_em_h] = c;
+            if (p.dbg & 2048) { if (c.b == 0x7FFFFFF1u) b.counters[GMK_DBG1] = 1; }      // (GM_DBG 2048: timing experiment, no candidate stores)
+            else if (em && b.fixed_cands != nullptr && n_em_h < GM_FIXED_C) b.fixed_cands[(size_t)rs * GM_FIXED_C + n_em_h] = c;
             else if (em) {                            // more candidates than own slots (or no own slots): the shared list
                 const uint32_t at = atomicAdd(&b.shard_cnt[shard * GM_SHARD_STRIDE], 1u);
                 if (at < b.cand_region) b.cands[(size_t)shard * b.cand_region + at] = c;
@@ -452,7 +467,7 @@ __global__ void __launch_bounds__(64, STEPS <= 4 ? 6 : 4) k_vote_bucket(GmDevInd
         }
         __syncthreads();
     }
-    if (jj == 0u && b.fixed_cands != nullptr && n_em_h != 0u) b.fixed_cnt[rs] = (uint8_t)(n_em_h < GM_FIXED_C ? n_em_h : GM_FIXED_C);
+    if (jj == 0u && b.fixed_cands != nullptr && n_em_h != 0u && !(p.dbg & 2048)) b.fixed_cnt[rs] = (uint8_t)(n_em_h < GM_FIXED_C ? n_em_h : GM_FIXED_C);
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------------------------------------

@@ -225,6 +225,16 @@ void gm_host_free(void*);
 int gm_map_batch(gm_index*, const gm_params*, gm_batch*, const gm_reads*, gm_hits* out, void* hip_stream);
 int gm_output_batch(gm_index*, const gm_params*, gm_batch*, const gm_reads*, const gm_hits*, gm_sam_out* out, void* hip_stream);
 
+/* enqueue / wait forms: the call is queued on the batch's own service thread and runs there exactly as the synchronous form would;
+ * the caller goes on (with another batch).  Calls queued on one batch run in order - gm_output_batch_enqueue may be queued right
+ * behind the gm_map_batch_enqueue whose gm_hits it reads - and after a failing call the rest of the batch's queue is skipped.
+ * gm_batch_wait returns when the batch's queue is empty: GM_OK, or the status of the first call that failed (gm_last_error() has its
+ * text).  gm_params / gm_reads are copied at enqueue time; the arrays behind gm_reads, gm_hits and gm_sam_out stay the caller's until
+ * the wait.  One HIP stream per batch, as with the synchronous forms. */
+int gm_map_batch_enqueue(gm_index*, const gm_params*, gm_batch*, const gm_reads*, gm_hits* out, void* hip_stream);
+int gm_output_batch_enqueue(gm_index*, const gm_params*, gm_batch*, const gm_reads*, const gm_hits*, gm_sam_out* out, void* hip_stream);
+int gm_batch_wait(gm_batch*);
+
 /* ---- unit-level device entry points (parity tests) ---- */
 int gm_dev_sa_interval(gm_index*, const char* kmers, uint32_t n, uint32_t m, uint64_t* start, uint64_t* end);
 int gm_dev_locate(gm_index*, const uint64_t* ranks, uint32_t n, int use_full_sa, uint64_t* out);

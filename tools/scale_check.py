@@ -259,6 +259,7 @@ def main(argv=None):
         t_or += time.time() - t0_
         log("[scale] checks of the block done")
     c = batch.counters()
+    out.update(path=batch.path())
     out.update(exact_reads_checked=checked, exact_reads_origin_found=found, mapped=mapped, max_reported_pos=max_pos)
     out.update(oracle_sample=int(a.sample), oracle_mismatches=int(bad), oracle_reads_per_s=round(a.sample / max(1e-9, t_or), 1),
                oracle_tail_reads=int((pos[pick] >= (1 << 31)).sum()))
