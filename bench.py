@@ -134,14 +134,18 @@ def make_reads(codes_t, n, L, seed, device):
     return B, Q, Ln
 
 
-def algorithmic_bytes(c, L, n_reads, fused=False):
+def algorithmic_bytes(c, L, n_reads, fused=False, bucket=False):
     """per-launch algorithmic bytes of each kernel from the kernel-side work counters (DESIGN.md 'Algorithmic bytes').
     fused: the seed lookup runs inside the vote kernel (no k_seed launch): k_prep also writes the reads' 2-bit forms (both strands +
-    a header word), the vote kernel reads them and the table records instead of seed rows"""
+    a header word), the vote kernel reads them and the table records instead of seed rows.
+    bucket: the lookup is one k-mer -> positions record per k-mer: 4 bytes of header per probe + 4 bytes per located position (the
+    positions ARE the suffix-array values; the record's unused words are not algorithmic bytes)"""
     win = L // 4 + 1
     forms = n_reads * (2 * (L // 4 + 1) + 4)
     vote = c["sa_hits"] * 4 + c["candidates"] * 16
-    if fused:
+    if bucket:
+        vote += c.get("table_lookups", 0) * 4 + forms + 2 * n_reads * 6
+    elif fused:
         vote += c["occ_blocks"] * 64 + c.get("table_lookups", 0) * 8 + forms + 2 * n_reads * 6
     else:
         vote += c["seeds_used"] * 12
@@ -349,6 +353,7 @@ def run_config(a, g, gd, torch, ix, fa, wd, B, Q, Ln, dev, rank, world, t_setup)
     elapsed = gd.max_over_ranks(t1 - t0, dev)
     ktimes = batch.kernel_times()
     counters = batch.counters()
+    kernel_path = batch.path()
     batch.set_profiling(False)
 
     # the path the ABI exports to a host driver (N = 1 only: it is a per-GPU figure and the host is shared)
@@ -422,7 +427,7 @@ def run_config(a, g, gd, torch, ix, fa, wd, B, Q, Ln, dev, rank, world, t_setup)
         ms_per_step = elapsed / a.steps * 1e3
         value = world * a.reads * a.steps / elapsed
         fused = ktimes.get("k_seed", (0.0, 0))[1] == 0 and a.locate == "full"      # seed lookup inside the vote kernel
-        alg = algorithmic_bytes(counters, a.read_len, a.reads, fused)
+        alg = algorithmic_bytes(counters, a.read_len, a.reads, fused, "bucket" in kernel_path)
         per_kernel = {}
         for k, (ms, n) in ktimes.items():
             if n:
@@ -480,6 +485,7 @@ def run_config(a, g, gd, torch, ix, fa, wd, B, Q, Ln, dev, rank, world, t_setup)
                        "sharding": f"reads x{world} (no data-path collective)"},
             "roofline": roof,
             "seed_lookup": "fused into the vote kernel" if fused else "k_seed",
+            "kernel_path": kernel_path,
             "cpu_baseline": cpu,
             "parity_sample": parity,
             "abi_reads_per_s": round(abi["reads_per_s"], 1) if abi else None,

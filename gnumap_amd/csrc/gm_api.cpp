@@ -128,7 +128,7 @@ struct gm_batch {
         // grouping (process_hits' unique map) and output stage, gm_output.hip
         g_sorted, g_ord, g_lead, g_krank, g_khash, g_nmatch, g_mbegin, g_multi, g_big, g_bigdone, g_sk0, g_sk1, g_si0, g_si1, g_matches, g_mhit, g_positions, scan_tmp,
         o_small, o_posmatch, o_post, o_mapq, o_emit, o_reccnt, o_cigcnt, o_cigall, o_recoff, o_cigoff, o_recs, o_pool, o_codes;
-    PinBuf h_top, h_hbegin, h_ord, h_post, h_mapq, h_emit, h_mhit;
+    PinBuf h_top, h_hbegin, h_ord, h_post, h_mapq, h_emit, h_mhit, h_stat;      // h_stat: the small status words a phase reads back (page-locked: one short DMA)
     std::vector<double> h_exp;          // exp(score) of every accepted hit of the last gm_map_batch (reused by gm_output_batch)
     uint64_t cache_hits = 0, cache_matches = 0;
     std::string path;                   // which kernels the last gm_map_batch_device chose (gm_batch_path)
@@ -555,7 +555,7 @@ extern "C" void gm_batch_destroy(gm_batch* b) {
                       &b->scan_tmp, &b->o_small, &b->o_posmatch, &b->o_post, &b->o_mapq, &b->o_emit, &b->o_reccnt, &b->o_cigcnt, &b->o_cigall, &b->o_recoff, &b->o_cigoff,
                       &b->o_recs, &b->o_pool, &b->o_codes };
     for (DevBuf* d : all) d->release();
-    PinBuf* pins[] = { &b->h_top, &b->h_hbegin, &b->h_ord, &b->h_post, &b->h_mapq, &b->h_emit, &b->h_mhit };
+    PinBuf* pins[] = { &b->h_top, &b->h_hbegin, &b->h_ord, &b->h_post, &b->h_mapq, &b->h_emit, &b->h_mhit, &b->h_stat };
     for (PinBuf* d : pins) d->release();
     for (int i = 0; i < gm_batch::NS; ++i) { if (b->sub_streams[i]) (void)hipStreamDestroy(b->sub_streams[i]); b->sub_gk[i].release(); b->sub_gv[i].release(); }
     if (b->sub_ready) (void)hipEventDestroy(b->sub_ready);
@@ -844,18 +844,31 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
     std::vector<uint32_t> heavy;                     // {rs, n_seeds, SA hits} triples
     if (b->heavy_list.ensure(3 * 2 * (size_t)b->n * 4 + 64)) return GM_E_NOMEM;
     // the list of the heavy path: right after k_seed, or (fused form) after the first vote launch, which left them alone
-    auto collect_heavy = [&]() -> int {
+    // status words of a phase come back in ONE short DMA into page-locked memory: [0..15] = b->small (n_retry, n_big, n_heavy, shard total,
+    // shard maximum), [16..] = the work counters
+    if (b->h_stat.ensure(64 + GMK_N * 8 + 64)) return GM_E_NOMEM;
+    uint32_t* const hs_small = b->h_stat.as<uint32_t>();
+    unsigned long long* const hs_ctr = reinterpret_cast<unsigned long long*>(b->h_stat.as<uint8_t>() + 64);
+    auto collect_heavy_enqueue = [&]() -> int {      // (the count is read back with the phase's status words)
         HIPCHK(hipMemsetAsync(b->small.as<uint32_t>() + 3, 0, 4, st));
         KCHK(gmk_heavy_collect(b->dev, heavy_min, b->small.as<uint32_t>() + 3, b->heavy_list.as<uint32_t>(), dp.fused, st));
-        uint32_t nh = 0;
-        HIPCHK(hipMemcpyAsync(&nh, b->small.as<uint32_t>() + 3, 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        return GM_OK;
+    };
+    auto fetch_heavy = [&](uint32_t nh) -> int {
         GM_TRACE("map_device: %u reads, seeds done, %u read x strands on the heavy path (> %u SA hits)", b->n, nh, heavy_min);
+        heavy.clear();
         if (nh) {
             heavy.resize(3 * (size_t)nh);
             HIPCHK(hipMemcpy(heavy.data(), b->heavy_list.p, heavy.size() * 4, hipMemcpyDeviceToHost));
         }
         return GM_OK;
+    };
+    auto collect_heavy = [&]() -> int {              // the two-kernel form: right after k_seed
+        int rc2 = collect_heavy_enqueue();
+        if (rc2) return rc2;
+        HIPCHK(hipMemcpyAsync(hs_small, b->small.p, 64, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return fetch_heavy(hs_small[3]);
     };
     if (!dp.fused) { rc = collect_heavy(); if (rc) return rc; }
     auto run_heavy = [&]() -> int {                  // expand + sort + run-length vote, chunk by chunk under the key budget
@@ -884,14 +897,16 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         }
         return GM_OK;
     };
-    std::vector<uint32_t> shard_host((size_t)GM_NSHARD * GM_SHARD_STRIDE);
-    auto read_shards = [&](uint64_t& total, uint32_t& mx) -> int {
-        HIPCHK(hipMemcpyAsync(shard_host.data(), b->shards.p, shard_host.size() * 4, hipMemcpyDeviceToHost, st));
+    // candidates per shard: total and maximum are reduced on the device (gmk_shard_stats -> small[4], small[5]) and come back with the status words
+    auto read_status = [&](uint64_t& total, uint32_t& mx) -> int {
+        KCHK(gmk_shard_stats(b->dev, b->small.as<uint32_t>() + 4, st));
+        HIPCHK(hipMemcpyAsync(hs_small, b->small.p, 64, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(hs_ctr, b->counters.p, GMK_N * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        total = 0; mx = 0;
-        for (int s = 0; s < GM_NSHARD; ++s) { uint32_t c = shard_host[(size_t)s * GM_SHARD_STRIDE]; total += c; mx = std::max(mx, c); }
+        total = hs_small[4]; mx = hs_small[5];
         return GM_OK;
     };
+    auto read_shards = read_status;
     for (int attempt = 0;; ++attempt) {
         HIPCHK(hipMemsetAsync(b->small.p, 0, 64, st));
         HIPCHK(hipMemsetAsync(b->shards.p, 0, (size_t)GM_NSHARD * GM_SHARD_STRIDE * 4, st));
@@ -909,13 +924,13 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
             else KCHK(gmk_vote(ix->dev, dp, b->dev, use_full, dense, slots_hint, st));
             KCHK(gmk_cand_gather(b->dev, st));
         }
-        if (dp.fused) { heavy.clear(); rc = collect_heavy(); if (rc) return rc; }
-        uint32_t small[2];
-        HIPCHK(hipMemcpyAsync(small, b->small.p, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(ctr, b->counters.p, sizeof ctr, hipMemcpyDeviceToHost, st));
+        if (dp.fused) { rc = collect_heavy_enqueue(); if (rc) return rc; }
         uint64_t total = 0; uint32_t mx = 0;
-        rc = read_shards(total, mx);
+        rc = read_status(total, mx);                 // the one wait of the vote phase
         if (rc) return rc;
+        memcpy(ctr, hs_ctr, sizeof ctr);
+        const uint32_t small[2] = { hs_small[0], hs_small[1] };
+        if (dp.fused) { rc = fetch_heavy(hs_small[3]); if (rc) return rc; }
         if (dp.dbg & 64) {                           // sampled phase clocks of the vote kernel (cycles of one lane per sampled workgroup)
             const double ns = (double)std::max<unsigned long long>(1, ctr[GMK_DBG8]);
             fprintf(stderr, "[gm_dbg] vote phases (mean cycles per sampled read x strand, %llu samples): desc %.0f, loads+window %.0f, pass1 %.0f, pass2a %.0f, scan %.0f, "
@@ -1241,14 +1256,11 @@ extern "C" int gm_map_batch(gm_index* ix, const gm_params* p, gm_batch* b, const
     const uint32_t n = b->n;
     out->n = n;
     if (n == 0) { out->match_begin[0] = 0; return GM_OK; }
-    uint64_t n_hits = 0;
-    HIPCHK(hipMemcpyAsync(&n_hits, b->hit_begin.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    pc.lap("device");
-    if (n_hits > b->raw_cap) { gm_set_error("internal: raw hit buffer too small"); return GM_E_CAPACITY; }
-    if (n_hits > 0xFFFFFFF0ull) { gm_set_error("more than 2^32 accepted hits in one batch; map the block in smaller pieces"); return GM_E_BATCH_TOO_LARGE; }
-    b->n_raw = n_hits;
-    const size_t nh = (size_t)n_hits + 16;
+    // the number of accepted hits stays on the device until the grouping kernels are done (no wait here): the workspace is sized by
+    // its upper bound, the candidates of the block (resume: the count the first call read)
+    const uint64_t hits_bound = resume ? b->n_raw : (uint64_t)b->n_cands;
+    if (hits_bound > 0xFFFFFFF0ull) { gm_set_error("more than 2^32 accepted hits in one batch; map the block in smaller pieces"); return GM_E_BATCH_TOO_LARGE; }
+    const size_t nh = (size_t)hits_bound + 16;
     if (b->g_sorted.ensure(nh * sizeof(GmRawHit)) || b->g_ord.ensure(nh * 4) || b->g_lead.ensure(nh * 4) || b->g_krank.ensure(nh * 4) ||
         b->g_khash.ensure(nh * 8) || b->g_positions.ensure(nh * sizeof(GmDevPos)) || b->g_matches.ensure(nh * sizeof(GmDevMatch)) || b->g_mhit.ensure(nh * 4) ||
         b->g_nmatch.ensure((size_t)n * 4) || b->g_mbegin.ensure(((size_t)n + 1) * 8) || b->g_multi.ensure((size_t)n * 4 + 64) ||
@@ -1271,15 +1283,20 @@ extern "C" int gm_map_batch(gm_index* ix, const gm_params* p, gm_batch* b, const
     }
     // what the host pass needs: per-read status / top score, the CSR of the hits and their scores in processing order
     if (b->h_top.ensure((size_t)n * 4) || b->h_hbegin.ensure(((size_t)n + 1) * 8) || b->h_ord.ensure(nh * 4)) return GM_E_NOMEM;
-    uint64_t n_m = 0;
-    HIPCHK(hipMemcpyAsync(&n_m, g.match_begin + n, 8, hipMemcpyDeviceToHost, st));
+    if (b->h_stat.ensure(64 + GMK_N * 8 + 64)) return GM_E_NOMEM;
+    uint64_t* const hs64 = b->h_stat.as<uint64_t>();        // [0] matches, [1] accepted hits: page-locked, with the rest of the phase's copies
+    HIPCHK(hipMemcpyAsync(&hs64[0], g.match_begin + n, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&hs64[1], b->hit_begin.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(out->status, b->status.p, n, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(out->self_score, b->self_score.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(b->h_top.p, b->top_score.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(b->h_hbegin.p, b->hit_begin.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, st));
-    if (n_hits) HIPCHK(hipMemcpyAsync(b->h_ord.p, g.ord_score, (size_t)n_hits * 4, hipMemcpyDeviceToHost, st));
+    if (hits_bound) HIPCHK(hipMemcpyAsync(b->h_ord.p, g.ord_score, (size_t)hits_bound * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(out->match_begin, g.match_begin, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    const uint64_t n_m = hs64[0], n_hits = hs64[1];
+    if (n_hits > hits_bound) { gm_set_error("internal: more accepted hits than candidates"); return GM_E_HIP; }
+    b->n_raw = n_hits;
     pc.lap("group");
     if (gm_trace_on()) {
         uint32_t cnt[16] = { 0 };
@@ -1362,13 +1379,12 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
             for (uint64_t m = m0; m < m1; ++m) {
                 const gm_match& mm = hits->matches[m];
                 if (mm.read != i || mm.pos_end < mm.pos_begin || mm.pos_end > hits->positions_cap || mm.first_strand > 1 || mm.first_pos >= ix->h.l_pac) { bad = true; break; }
+                for (uint32_t q = mm.pos_begin; q < mm.pos_end; ++q) if (hits->positions[q].strand > 1 || hits->positions[q].pos >= ix->h.l_pac) bad = true;   // the places of THIS match (slots no match points at are never read)
                 n_p = std::max<uint64_t>(n_p, mm.pos_end);
             }
         }
         if (bad) { gm_set_error("gm_hits: a match does not belong to its read, or its positions / first position are out of range"); return GM_E_ARG; }
         if (b->cache_matches == n_m64 && b->cache_hits <= hits->positions_cap && b->cache_hits >= n_p) n_p = b->cache_hits;     // this batch's own gm_map_batch result: positions share the hit CSR
-        for (uint64_t q = 0; q < n_p; ++q) if (hits->positions[q].strand > 1 || hits->positions[q].pos >= ix->h.l_pac) { bad = true; break; }
-        if (bad) { gm_set_error("gm_hits: a position is outside the reference"); return GM_E_ARG; }
     }
     const uint32_t ops_words = gm_ops_words(b->stride), codes_stride = 32u * ops_words;
     const bool nuc = p->mode != GM_MODE_NORMAL && ix->nuc_on;

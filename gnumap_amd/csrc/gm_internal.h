@@ -167,6 +167,7 @@ int gmk_scan_entries(const GmDevBatch& b, void* stream);
 int gmk_locate_sampled(const GmDevIndex& ix, const GmDevBatch& b, void* stream);
 int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, int dense, int slots_hint, void* stream);
 int gmk_cand_gather(const GmDevBatch& b, void* stream);
+int gmk_shard_stats(const GmDevBatch& b, uint32_t* out /* {total, max} in device memory */, void* stream);
 // gm_bucket.hip: the bucket table and the one-wave-per-read vote kernel that looks its seeds up in it
 int gmk_build_bucket(const uint2* tab, const uint32_t* full_sa, uint4* bucket, int T, void* stream);
 int gmk_vote_bucket(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint32_t max_reg, void* stream);

@@ -2278,6 +2278,22 @@ __global__ void __launch_bounds__(256) k_cand_gather(GmDevBatch b) {
         if (base + k < b.cand_region) b.cands[(size_t)shard * b.cand_region + base + k] = b.fixed_cands[(size_t)rs * GM_FIXED_C + k];
 }
 
+// total and maximum of the candidate shards' fill counts, for the host's sizing decision: 8 bytes come back instead of the 128 KB the
+// counters are spread over (one 128-byte line each)
+__global__ void __launch_bounds__(256) k_shard_stats(GmDevBatch b, uint32_t* out /* {total, max} */) {
+    __shared__ uint32_t s_sum[4], s_max[4];
+    uint32_t sum = 0, mx = 0;
+    for (uint32_t q = threadIdx.x; q < GM_NSHARD; q += 256) { const uint32_t c = b.shard_cnt[(size_t)q * GM_SHARD_STRIDE]; sum += c; mx = c > mx ? c : mx; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { sum += __shfl_xor(sum, off); const uint32_t o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
+    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = sum; s_max[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        out[1] = std::max(std::max(s_max[0], s_max[1]), std::max(s_max[2], s_max[3]));
+    }
+}
+
 __global__ void __launch_bounds__(256) k_scatter_hits(GmDevBatch b) {
     __shared__ uint32_t s_pre[GM_NSHARD + 4];
     const uint32_t n_cands = gm_cand_prefix(b, s_pre);
@@ -2790,6 +2806,11 @@ int gmk_vote_list(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& 
     const uint32_t lgrid = (uint32_t)std::min<uint64_t>(cdiv(2ull * b.n, 4), 256 * 20);
     if (b.max_seeds > 32) hipLaunchKernelGGL(k_vote_fast_list<true>, dim3(lgrid), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
     else hipLaunchKernelGGL(k_vote_fast_list<false>, dim3(lgrid), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
+    return (int)hipGetLastError();
+}
+
+int gmk_shard_stats(const GmDevBatch& b, uint32_t* out, void* stream) {
+    hipLaunchKernelGGL(k_shard_stats, dim3(1), dim3(256), 0, S_(stream), b, out);
     return (int)hipGetLastError();
 }
 
