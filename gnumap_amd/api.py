@@ -50,7 +50,8 @@ class gm_match(C.Structure):
 
 class gm_hits(C.Structure):
     _fields_ = [("n", C.c_uint32), ("status", C.c_void_p), ("self_score", C.c_void_p), ("top_score", C.c_void_p), ("denominator", C.c_void_p),
-                ("match_begin", C.c_void_p), ("matches", C.c_void_p), ("matches_cap", u64), ("positions", C.c_void_p), ("positions_cap", u64)]
+                ("match_begin", C.c_void_p), ("matches", C.c_void_p), ("matches_cap", u64), ("positions", C.c_void_p), ("positions_cap", u64),
+                ("stamp", u64)]
 
 
 class gm_sam_rec(C.Structure):
@@ -77,7 +78,7 @@ SAM_DTYPE = np.dtype([("read", "<u4"), ("pos", "<u8"), ("contig", "<u4"), ("chr_
                       ("a_score", "<f4"), ("post_prob", "<f4"), ("sim_matches", "<i4"), ("cigar_off", "<u4")], align=True)
 
 # every symbol include/gnumap_hip.h declares
-EXPORTS = ["gm_last_error", "gm_version", "gm_set_option", "gm_index_build", "gm_index_build_on", "gm_index_open", "gm_index_close", "gm_index_get_info", "gm_index_contig_name",
+EXPORTS = ["gm_last_error", "gm_version", "gm_set_option", "gm_index_build", "gm_index_build_on", "gm_index_open", "gm_index_close", "gm_index_prepare", "gm_index_get_info", "gm_index_contig_name",
            "gm_index_contig_offset", "gm_index_window", "gm_params_default", "gm_params_finalize", "gm_params_load_subst", "gm_batch_create", "gm_batch_destroy",
            "gm_batch_upload", "gm_map_batch_device", "gm_batch_counters", "gm_batch_path", "gm_batch_set_profiling", "gm_batch_kernel_times", "gm_kernel_name",
            "gm_batch_raw_hits", "gm_stream_create", "gm_stream_destroy", "gm_host_alloc", "gm_host_free", "gm_map_batch", "gm_output_batch",
@@ -107,6 +108,7 @@ def load_library():
     L.gm_index_build_on.argtypes = [C.c_char_p, C.c_int, C.c_int]
     L.gm_index_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.gm_index_close.argtypes = [C.c_void_p]; L.gm_index_close.restype = None
+    L.gm_index_prepare.argtypes = [C.c_void_p, C.POINTER(gm_params)]
     L.gm_index_get_info.argtypes = [C.c_void_p, C.POINTER(gm_index_info)]
     L.gm_index_contig_name.argtypes = [C.c_void_p, C.c_uint32]; L.gm_index_contig_name.restype = C.c_char_p
     L.gm_index_contig_offset.argtypes = [C.c_void_p, C.c_uint32]; L.gm_index_contig_offset.restype = u64
@@ -235,6 +237,10 @@ class Index:
             self.close()
         except Exception:
             pass
+
+    def prepare(self, params):
+        """build the k-mer tables / records for these parameters now (gm_index_prepare) instead of inside the first map call"""
+        _chk(lib().gm_index_prepare(self.h, C.byref(params.c)))
 
     def contigs(self):
         return [(lib().gm_index_contig_name(self.h, i).decode(), lib().gm_index_contig_offset(self.h, i)) for i in range(self.info.n_seqs)]

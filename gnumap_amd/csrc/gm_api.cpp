@@ -17,6 +17,8 @@
 #include <functional>
 #include <set>
 #include <thread>
+#include <fcntl.h>
+#include <unistd.h>
 
 static thread_local std::string g_err;
 // ---- run-time switches: gm_set_option() overrides, else the environment; never latched (see gm_internal.h) ----
@@ -131,6 +133,9 @@ struct gm_batch {
     PinBuf h_top, h_hbegin, h_ord, h_post, h_mapq, h_emit, h_mhit, h_stat;      // h_stat: the small status words a phase reads back (page-locked: one short DMA)
     std::vector<double> h_exp;          // exp(score) of every accepted hit of the last gm_map_batch (reused by gm_output_batch)
     uint64_t cache_hits = 0, cache_matches = 0;
+    uint32_t fixed_epoch = 0;           // launch stamp of the own-slot candidates of k_vote_bucket (GmDevBatch::fixed_epoch); 0 = the count array form
+    uint32_t epoch_ctr = 0;
+    uint64_t stamp = 0;                 // names the gm_map_batch result resident in g_matches / g_positions (gm_hits::stamp); 0 = none
     std::string path;                   // which kernels the last gm_map_batch_device chose (gm_batch_path)
     // gm_*_enqueue / gm_batch_wait: the batch's own service thread runs the queued calls in order, the caller goes on
     struct Service {
@@ -463,6 +468,17 @@ extern "C" int gm_index_open(const char* fasta_path, int device_id, int flags, g
     return GM_OK;
 }
 
+// the tables the mapping kernels need for these parameters (memoised backward search of the seed, its compact form, the k-mer ->
+// positions records) are built on the first gm_map_batch_device otherwise: a driver that wants its first block at full rate stages
+// them with the index
+extern "C" int gm_index_prepare(gm_index* ix, const gm_params* p) {
+    if (!ix || !p || !p->finalized) return GM_E_ARG;
+    if (ix->host_only) return GM_E_NO_DEVICE;
+    HIPCHK(hipSetDevice(ix->device));
+    GmDevParams dp;
+    return sync_params(ix, p, dp, nullptr, true);
+}
+
 extern "C" void gm_index_close(gm_index* ix) {
     if (!ix) return;
     if (!ix->host_only && ix->device >= 0) {
@@ -592,7 +608,7 @@ static void fill_dev_batch(gm_batch* b) {
     d.gtab_keys = b->gtab_keys.as<uint32_t>(); d.gtab_vals = b->gtab_vals.as<uint32_t>();
     d.cands = b->cands.as<GmCand>(); d.cand_cap = b->cand_cap; d.cand_region = b->cand_cap / GM_NSHARD;
     d.shard_cnt = b->shards.as<uint32_t>();
-    d.fixed_cands = b->use_fixed ? b->fixed_cands.as<GmCand>() : nullptr; d.fixed_cnt = b->fixed_cnt.as<uint8_t>();
+    d.fixed_cands = b->use_fixed ? b->fixed_cands.as<GmCand>() : nullptr; d.fixed_cnt = b->fixed_cnt.as<uint8_t>(); d.fixed_epoch = b->use_fixed ? b->fixed_epoch : 0u;
     d.hit_count = b->hit_count.as<uint32_t>(); d.hit_begin = b->hit_begin.as<uint64_t>(); d.hit_cursor = b->hit_cursor.as<uint32_t>();
     d.raw_hits = b->raw_hits.as<GmRawHit>(); d.raw_cap = b->raw_cap;
     d.counters = b->counters.as<unsigned long long>();
@@ -607,7 +623,7 @@ extern "C" int gm_batch_upload(gm_batch* b, const gm_params* p, const gm_reads* 
     if (r->stride % 8 != 0) { gm_set_error("gm_reads.stride must be a multiple of 8"); return GM_E_ARG; }
     HIPCHK(hipSetDevice(b->ix->device));
     hipStream_t st = S_(stream);
-    b->n = r->n; b->stride = r->stride; b->mapped = false; b->cache_hits = b->cache_matches = 0; b->resume_ptr = nullptr;
+    b->n = r->n; b->stride = r->stride; b->mapped = false; b->cache_hits = b->cache_matches = 0; b->resume_ptr = nullptr; b->stamp = 0;
     size_t bytes = (size_t)r->n * r->stride;
     if (b->bases.ensure(bytes + 16) || b->quals.ensure(bytes + 16) || b->len.ensure((size_t)r->n * 2 + 16)) return GM_E_NOMEM;
     b->len_host.assign(r->len, r->len + r->n);
@@ -817,7 +833,12 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
     {
         const bool fixed_ok = !gm_opt_is("GM_VOTE_FIXED", "0");
         b->use_fixed = fixed_ok && (use_bucket || ((dense == 1 || dense == 2) && !gm_opt("GM_VOTE_KERNEL")));      // k_vote_bucket, k_vote_tiny*, k_vote_slots (all forms)
-        if (b->use_fixed && (b->fixed_cands.ensure(2 * (size_t)b->n * GM_FIXED_C * sizeof(GmCand)) || b->fixed_cnt.ensure(2 * (size_t)b->n + 64))) return GM_E_NOMEM;
+        if (b->use_fixed) {
+            const void* before = b->fixed_cands.p;
+            if (b->fixed_cands.ensure(2 * (size_t)b->n * GM_FIXED_C * sizeof(GmCand)) || b->fixed_cnt.ensure(2 * (size_t)b->n + 64)) return GM_E_NOMEM;
+            if (b->fixed_cands.p != before) { HIPCHK(hipMemsetAsync(b->fixed_cands.p, 0, b->fixed_cands.cap, st)); b->epoch_ctr = 0; }      // new memory: no stale launch stamps
+        }
+        b->fixed_epoch = 0;
     }
     {
         char buf[160];
@@ -913,7 +934,11 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         HIPCHK(hipMemsetAsync(b->rs_overflow.p, 0, 2 * (size_t)b->n, st));
         HIPCHK(hipMemsetAsync(b->counters.as<unsigned long long>() + GMK_HEAVY_SLOTS, 0, 8, st));
         HIPCHK(hipMemsetAsync(b->counters.as<unsigned long long>() + GMK_OVERFLOW_RS, 0, 8, st));
-        if (b->use_fixed) HIPCHK(hipMemsetAsync(b->fixed_cnt.p, 0, 2 * (size_t)b->n, st));
+        if (b->use_fixed && use_bucket) {           // own-slot candidates carry the launch's stamp: nothing to zero
+            if (++b->epoch_ctr == 0) { HIPCHK(hipMemsetAsync(b->fixed_cands.p, 0, b->fixed_cands.cap, st)); b->epoch_ctr = 1; }
+            b->fixed_epoch = b->epoch_ctr;
+            fill_dev_batch(b);
+        } else if (b->use_fixed) HIPCHK(hipMemsetAsync(b->fixed_cnt.p, 0, 2 * (size_t)b->n, st));
         if (dp.fused) {                              // the seed search runs inside the vote launch: its work counters start over with it
             HIPCHK(hipMemsetAsync(b->counters.as<unsigned long long>() + GMK_KMERS, 0, 4 * 8, st));            // KMERS, OCC, SEEDS, SA_HITS
             HIPCHK(hipMemsetAsync(b->counters.as<unsigned long long>() + GMK_OCC_BLOCKS, 0, 2 * 8, st));       // OCC_BLOCKS, TAB_LOOKUPS
@@ -1273,7 +1298,7 @@ extern "C" int gm_map_batch(gm_index* ix, const gm_params* p, gm_batch* b, const
     g.big_list = b->g_big.as<uint32_t>(); g.n_big = b->o_small.as<uint32_t>() + 1; g.big_done = b->g_bigdone.as<uint8_t>();
     g.sk0 = b->g_sk0.as<unsigned long long>(); g.sk1 = b->g_sk1.as<unsigned long long>(); g.si0 = b->g_si0.as<uint32_t>(); g.si1 = b->g_si1.as<uint32_t>();
     g.matches = b->g_matches.as<GmDevMatch>(); g.match_hit = b->g_mhit.as<uint32_t>(); g.positions = b->g_positions.as<GmDevPos>();
-    b->cache_hits = b->cache_matches = 0;
+    b->cache_hits = b->cache_matches = 0; b->stamp = 0; out->stamp = 0;
     if (!resume) {
         HIPCHK(hipMemsetAsync(b->o_small.p, 0, 64, st));
         if (p->unique_only && !p->nw) HIPCHK(hipMemsetAsync(b->g_positions.p, 0, nh * sizeof(GmDevPos), st));      // dropped hits leave holes
@@ -1340,6 +1365,11 @@ extern "C" int gm_map_batch(gm_index* ix, const gm_params* p, gm_batch* b, const
     pc.lap("exp");
     HIPCHK(hipStreamSynchronize(st));
     b->cache_hits = n_hits; b->cache_matches = n_m;          // h_exp / h_ord / h_mhit describe this result
+    {
+        static std::atomic<uint64_t> next_stamp{ 1 };
+        b->stamp = next_stamp.fetch_add(1);
+        out->stamp = b->stamp;
+    }
     pc.lap("records");
     return GM_OK;
 }
@@ -1366,11 +1396,14 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
     if (n_m64 > 0x7FFFFFFFull) { gm_set_error("too many matches in one batch; map the block in smaller pieces"); return GM_E_BATCH_TOO_LARGE; }
     const uint32_t n_m = (uint32_t)n_m64;
     // ---- device, part 1: everything that does not depend on the posteriors is enqueued BEFORE the host pass and runs under it ----
-    // `hits` may have been edited by the caller: everything the kernels index with is checked HERE, before the first enqueue (a match
-    // of another read would make k_traceback read rows that do not exist, a position range beyond the buffer would make k_out_items
-    // write past o_posmatch)
+    // hits->stamp names this batch's resident result: its matches / positions are used where they are.  Otherwise `hits` may have been
+    // edited by the caller: everything the kernels index with is checked HERE, before the first enqueue (a match of another read
+    // would make k_traceback read rows that do not exist, a position range beyond the buffer would make k_out_items write past
+    // o_posmatch), and the records are uploaded again.
+    const bool resident = hits->stamp != 0 && hits->stamp == b->stamp && b->cache_matches == n_m64 && b->cache_hits <= hits->positions_cap;
     uint64_t n_p = 0;
-    {
+    if (resident) n_p = b->cache_hits;
+    else {
         if (hits->match_begin[0] != 0) { gm_set_error("gm_hits: match_begin[0] must be 0"); return GM_E_ARG; }
         bool bad = false;
         for (uint32_t i = 0; i < n && !bad; ++i) {
@@ -1384,7 +1417,7 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
             }
         }
         if (bad) { gm_set_error("gm_hits: a match does not belong to its read, or its positions / first position are out of range"); return GM_E_ARG; }
-        if (b->cache_matches == n_m64 && b->cache_hits <= hits->positions_cap && b->cache_hits >= n_p) n_p = b->cache_hits;     // this batch's own gm_map_batch result: positions share the hit CSR
+        if (b->cache_matches == n_m64 && b->cache_hits <= hits->positions_cap && b->cache_hits >= n_p) n_p = b->cache_hits;     // positions share the hit CSR
     }
     const uint32_t ops_words = gm_ops_words(b->stride), codes_stride = 32u * ops_words;
     const bool nuc = p->mode != GM_MODE_NORMAL && ix->nuc_on;
@@ -1395,8 +1428,11 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
         b->o_cigoff.ensure(((size_t)n_m + 1) * 8) || b->scan_tmp.ensure(((size_t)std::max<uint32_t>(n_m, n) / 1024 + 8) * 8) || b->o_small.ensure(64) ||
         (nuc && b->o_codes.ensure((size_t)n_m * codes_stride))) return GM_E_NOMEM;
     const GmDevMatch* d_m = b->g_matches.as<GmDevMatch>(); const GmDevPos* d_p = b->g_positions.as<GmDevPos>();
-    HIPCHK(hipMemcpyAsync(b->g_matches.p, hits->matches, (size_t)n_m * sizeof(gm_match), hipMemcpyHostToDevice, st));
-    if (n_p) HIPCHK(hipMemcpyAsync(b->g_positions.p, hits->positions, (size_t)n_p * sizeof(gm_pos), hipMemcpyHostToDevice, st));
+    if (!resident) {
+        HIPCHK(hipMemcpyAsync(b->g_matches.p, hits->matches, (size_t)n_m * sizeof(gm_match), hipMemcpyHostToDevice, st));
+        if (n_p) HIPCHK(hipMemcpyAsync(b->g_positions.p, hits->positions, (size_t)n_p * sizeof(gm_pos), hipMemcpyHostToDevice, st));
+        b->stamp = 0;                                          // what is resident now is the caller's version
+    }
     HIPCHK(hipMemsetAsync(b->o_posmatch.p, 0xFF, (size_t)(n_p + 1) * 4, st));
     HIPCHK(hipMemsetAsync(b->o_small.p, 0, 64, st));
     if (p->max_gap != 3 && b->band_moves.ensure(gm_band_moves_words(n_m, b->stride) * 8)) return GM_E_NOMEM;
@@ -1678,7 +1714,10 @@ extern "C" int gm_dev_traceback(gm_index* ix, const gm_params* p, const gm_reads
 // ------------------------------------------------------------------------------------------------
 extern "C" int gm_coverage_reset(gm_index* ix, uint32_t bin_size) {
     if (!ix || bin_size == 0) return GM_E_ARG;
-    if (ix->host_only) return GM_E_NO_DEVICE;
+    if (ix->host_only) {                                // no track in HBM: only the geometry the text writers need (CPU-side tests of gm_coverage_write_*)
+        ix->cov_bins = ix->h.l_pac / bin_size + 64; ix->cov_bin_size = bin_size;
+        return GM_OK;
+    }
     HIPCHK(hipSetDevice(ix->device));
     uint64_t bins = ix->h.l_pac / bin_size + 64;        // the reference allocates l_pac/gGEN_SIZE floats and writes a little past it
     if (ix->d_cov.ensure(bins * 4)) return GM_E_NOMEM;
@@ -1722,37 +1761,99 @@ extern "C" int gm_coverage_download(gm_index* ix, float* host) {
 
 enum { MAX_SGR_LINE = 1200 };
 
+// ---- track text at memory speed ------------------------------------------------------------------------------------------------------
+// printf("%.Nf") of a float bin, N = 5 or 6, without printf: a float has 24 significant bits, so value x 10^N is exact in a double for
+// every value below 2^53 / 10^N x 2^-17 (far beyond any coverage), and rint() of an exact number in the default rounding mode is the
+// correctly rounded decimal glibc's printf prints (ties to even included).  Larger or non-finite values take snprintf.
+static inline char* put_fixed(char* w, float v, int decimals) {
+    const double scale = decimals == 5 ? 100000.0 : 1000000.0;
+    if (!(v >= 0.0f) || !(v < 1.0e9f)) return w + snprintf(w, 64, decimals == 5 ? "%.5f" : "%f", v);
+    const uint64_t q = (uint64_t)rint((double)v * scale);
+    const uint64_t ip = q / (uint64_t)scale; uint32_t fp = (uint32_t)(q % (uint64_t)scale);
+    char tmp[24]; int k = 0;
+    uint64_t t = ip;
+    do { tmp[k++] = (char)('0' + t % 10); t /= 10; } while (t);
+    while (k) *w++ = tmp[--k];
+    *w++ = '.';
+    for (int d = decimals - 1; d >= 0; --d) { w[d] = (char)('0' + fp % 10); fp /= 10; }
+    return w + decimals;
+}
+static inline char* put_long(char* w, long v) {
+    if (v < 0) { *w++ = '-'; v = -v; }
+    char tmp[24]; int k = 0;
+    do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (k) *w++ = tmp[--k];
+    return w;
+}
+
+// bins [0, nb) in slabs: host_threads() threads format one slice of a slab each (emit(k, w) appends the line of bin k, if it has
+// one), the pieces are written with pwrite() at their offsets by the same threads
+template <class Emit> static int write_track_text(const char* path, int append, uint64_t nb, size_t max_line, Emit&& emit) {
+    const int fd = ::open(path, O_WRONLY | O_CREAT | (append ? O_APPEND : O_TRUNC), 0644);
+    if (fd < 0) { gm_set_error(std::string("cannot write ") + path); return GM_E_IO; }
+    uint64_t file_off = append ? (uint64_t)lseek(fd, 0, SEEK_END) : 0;
+    const unsigned T = host_threads();
+    const uint64_t per = 1u << 20;                               // bins per slice
+    std::vector<std::vector<char>> buf(T);
+    std::vector<size_t> used(T);
+    std::atomic<int> bad{ 0 };
+    for (uint64_t s0 = 0; s0 < nb && !bad; s0 += per * T) {
+        const unsigned parts = (unsigned)std::min<uint64_t>(T, (nb - s0 + per - 1) / per);
+        auto format = [&](unsigned c) {
+            const uint64_t lo = s0 + c * per, hi = std::min<uint64_t>(nb, lo + per);
+            std::vector<char>& o = buf[c];
+            if (o.size() < (size_t)(hi - lo) * max_line) o.resize((size_t)(hi - lo) * max_line);
+            char* w = o.data();
+            for (uint64_t k = lo; k < hi; ++k) w = emit(k, w, c, k == lo);
+            used[c] = (size_t)(w - o.data());
+        };
+        {
+            std::vector<std::thread> th;
+            for (unsigned c = 1; c < parts; ++c) th.emplace_back(format, c);
+            format(0);
+            for (auto& x : th) x.join();
+        }
+        std::vector<uint64_t> off(parts);
+        for (unsigned c = 0; c < parts; ++c) { off[c] = file_off; file_off += used[c]; }
+        auto put = [&](unsigned c) {
+            const char* q = buf[c].data(); size_t n = used[c]; uint64_t at = off[c];
+            while (n) { const ssize_t k = ::pwrite(fd, q, n, (off_t)at); if (k <= 0) { bad = 1; return; } q += k; n -= (size_t)k; at += (uint64_t)k; }
+        };
+        {
+            std::vector<std::thread> th;
+            for (unsigned c = 1; c < parts; ++c) th.emplace_back(put, c);
+            put(0);
+            for (auto& x : th) x.join();
+        }
+    }
+    ::close(fd);
+    if (bad) { gm_set_error(std::string("write failed: ") + path); return GM_E_IO; }
+    return GM_OK;
+}
+
 extern "C" int gm_coverage_write_sgr(gm_index* ix, const float* bins, const char* path, int append) {
     // GenomeBwt::PrintFinalSGR src/GenomeBwt.cpp:1212-1273: bins run over the CONCATENATED coordinate
     if (!ix || !bins || !path || !ix->cov_bin_size) return GM_E_ARG;
-    FILE* f = fopen(path, append ? "a" : "w");
-    if (!f) { gm_set_error(std::string("cannot write ") + path); return GM_E_IO; }
     const GmHostIndex& h = ix->h;
     const uint64_t bs = ix->cov_bin_size;
     // the reference walks `count` over the concatenated coordinate in steps of bin_size without resetting it per contig,
-    // so bin k is printed under the contig that holds k * bin_size; text is produced in parallel slices, written in order
+    // so bin k is printed under the contig that holds k * bin_size
     const uint64_t nb = (h.l_pac + bs - 1) / bs;
-    const uint64_t slab = 1u << 22;
-    for (uint64_t s0 = 0; s0 < nb; s0 += slab * host_threads()) {
-        const uint32_t span = (uint32_t)std::min<uint64_t>(nb - s0, slab * host_threads());
-        std::vector<std::string> parts(host_threads());
-        const unsigned T = parallel_chunks(span, 65536, host_threads(), [&](unsigned c, uint32_t lo, uint32_t hi) {
-            std::string& out = parts[c];
-            char buf[MAX_SGR_LINE];
-            int i = lo < hi ? host_pos2rid(h, (s0 + lo) * bs) : 0;
-            for (uint64_t k = s0 + lo; k < s0 + hi; ++k) {
-                const uint64_t count = k * bs;
-                while ((size_t)i + 1 < h.contigs.size() && count >= h.contigs[(size_t)i + 1].offset) ++i;
-                if ((double)bins[k] > 0.001) {      // MIN_PRINT, GenomeBwt.cpp:928
-                    int len = snprintf(buf, sizeof buf, "%s\t%ld\t%.5f\n", h.contigs[(size_t)i].name.c_str(), (long)(count - h.contigs[(size_t)i].offset) + 1, bins[k]);
-                    out.append(buf, (size_t)std::min<int>(len, (int)sizeof buf - 1));
-                }
-            }
-        });
-        for (unsigned c = 0; c < T; ++c) if (!parts[c].empty()) fwrite(parts[c].data(), 1, parts[c].size(), f);
-    }
-    fclose(f);
-    return GM_OK;
+    size_t max_name = 0;
+    for (const auto& c : h.contigs) max_name = std::max(max_name, c.name.size());
+    std::vector<int> cur(host_threads(), 0);
+    return write_track_text(path, append, nb, max_name + 48, [&](uint64_t k, char* w, unsigned c, bool first) -> char* {
+        int& i = cur[c];
+        const uint64_t count = k * bs;
+        if (first) i = (int)host_pos2rid(h, count);
+        while ((size_t)i + 1 < h.contigs.size() && count >= h.contigs[(size_t)i + 1].offset) ++i;
+        if (!((double)bins[k] > 0.001)) return w;       // MIN_PRINT, GenomeBwt.cpp:928
+        const GmContig& cg = h.contigs[(size_t)i];
+        memcpy(w, cg.name.data(), cg.name.size()); w += cg.name.size();
+        *w++ = '\t'; w = put_long(w, (long)(count - cg.offset) + 1); *w++ = '\t';
+        w = put_fixed(w, bins[k], 5); *w++ = '\n';
+        return w;
+    });
 }
 
 extern "C" int gm_coverage_enable_nuc(gm_index* ix) {
@@ -1776,35 +1877,26 @@ extern "C" int gm_coverage_download_nuc(gm_index* ix, float* host) {
 extern "C" int gm_coverage_write_gmp(gm_index* ix, const gm_params* p, const float* bins, const float* nuc, const char* path, int append) {
     // GenomeBwt::PrintFinalBisulfite src/GenomeBwt.cpp:1092-1210
     if (!ix || !p || !bins || !nuc || !path || !ix->cov_bin_size || p->mode == GM_MODE_NORMAL) return GM_E_ARG;
-    FILE* f = fopen(path, append ? "a" : "w");
-    if (!f) { gm_set_error(std::string("cannot write ") + path); return GM_E_IO; }
     const GmHostIndex& h = ix->h;
     const uint64_t bs = ix->cov_bin_size, nb = ix->cov_bins;
     const char want = p->mode == GM_MODE_BS ? 'c' : p->mode == GM_MODE_BS2 ? 'g' : p->mode == GM_MODE_ATOG ? 'a' : 't';
     const uint64_t nbk = (h.l_pac + bs - 1) / bs;
-    const uint64_t slab = 1u << 22;
-    for (uint64_t s0 = 0; s0 < nbk; s0 += slab * host_threads()) {
-        const uint32_t span = (uint32_t)std::min<uint64_t>(nbk - s0, slab * host_threads());
-        std::vector<std::string> parts(host_threads());
-        const unsigned T = parallel_chunks(span, 65536, host_threads(), [&](unsigned c, uint32_t lo, uint32_t hi) {
-            std::string& out = parts[c];
-            char buf[MAX_SGR_LINE];
-            int i = lo < hi ? host_pos2rid(h, (s0 + lo) * bs) : 0;
-            for (uint64_t k = s0 + lo; k < s0 + hi; ++k) {
-                const uint64_t count = k * bs;
-                while ((size_t)i + 1 < h.contigs.size() && count >= h.contigs[(size_t)i + 1].offset) ++i;
-                char at = "acgt"[(h.pac[count >> 2] >> ((~count & 3) << 1)) & 3];
-                if (at != want) continue;
-                if (bins[k] > 0.0f) {
-                    int len = snprintf(buf, sizeof buf, "%s\t%ld\t%f\t%.5f\t%.5f\t%.5f\t%.5f\t%.5f\n", h.contigs[(size_t)i].name.c_str(),
-                                       (long)(count - h.contigs[(size_t)i].offset) + 1, bins[k], nuc[k], nuc[nb + k], nuc[2 * nb + k], nuc[3 * nb + k],
-                                       nuc[4 * nb + k]);
-                    out.append(buf, (size_t)std::min<int>(len, (int)sizeof buf - 1));
-                }
-            }
-        });
-        for (unsigned c = 0; c < T; ++c) if (!parts[c].empty()) fwrite(parts[c].data(), 1, parts[c].size(), f);
-    }
-    fclose(f);
-    return GM_OK;
+    size_t max_name = 0;
+    for (const auto& c : h.contigs) max_name = std::max(max_name, c.name.size());
+    std::vector<int> cur(host_threads(), 0);
+    return write_track_text(path, append, nbk, max_name + 160, [&](uint64_t k, char* w, unsigned c, bool first) -> char* {
+        int& i = cur[c];
+        const uint64_t count = k * bs;
+        if (first) i = (int)host_pos2rid(h, count);
+        while ((size_t)i + 1 < h.contigs.size() && count >= h.contigs[(size_t)i + 1].offset) ++i;
+        const char at = "acgt"[(h.pac[count >> 2] >> ((~count & 3) << 1)) & 3];
+        if (at != want || !(bins[k] > 0.0f)) return w;
+        const GmContig& cg = h.contigs[(size_t)i];
+        memcpy(w, cg.name.data(), cg.name.size()); w += cg.name.size();
+        *w++ = '\t'; w = put_long(w, (long)(count - cg.offset) + 1); *w++ = '\t';
+        w = put_fixed(w, bins[k], 6);                                         // "%f"
+        for (int q = 0; q < 5; ++q) { *w++ = '\t'; w = put_fixed(w, nuc[(uint64_t)q * nb + k], 5); }
+        *w++ = '\n';
+        return w;
+    });
 }

@@ -419,6 +419,7 @@ __global__ void __launch_bounds__(64, STEPS <= 4 ? 7 : 4) k_vote_bucket(GmDevInd
     // ---- sweeps: one per distinct key of a half's list (both halves in the same instructions) ----
     uint32_t mykey = jj < lc_h ? keys[jj] : 0u;       // lane jj holds list entry jj of its half; 0 = none / done
     uint32_t n_em_h = 0;                              // candidates of this half so far
+    GmCand first_c; first_c.rs = rs; first_c.b = 0; first_c.step = 0; first_c.flags = 4; first_c.pad = 0; first_c.score = 0.0f;
     const uint32_t shard = (2u * blockIdx.x + h) & (GM_NSHARD - 1);
     for (;;) {
         const unsigned long long rem = __builtin_amdgcn_ballot_w64(mykey != 0u);
@@ -458,6 +459,7 @@ __global__ void __launch_bounds__(64, STEPS <= 4 ? 7 : 4) k_vote_bucket(GmDevInd
             GmCand c;
             c.rs = rs; c.b = key; c.step = (uint16_t)step; c.flags = 4; c.pad = 0; c.score = 0.0f;           // key = (position + 1) - (read offset + 1): the window start
             if (p.dbg & 2048) { if (c.b == 0x7FFFFFF1u) b.counters[GMK_DBG1] = 1; }      // (GM_DBG 2048: timing experiment, no candidate stores)
+            else if (em && b.fixed_cands != nullptr && n_em_h == 0u) first_c = c;          // slot 0 is stored last, with the count (one store for the usual single candidate)
             else if (em && b.fixed_cands != nullptr && n_em_h < GM_FIXED_C) b.fixed_cands[(size_t)rs * GM_FIXED_C + n_em_h] = c;
             else if (em) {                            // more candidates than own slots (or no own slots): the shared list
                 const uint32_t at = atomicAdd(&b.shard_cnt[shard * GM_SHARD_STRIDE], 1u);
@@ -467,7 +469,11 @@ __global__ void __launch_bounds__(64, STEPS <= 4 ? 7 : 4) k_vote_bucket(GmDevInd
         }
         __syncthreads();
     }
-    if (jj == 0u && b.fixed_cands != nullptr && n_em_h != 0u && !(p.dbg & 2048)) b.fixed_cnt[rs] = (uint8_t)(n_em_h < GM_FIXED_C ? n_em_h : GM_FIXED_C);
+    if (jj == 0u && b.fixed_cands != nullptr && n_em_h != 0u && !(p.dbg & 2048)) {
+        first_c.pad = (uint8_t)(n_em_h < GM_FIXED_C ? n_em_h : GM_FIXED_C);
+        first_c.score = __uint_as_float(b.fixed_epoch);                            // k_cand_gather takes slots stamped with this launch only: no count array to zero, no second store
+        b.fixed_cands[(size_t)rs * GM_FIXED_C] = first_c;
+    }
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------------------------------------

@@ -102,6 +102,7 @@ struct GmDevBatch {
     // ONE atomic per 64 read x strands; null = not in use
     GmCand* fixed_cands;            // 2n x GM_FIXED_C
     uint8_t* fixed_cnt;             // 2n, zeroed before the vote kernel
+    uint32_t fixed_epoch;           // != 0: no fixed_cnt - slot 0 of a read x strand says how many of its slots are in use (pad) and for which launch (score bits = this value)
     uint32_t* hit_count;            // n
     uint64_t* hit_begin;            // n+1
     uint32_t* hit_cursor;           // n

@@ -2266,7 +2266,11 @@ __global__ void __launch_bounds__(256, NCH > 0 ? 3 : GM_NW_OCC) k_nw_lane(GmDevI
 __global__ void __launch_bounds__(256) k_cand_gather(GmDevBatch b) {
     const uint32_t rs = blockIdx.x * 256 + threadIdx.x;
     const int lane = gm_lane();
-    uint32_t c = rs < 2 * b.n ? b.fixed_cnt[rs] : 0u;
+    uint32_t c = 0;
+    if (rs < 2 * b.n) {
+        if (b.fixed_epoch) { const GmCand c0 = b.fixed_cands[(size_t)rs * GM_FIXED_C]; c = __float_as_uint(c0.score) == b.fixed_epoch ? c0.pad : 0u; }      // k_vote_bucket: count + launch stamp in slot 0
+        else c = b.fixed_cnt[rs];
+    }
     const uint32_t incl = gm_wave_scan_incl(c);
     const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
     if (total == 0u) return;                             // wave-uniform
@@ -2275,7 +2279,7 @@ __global__ void __launch_bounds__(256) k_cand_gather(GmDevBatch b) {
     if (lane == 0) base = atomicAdd(&b.shard_cnt[shard * GM_SHARD_STRIDE], total);
     base = __builtin_amdgcn_readfirstlane(base) + incl - c;
     for (uint32_t k = 0; k < c; ++k)
-        if (base + k < b.cand_region) b.cands[(size_t)shard * b.cand_region + base + k] = b.fixed_cands[(size_t)rs * GM_FIXED_C + k];
+        if (base + k < b.cand_region) { GmCand cc = b.fixed_cands[(size_t)rs * GM_FIXED_C + k]; cc.pad = 0; cc.score = 0.0f; b.cands[(size_t)shard * b.cand_region + base + k] = cc; }
 }
 
 // total and maximum of the candidate shards' fill counts, for the host's sizing decision: 8 bytes come back instead of the 128 KB the

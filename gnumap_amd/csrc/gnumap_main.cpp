@@ -568,6 +568,8 @@ int main(int argc, char** argv) {
         for (int g = 1; g < o.gpus; ++g)
             if (gm_index_open(o.genome.c_str(), g, flags, &gpu_ix[(size_t)g]) != GM_OK) { fprintf(stderr, "ERROR: GPU %d: %s\n", g, gm_last_error()); return 1; }
     }
+    for (int g = 0; g < o.gpus; ++g)                                   // k-mer tables / records for these parameters: part of staging the index
+        if (gm_index_prepare(gpu_ix[(size_t)g], &o.p) != GM_OK) { fprintf(stderr, "ERROR: GPU %d: %s\n", g, gm_last_error()); return 1; }
     std::vector<Worker> workers((size_t)o.gpus * (size_t)o.workers);
     for (int g = 0; g < o.gpus; ++g) {
         if (gm_coverage_reset(gpu_ix[(size_t)g], (uint32_t)o.p.bin_size) != GM_OK ||
@@ -756,12 +758,12 @@ int main(int argc, char** argv) {
     auto t_cov0 = std::chrono::steady_clock::now();
     // coverage: all-reduce over the GPUs, then PrintFinalSGR / PrintFinalBisulfite
     if (gm_coverage_allreduce(gpu_ix.data(), o.gpus) != GM_OK) { fprintf(stderr, "ERROR: %s\n", gm_last_error()); return 1; }
-    std::vector<float> cov(gm_coverage_bins(gpu_ix[0]));
+    PinVec<float> cov; cov.ensure(gm_coverage_bins(gpu_ix[0]));                         // page-locked: the 1.5 GB of a human track come down at link rate
     if (gm_coverage_download(gpu_ix[0], cov.data()) != GM_OK) { fprintf(stderr, "ERROR: %s\n", gm_last_error()); return 1; }
     if (o.p.mode == GM_MODE_NORMAL) {                                  // GenomeBwt::PrintFinal src/GenomeBwt.cpp:915-926
         if (gm_coverage_write_sgr(gpu_ix[0], cov.data(), (o.output + ".sgr").c_str(), 0) != GM_OK) { fprintf(stderr, "ERROR: %s\n", gm_last_error()); return 1; }
     } else {
-        std::vector<float> nuc(5 * cov.size());
+        std::vector<float> nuc(5 * (size_t)gm_coverage_bins(gpu_ix[0]));
         if (gm_coverage_download_nuc(gpu_ix[0], nuc.data()) != GM_OK ||
             gm_coverage_write_gmp(gpu_ix[0], &o.p, cov.data(), nuc.data(), (o.output + ".gmp").c_str(), 0) != GM_OK) {
             fprintf(stderr, "ERROR: %s\n", gm_last_error());

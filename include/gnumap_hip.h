@@ -127,6 +127,10 @@ typedef struct {
     uint64_t* match_begin;      /* n+1: CSR into matches[], matches of a read in std::map (key) order */
     gm_match* matches;  uint64_t matches_cap;
     gm_pos* positions;  uint64_t positions_cap;
+    uint64_t stamp;             /* set by gm_map_batch: names the result that is still resident in the batch's HBM.  gm_output_batch given the
+                                   same stamp uses the resident matches / positions as they are (no upload, no re-validation); a caller
+                                   that EDITS matches / positions / match_begin sets stamp = 0 (status, denominator and top_score are always
+                                   taken from the host arrays) */
 } gm_hits;
 
 /* one SAM record (TopReadOutput, inc/const_include.h:193-206) */
@@ -174,6 +178,9 @@ enum { GM_BUILD_AUTO = 0 /* device if there is one, else host; env GM_INDEX_BUIL
 int gm_index_build_on(const char* fasta_path, int where, int device_id);
 int gm_index_open(const char* fasta_path, int device_id, int flags, gm_index** out);
 void gm_index_close(gm_index*);
+/* stage what the mapping kernels derive from the index for these parameters (k-mer tables, k-mer -> positions records: tens of GB of HBM
+ * at human scale, built on the device in well under a second) now instead of inside the first gm_map_batch; optional */
+int gm_index_prepare(gm_index*, const gm_params*);
 int gm_index_get_info(const gm_index*, gm_index_info* out);
 const char* gm_index_contig_name(const gm_index*, uint32_t i);
 uint64_t gm_index_contig_offset(const gm_index*, uint32_t i);   /* i == n_seqs gives l_pac */

@@ -96,6 +96,11 @@ def test_damaged_hits_are_refused_before_any_kernel_runs(ix_full, packed):
 
     M = res["matches"]
     keep = M[5].copy()
+    # the stamp of gm_map_batch says "use what is resident in HBM": with it, edits of the host copy are not even looked at
+    M[5]["read"] = 10 ** 9
+    assert out_rc() == 0
+    M[5] = keep
+    res["_struct"].stamp = 0                                              # a caller that edits the records says so
     for field, value in (("read", 10 ** 9), ("read", int(M[5]["read"]) + 1), ("pos_end", 2 ** 31), ("first_strand", 7), ("first_pos", 2 ** 40)):
         M[5][field] = value
         assert out_rc() == -1 and "gm_hits" in L.gm_last_error().decode(), field
@@ -105,5 +110,7 @@ def test_damaged_hits_are_refused_before_any_kernel_runs(ix_full, packed):
     P[3]["pos"] = 2 ** 40
     assert out_rc() == -1
     P[3] = keep_p
-    assert out_rc() == 0                                                  # intact again: accepted
+    assert out_rc() == 0                                                  # intact again: accepted (uploaded again, validated)
+    recs2, _ = batch.output(p, res)
+    assert recs2.tobytes() == recs.tobytes() or [tuple(r[f] for f in recs.dtype.names) for r in recs2] == [tuple(r[f] for f in recs.dtype.names) for r in recs]
     batch.destroy()
