@@ -303,6 +303,7 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
     // k-mer interval table: the last T characters of every seed are one lookup (GM_KMER_TABLE=0 keeps the pure occ walk;
     // GM_KMER_TABLE=<T> picks another suffix length, at most 16)
     dp.kmer_tab = nullptr; dp.kmer_T = 0; dp.kmer_ctab = nullptr; dp.bucket = nullptr;
+    dp.bucket_ecap = (uint32_t)std::min<long long>(384, gm_opt_ll("GM_BUCKET_ECAP", 384)); dp.bucket_ovcap = (uint32_t)std::min<long long>(16, gm_opt_ll("GM_BUCKET_OVCAP", 16));
     {
         // up to 12 characters by default; more for longer seeds on references where the extra occ steps are HBM misses anyway
         // (>= 50 Mbp): 14 characters = 2 GB + 0.5 GB compact,

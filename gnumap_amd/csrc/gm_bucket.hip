@@ -13,8 +13,8 @@
 // One wavefront = one read: lanes 0-31 the + strand, lanes 32-63 the - strand (two independent vote problems side by side: every
 // vector instruction works for both), step st of a half fetches the records of seeds 4 st .. 4 st + 3 (8 lanes each; record layout
 // at k_build_bucket).  While every k-mer at i = 0, jump, 2 jump .. occurs (and stays within -h) that is the adaptive walk; otherwise
-// the half walks again (gm_bucket_rewalk: a regular round finds the first failing k-mer, a round over CONSECUTIVE positions the next
-// one that does not fail - two round trips per failing seed however far the walk has to slide).  Votes: see k_vote_bucket.  Read x
+// the half walks again (gm_bucket_rewalk: it asks about EVERY position of the read at once and walks over the answers - one more round
+// trip however many k-mers are capped or absent).  Votes: see k_vote_bucket.  Read x
 // strands that do not fit (too many hits, a record with an early position, a non-ACGT base) get their seed rows written and go to
 // the list / heavy kernels exactly as from k_vote_tiny.
 #include <hip/hip_runtime.h>
@@ -78,6 +78,7 @@ struct GmBucketLds {
     uint32_t s_code[2][GMB_MAXS];                                // seeds of a half that walked again
     uint16_t s_pos[2][GMB_MAXS];
     uint32_t ov_k[2][GMB_OV], ov_n[2][GMB_OV], ov_ot[2][GMB_OV]; // seeds with more than GMB_C hits: first SA rank, count, (read offset + 1) | tag << 16
+    uint32_t s_ok[2][64];                                        // gm_bucket_rewalk: which positions of the read can be seeds, one bit each
 };
 
 __device__ __forceinline__ uint32_t gmb_half_bits(unsigned long long m, uint32_t h) { return h ? (uint32_t)(m >> 32) : (uint32_t)m; }
@@ -95,12 +96,14 @@ __device__ __forceinline__ uint32_t gmb_code_at(const uint32_t* form, uint32_t w
 
 // The walk of the halves (strands) whose regular positions do not all succeed; all 64 lanes call it, `need` = this lane's half walks.
 // Seeds p_0 = first position >= 0 whose k-mer occurs (and stays within -h), p_{n+1} = first such position >= p_n + jump
-// (inc/align_seq2_raw.cpp:200-231).  Round A: lane j probes pos0 + j * jump - the seeds before the first failing k-mer are final;
-// round B: lane j probes pos0 + j, consecutive positions behind the failing k-mer (behind its dead suffix when it does not occur at
-// all: every k-mer in between contains it) - the first that does not fail is the next seed.  Codes and offsets of the seeds go to
-// s_code / s_pos; returns the half's seed count (0 for a half that did not walk).
+// (inc/align_seq2_raw.cpp:200-231).  Which positions a seed lands on depends on every k-mer before it, but WHETHER a position can be a
+// seed does not: so the half asks about every position of the read at once - lane j the k-mers at j, j + 32, j + 64 .., their
+// header loads all in flight, ONE round trip whatever the number of capped or absent k-mers (a read inside a repeat family has most
+// of its regular positions capped: round after round of dependent probes made such reads 6 x slower than the rest) - and the walk
+// itself is bit arithmetic on the answers.  Codes and offsets of the seeds go to s_code / s_pos; returns the half's seed count
+// (0 for a half that did not walk).  s_ok: one word per 32 positions and half.
 static __device__ __attribute__((noinline)) uint32_t gm_bucket_rewalk(const GmKArgs* a, const uint32_t r, const int lane, const bool need, uint32_t* s_code /* [2][GMB_MAXS] */,
-                                                                      uint16_t* s_pos /* [2][GMB_MAXS] */) {
+                                                                      uint16_t* s_pos /* [2][GMB_MAXS] */, uint32_t* s_ok /* [2][64] */) {
     const GmDevParams& p = a->p;
     const GmDevBatch& b = a->b;
     const uint32_t m = (uint32_t)p.mer, jump = (uint32_t)p.jump, w2 = b.pack_w2;
@@ -109,45 +112,45 @@ static __device__ __attribute__((noinline)) uint32_t gm_bucket_rewalk(const GmKA
     const uint32_t* const form = row + (h ? w2 + 2u : 1u);
     const uint32_t L = row[0] & 0xFFFFu, last = L - m;
     const uint32_t cmask = m >= 16u ? 0xFFFFFFFFu : ((1u << (2u * m)) - 1u);
+    const uint32_t zero_code = cmask + 1u;
     const uint4* const bucket = reinterpret_cast<const uint4*>(p.bucket);
-    uint32_t pos0 = 0, ns = 0, mode = 0;
-    bool walking = need;
-    uint32_t extra = 0;                               // failing k-mers looked at (work counter)
-    while (__builtin_amdgcn_ballot_w64(walking) != 0ull) {
-        const uint32_t i = mode == 0u ? pos0 + jj * jump : pos0 + jj;
-        const bool act = walking && i < last;
-        uint32_t code = 0, hd = 0x40000000u, big_cnt = 0;
-        if (act) {
-            code = gmb_code_at(form, w2, m, i, cmask);
-            const uint4 rec = bucket[(size_t)code * 8u];                         // lane 0's part: header, first SA rank, count
-            hd = rec.x; big_cnt = rec.z;
+    const uint32_t nchunk = (last + 31u) >> 5;         // <= 64: reads of at most 2048 bases
+    // 1. every position: does its k-mer occur, within -h?
+    for (uint32_t c0 = 0; c0 < nchunk; c0 += 4u) {
+        uint4 rec[4];
+        bool act[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t i = 32u * (c0 + u) + jj;
+            act[u] = need && c0 + u < nchunk && i < last;
+            rec[u] = bucket[(size_t)(act[u] ? gmb_code_at(form, w2, m, i, cmask) : zero_code) * 8u];      // lane 0's part of the record: header, first SA rank, count
         }
-        const bool empty = (hd & 0x40000000u) != 0u;
-        const uint32_t cnt = (hd & 0x80000000u) ? big_cnt : (hd & 0xFFFFu);
-        const bool capped = !empty && p.hcap > 0 && cnt > p.hcap;
-        const bool ok = act && !empty && !capped;
-        const uint32_t bh = gmb_half_bits(__builtin_amdgcn_ballot_w64(act && !ok), h), ah = gmb_half_bits(__builtin_amdgcn_ballot_w64(act), h),
-                       oh = gmb_half_bits(__builtin_amdgcn_ballot_w64(ok), h);
-        // round A: seeds before the first failing lane; what that lane found
-        const uint32_t f = bh ? (uint32_t)(__ffs((int)bh) - 1) : (uint32_t)__popc(ah);
-        const uint32_t adv_self = capped ? 1u : (m - (hd & 0xFFu)) + 1u;         // how far the walk moves on behind this k-mer
-        const uint32_t adv_f = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane & 32u) + (f & 31u)) << 2, (int)adv_self);
-        if (walking) {
-            if (mode == 0u) {
-                if (jj < f && ns + jj < GMB_MAXS) { s_code[h * GMB_MAXS + ns + jj] = code; s_pos[h * GMB_MAXS + ns + jj] = (uint16_t)i; }
-                ns += f;
-                if (!bh) walking = false;
-                else { pos0 += f * jump + adv_f; mode = 1u; extra += 1u; }
-            } else {
-                if (oh) { const uint32_t s = (uint32_t)(__ffs((int)oh) - 1); pos0 += s; extra += s; mode = 0u; }
-                else if (pos0 + 32u < last) { pos0 += 32u; extra += 32u; }
-                else { extra += (uint32_t)__popc(ah); walking = false; }
-            }
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t hd = rec[u].x;
+            const uint32_t cnt = (hd & 0x80000000u) ? rec[u].z : (hd & 0xFFFFu);
+            const bool ok = act[u] && !(hd & 0x40000000u) && !(p.hcap > 0 && cnt > p.hcap);
+            const uint32_t okh = gmb_half_bits(__builtin_amdgcn_ballot_w64(ok), h);
+            if (jj == 0u && c0 + u < nchunk) s_ok[h * 64u + c0 + u] = okh;
         }
     }
-    if (jj == 0u && extra) { atomicAdd(&b.counters[GMK_KMERS], (unsigned long long)extra); atomicAdd(&b.counters[GMK_TAB_LOOKUPS], (unsigned long long)extra); }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    return ns < GMB_MAXS ? ns : GMB_MAXS;
+    __syncthreads();
+    // 2. the walk over the answers (the same in every lane of a half); lane n keeps seed n
+    uint32_t cur = 0, ns = 0, failed = 0, mypos = 0;
+    while (need && cur < last && ns < GMB_MAXS) {
+        uint32_t w = cur >> 5, bits = s_ok[h * 64u + w] >> (cur & 31u), pos = 0xFFFFFFFFu;
+        if (bits) pos = cur + (uint32_t)(__ffs((int)bits) - 1);
+        else for (++w; w < nchunk; ++w) { bits = s_ok[h * 64u + w]; if (bits) { pos = 32u * w + (uint32_t)(__ffs((int)bits) - 1); break; } }
+        if (pos >= last) { failed += last - cur; break; }            // (also: none found)
+        failed += pos - cur;                           // the k-mers the reference tries one by one in between
+        if (jj == ns) mypos = pos;
+        ++ns; cur = pos + jump;
+    }
+    // 3. the seeds' codes
+    if (need && jj < ns) { s_pos[h * GMB_MAXS + jj] = (uint16_t)mypos; s_code[h * GMB_MAXS + jj] = gmb_code_at(form, w2, m, mypos, cmask); }
+    if (need && jj == 0u && failed) { atomicAdd(&b.counters[GMK_KMERS], (unsigned long long)failed); atomicAdd(&b.counters[GMK_TAB_LOOKUPS], (unsigned long long)failed); }
+    __syncthreads();
+    return need ? ns : 0u;
 }
 
 // inclusive prefix sum within each half (32 lanes) of the wave: gm_wave_scan_incl without its last step
@@ -273,7 +276,7 @@ __global__ void __launch_bounds__(64, STEPS <= 4 ? 7 : 4) k_vote_bucket(GmDevInd
             const unsigned long long fm = __builtin_amdgcn_ballot_w64(fail);
             if (attempt == 1 || fm == 0ull) break;
             walked = gmb_half_bits(fm, h) != 0u;
-            const uint32_t nw = gm_bucket_rewalk(gm_kargs(), r, lane, walked, &S.s_code[0][0], &S.s_pos[0][0]);
+            const uint32_t nw = gm_bucket_rewalk(gm_kargs(), r, lane, walked, &S.s_code[0][0], &S.s_pos[0][0], &S.s_ok[0][0]);
             if (walked) ns_h = nw;
         }
     }
@@ -334,7 +337,7 @@ __global__ void __launch_bounds__(64, STEPS <= 4 ? 7 : 4) k_vote_bucket(GmDevInd
             n_ov_h = (uint32_t)__popc(gmb_half_bits(om, h));
         }
     }
-    const bool big_h = ns_h != 0u && !heavy_h && (listed || early_h || Ev_h > GMB_ECAP || n_ov_h > GMB_OV);
+    const bool big_h = ns_h != 0u && !heavy_h && (listed || early_h || Ev_h > p.bucket_ecap || n_ov_h > p.bucket_ovcap);
     bool vote_h = ns_h != 0u && !heavy_h && !big_h;
     // halves that leave: their seed rows {first SA rank, last SA rank, read offset} for the kernel they go to
     auto write_rows = [&](const bool which) {

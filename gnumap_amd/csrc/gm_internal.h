@@ -44,6 +44,7 @@ struct GmDevParams {
     const uint4* kmer_ctab;         // compact form of kmer_tab, 16 B per 8 consecutive codes: {first SA rank, 8 x u8 hit counts (2 words), escape flag}; null = not built
     const float2* lut;              // [0..255] Phred+33, [256..511] Phred+64: (p, (1-p)/3) as fp32; p = NaN when negative
     const uint4* bucket;            // direct-addressed k-mer -> positions table (gm_bucket.hip): 128 bytes per mer-mer code, or null
+    uint32_t bucket_ecap, bucket_ovcap;   // k_vote_bucket votes itself on a strand with at most this many SA hits / seeds beyond 28 hits; more -> list kernel
 };
 
 struct GmSeed { uint32_t k, l, pos; };

@@ -2102,8 +2102,12 @@ __global__ void __launch_bounds__(256) k_nw(GmDevIndex ix, GmDevParams p, GmDevB
 // NCH > 0: the candidate's read row (bases and qualities, NCH 8-byte words each) is loaded into registers up front - every load of
 // a lane goes out back to back and each 128-byte line is fetched once - instead of streaming one word per 8 DP rows (which re-fetched
 // the lines ~9 times: 3.9 KB of HBM traffic per candidate for 208 bytes of read).  NCH = 0 keeps the streaming form (long reads).
-template <int NCH>
-__global__ void __launch_bounds__(256, NCH > 0 ? 3 : GM_NW_OCC) k_nw_lane(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
+// LDSR (NCH > 0): the candidate's read row waits in LDS instead of 4 NCH registers - [chunk][thread] 8-byte slots, so that a thread's
+// own slot of ANY chunk sits on the same two banks (conflict-free whatever chunk each lane is at) and the row pick of every eighth DP
+// row is two ds_read_b64 instead of a 13-way mask-and-or over 52 registers (229 vector instructions per pick, a sixth of the kernel)
+template <int NCH, bool LDSR>
+__global__ void __launch_bounds__(256, NCH > 0 ? (LDSR ? 2 : 3) : GM_NW_OCC) k_nw_lane(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
+    extern __shared__ __attribute__((aligned(16))) uint2 s_rows[];          // LDSR: [2][NCH][256] bases, then qualities
     __shared__ float2 s_lut[512];
     __shared__ uint32_t s_coff[GM_NW_NCOFF];
     __shared__ uint32_t s_pre[GM_NSHARD + 4];
@@ -2155,8 +2159,9 @@ __global__ void __launch_bounds__(256, NCH > 0 ? 3 : GM_NW_OCC) k_nw_lane(GmDevI
             // the read streams through 8-byte words; the NEXT word is requested one chunk ahead so its latency hides under 8 rows
             const int src0 = strand ? 0 : Li - 1, cstep = strand ? 1 : -1, nchunk = (Li + 7) >> 3;
             int chunk = src0 >> 3;
-            uint2 RB[NCH > 0 ? NCH : 1], RQ[NCH > 0 ? NCH : 1];
+            uint2 RB[(NCH > 0 && !LDSR) ? NCH : 1], RQ[(NCH > 0 && !LDSR) ? NCH : 1];
             auto pick = [&](int cch, uint2& bo, uint2& qo) {           // mask-and-or: keeps the rows in registers (a select chain became a scratch array)
+                if constexpr (LDSR) { bo = s_rows[(size_t)cch * 256 + threadIdx.x]; qo = s_rows[(size_t)(NCH + cch) * 256 + threadIdx.x]; return; }
                 uint32_t bx = 0, by = 0, qx = 0, qy = 0;
 #pragma unroll
                 for (int k = 0; k < (NCH > 0 ? NCH : 1); ++k) {
@@ -2166,7 +2171,18 @@ __global__ void __launch_bounds__(256, NCH > 0 ? 3 : GM_NW_OCC) k_nw_lane(GmDevI
                 bo = make_uint2(bx, by); qo = make_uint2(qx, qy);
             };
             uint2 bw, qw, bn, qn;
-            if constexpr (NCH > 0) {
+            if constexpr (NCH > 0 && LDSR) {
+                uint2 tb[NCH], tq[NCH];                                // all loads of the lane in flight, then its own LDS slots (read back by this thread only: no barrier)
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    tb[k] = make_uint2(0u, 0u); tq[k] = make_uint2(0u, 0u);
+                    if (k < nchunk) { tb[k] = *reinterpret_cast<const uint2*>(rb + (k << 3)); tq[k] = *reinterpret_cast<const uint2*>(rq + (k << 3)); }
+                }
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) { s_rows[(size_t)k * 256 + threadIdx.x] = tb[k]; s_rows[(size_t)(NCH + k) * 256 + threadIdx.x] = tq[k]; }
+                pick(chunk, bw, qw);
+                bn = bw; qn = qw;
+            } else if constexpr (NCH > 0) {
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
                     RB[k] = make_uint2(0u, 0u); RQ[k] = make_uint2(0u, 0u);
@@ -2844,10 +2860,20 @@ int gmk_nw(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint
         // rows in registers while the candidates are sparse (about one per read: every candidate touches its own lines); with several
         // candidates per read (dense seeds) neighbouring lanes share the lines and the streaming form with its 5 waves per SIMD wins
         // (measured at configs[1], 4.3 candidates per read: 2.8 against 3.2 ms).  GM_NW_ROWS=0: streaming form always
+        // GM_NW_ROWS=1 (default): the row waits in registers; 2: in LDS (measured: 6.7 against 4.7 ms - two workgroups per CU instead of
+        // three cost more than the 13-way register pick it removes)
         const int rows_in_regs = (int)gm_opt_ll("GM_NW_ROWS", 1);
-        if (rows_in_regs && n_cands < 2.5 * b.n && b.stride <= 104) hipLaunchKernelGGL(k_nw_lane<13>, dim3(nw_grid), dim3(256), 0, S_(stream), ix, p, b);
-        else if (rows_in_regs && n_cands < 2.5 * b.n && b.stride <= 152) hipLaunchKernelGGL(k_nw_lane<19>, dim3(nw_grid), dim3(256), 0, S_(stream), ix, p, b);
-        else hipLaunchKernelGGL(k_nw_lane<0>, dim3(nw_grid), dim3(256), 0, S_(stream), ix, p, b);
+        const bool sparse = rows_in_regs && n_cands < 2.5 * b.n;
+        static const bool big_lds = [] {                      // 53 / 78 KB of rows + 12 KB of tables: beyond the 64 KB a launch gets by default
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nw_lane<13, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 13 * 256 * 8) == hipSuccess &&
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nw_lane<19, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 19 * 256 * 8) == hipSuccess;
+        }();
+        if (!big_lds && rows_in_regs == 2) return (int)hipErrorInvalidValue;
+        if (sparse && rows_in_regs == 2 && b.stride <= 104) hipLaunchKernelGGL((k_nw_lane<13, true>), dim3(nw_grid), dim3(256), (size_t)2 * 13 * 256 * 8, S_(stream), ix, p, b);
+        else if (sparse && rows_in_regs == 2 && b.stride <= 152) hipLaunchKernelGGL((k_nw_lane<19, true>), dim3(nw_grid), dim3(256), (size_t)2 * 19 * 256 * 8, S_(stream), ix, p, b);
+        else if (sparse && b.stride <= 104) hipLaunchKernelGGL((k_nw_lane<13, false>), dim3(nw_grid), dim3(256), 0, S_(stream), ix, p, b);
+        else if (sparse && b.stride <= 152) hipLaunchKernelGGL((k_nw_lane<19, false>), dim3(nw_grid), dim3(256), 0, S_(stream), ix, p, b);
+        else hipLaunchKernelGGL((k_nw_lane<0, false>), dim3(nw_grid), dim3(256), 0, S_(stream), ix, p, b);
         return (int)hipGetLastError();
     }
     uint32_t Lp = lp_of(b.stride);

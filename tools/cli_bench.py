@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--len", type=int, default=100)
     ap.add_argument("--args", default="-a 0.9")
     ap.add_argument("--dir", default="/tmp/gm_cli")
+    ap.add_argument("--sweep", default="", help="further argument sets for the timed run, separated by ';' (each one more run on the same files)")
     a = ap.parse_args()
     os.makedirs(a.dir, exist_ok=True)
     fa = os.path.join(a.dir, "g%g.fa" % a.mbp); fq = os.path.join(a.dir, "r%d.fq" % a.reads)
@@ -53,15 +54,16 @@ def main():
     exe = os.path.join(ROOT, "gnumap_amd", "bin", "gnumap")
     out = os.path.join(a.dir, "out")
     env = dict(os.environ)
-    for run in ("index+map", "map"):
+    runs = [("index+map", a.args), ("map", a.args)] + [("map " + x.strip(), a.args + " " + x.strip()) for x in a.sweep.split(";") if x.strip()]
+    for run, args in runs:
         for ext in (".sam", ".sgr", ".gmp"):                     # a fresh output file each time (overwriting 8 GB of page cache is a different test)
             if os.path.exists(out + ext):
                 os.remove(out + ext)
         t0 = time.time()
-        r = subprocess.run([exe, "-g", fa, "-o", out, "-v", "1"] + a.args.split() + [fq], capture_output=True, text=True, env=env)
+        r = subprocess.run([exe, "-g", fa, "-o", out, "-v", "1"] + args.split() + [fq], capture_output=True, text=True, env=env)
         dt = time.time() - t0
         print(f"--- {run}: {dt:.2f} s wall, {n / dt / 1e6:.3f} M reads/s end to end (rc {r.returncode})")
-        print(r.stderr[-3000:])
+        print("\n".join(l for l in r.stderr[-3000:].splitlines() if not l.startswith("[gm_")))
     print("SAM bytes", os.path.getsize(out + ".sam"), "FASTQ bytes", os.path.getsize(fq))
 
 

@@ -6,7 +6,7 @@ import re
 import sys
 
 rows = []
-for f in sys.argv[1:][::-1]:
+for f in sys.argv[1:]:
     for l in open(f):
         if l.strip():
             rows.append(json.loads(l))
@@ -17,6 +17,6 @@ for j in rows:
     flags = re.search(r"(-a 0\.9.*?), locate", c["workload"]).group(1).replace("NormalScoredSeq NW", "NW")
     g = lambda n: k.get(n, {}).get("ms_per_step", 0.0)
     cpu = j.get("cpu_baseline") or {}
-    print(f"| {c['genome_mbp']:g} Mbp | {c['reads_per_gpu'] / 1e6:g} M x {c['read_len']} | `{flags}` | **{j['value'] / 1e6:.1f} M** | {j['ms_per_step']:.1f} | "
+    print(f"| {c['genome_mbp']:g} Mbp{' repeat-rich' if c.get('repeat_rich') else ''} | {c['reads_per_gpu'] / 1e6:g} M x {c['read_len']} | `{flags}` | **{j['value'] / 1e6:.1f} M** | {j['ms_per_step']:.1f} | "
           f"{g('k_vote') + g('k_vote_retry'):.1f} / {g('k_seed'):.1f} / {g('k_nw'):.1f} / {g('k_prep'):.1f} | {(j.get('abi_reads_per_s') or 0) / 1e6:.1f} M | "
           f"{cpu.get('value', 0) / 1e3:.2f} k ({cpu.get('kind', '-')}) | {j['roofline']['frac']:.3f} ({j['roofline']['kernel']}) |")
