@@ -123,6 +123,7 @@ struct gm_index {
 struct gm_batch {
     gm_index* ix = nullptr;
     uint32_t max_reads = 0, max_len = 0;
+    uint32_t len_max = 0;                 // longest read of the uploaded block
     uint32_t n = 0, stride = 0, max_seeds = 0, illumina_until = 0;
     DevBuf bases, quals, len, status, self_score, min_score, top_score, seeds, n_seeds, n_entries, entry_off, coords,
         rs_overflow, retry_list, retry_off, gtab_keys, gtab_vals, cands, fixed_cands, fixed_cnt, heavy_list, heavy_off, heavy_k0, heavy_k1, heavy_tmp, hit_count, hit_begin, hit_cursor, raw_hits, counters, small, shards, big_list,
@@ -302,7 +303,7 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
     dp.dbg = (int)gm_opt_ll("GM_DBG", 0);
     // k-mer interval table: the last T characters of every seed are one lookup (GM_KMER_TABLE=0 keeps the pure occ walk;
     // GM_KMER_TABLE=<T> picks another suffix length, at most 16)
-    dp.kmer_tab = nullptr; dp.kmer_T = 0; dp.kmer_ctab = nullptr; dp.bucket = nullptr;
+    dp.kmer_tab = nullptr; dp.kmer_T = 0; dp.kmer_ctab = nullptr; dp.bucket = nullptr; dp.bucket_T = 0; dp.bucket_ctx = 0;
     dp.bucket_ecap = (uint32_t)std::min<long long>(384, gm_opt_ll("GM_BUCKET_ECAP", 384)); dp.bucket_ovcap = (uint32_t)std::min<long long>(16, gm_opt_ll("GM_BUCKET_OVCAP", 16));
     {
         // up to 12 characters by default; more for longer seeds on references where the extra occ steps are HBM misses anyway
@@ -311,6 +312,16 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
         // ONE random 16-byte probe instead of a probe + two search steps
         int T = std::min(p->mer, ix->h.seq_len >= 50000000ull ? 16 : 12);
         if (const char* e = gm_opt("GM_KMER_TABLE")) { if (*e) T = std::min(std::min(atoi(e), p->mer), 16); }
+        // seeds longer than a direct-addressed table of whole seeds can be (-m 16 .. 20 at human scale): the bucket table of their last
+        // GM_BUCKET_T=<t> characters with context records (gm_bucket.hip) - the k-mer table is then the one of that length.  Opt-in:
+        // correct, but with 1 % sequencing errors 60 % of the strands of 100-bp reads hold a 20-mer that does not occur and walk again,
+        // which one read per wavefront does 3.5 x slower than k_seed's one read x strand per lane (84 against 24 ms per 10 M reads).
+        const long long bucket_opt = gm_opt_ll("GM_SEED_BUCKET", -1);
+        int ctx_T = 0;
+        if (want_bucket && bucket_opt != 0 && ix->full_sa && ix->h.seq_len < 0xFFFFE000ull && !gm_opt("GM_KMER_TABLE")) {
+            const int t = (int)gm_opt_ll("GM_BUCKET_T", 0);
+            if (t >= 4 && t <= 15 && t < p->mer && p->mer - t <= 5) { ctx_T = t; T = t; }
+        }
         if (T >= 4) {
             std::lock_guard<std::mutex> lk(ix->mu);
             // the 15- / 16-character tables are bought with free HBM: step down while table + previous level + compact form (+ 8 GB
@@ -359,24 +370,25 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
             // fraction of a time and ~20 times in the reference (a record holds 28 positions; more go through the suffix array),
             // and 128 bytes per code have to fit beside everything else: -m 14 = 34 GB of the 288.  GM_SEED_BUCKET=0 / 1: never /
             // whenever the table can be built.
-            const long long bucket_opt = gm_opt_ll("GM_SEED_BUCKET", -1);
             const double occ = (double)ix->h.seq_len / pow(4.0, (double)std::min(p->mer, 31));
-            if (want_bucket && bucket_opt != 0 && ix->full_sa && T == p->mer && T <= 15 && ix->h.seq_len < 0xFFFFE000ull && (bucket_opt > 0 || (occ >= 1.0 && occ <= 20.0))) {
-                auto it = ix->buckets.find(T);
+            const bool ctx = ctx_T != 0 && T == ctx_T;      // (T may have been stepped down for lack of memory: then no bucket table)
+            if (want_bucket && bucket_opt != 0 && ix->full_sa && T <= 15 && ix->h.seq_len < 0xFFFFE000ull &&
+                (ctx || (ctx_T == 0 && T == p->mer && (bucket_opt > 0 || (occ >= 1.0 && occ <= 20.0))))) {
+                auto it = ix->buckets.find(T + (ctx ? 100 : 0));
                 if (it == ix->buckets.end()) {
                     DevBuf bb;
                     const size_t need = (((size_t)1 << (2 * T)) + 1) * 128;            // + the all-zero record behind the last code
                     size_t fr = 0, tot = 0;
                     if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr >= need + ((size_t)24 << 30) && bb.ensure(need) == GM_OK) {
                         const auto t0 = std::chrono::steady_clock::now();
-                        KCHK(gmk_build_bucket(tb.as<uint2>(), ix->d_full.as<uint32_t>(), bb.as<uint4>(), T, st));
+                        KCHK(gmk_build_bucket(tb.as<uint2>(), ix->d_full.as<uint32_t>(), ix->dev.pac, bb.as<uint4>(), T, ctx ? 1 : 0, st));
                         HIPCHK(hipStreamSynchronize(st));
                         ix->hbm_bytes += bb.cap;
-                        GM_TRACE("bucket table: %d-mers, %.1f GB, built in %.0f ms", T, need / 1e9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+                        GM_TRACE("bucket table: %d-mers%s, %.1f GB, built in %.0f ms", T, ctx ? " + context" : "", need / 1e9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
                     }
-                    it = ix->buckets.emplace(T, bb).first;     // an empty entry = does not fit: not tried again
+                    it = ix->buckets.emplace(T + (ctx ? 100 : 0), bb).first;     // an empty entry = does not fit: not tried again
                 }
-                dp.bucket = it->second.as<uint4>();
+                dp.bucket = it->second.as<uint4>(); dp.bucket_T = T; dp.bucket_ctx = ctx ? 1 : 0;
             }
         }
     }
@@ -609,7 +621,7 @@ static void fill_dev_batch(gm_batch* b) {
     d.gtab_keys = b->gtab_keys.as<uint32_t>(); d.gtab_vals = b->gtab_vals.as<uint32_t>();
     d.cands = b->cands.as<GmCand>(); d.cand_cap = b->cand_cap; d.cand_region = b->cand_cap / GM_NSHARD;
     d.shard_cnt = b->shards.as<uint32_t>();
-    d.fixed_cands = b->use_fixed ? b->fixed_cands.as<GmCand>() : nullptr; d.fixed_cnt = b->fixed_cnt.as<uint8_t>(); d.fixed_epoch = b->use_fixed ? b->fixed_epoch : 0u;
+    d.fixed_cands = b->use_fixed ? b->fixed_cands.as<GmCand>() : nullptr; d.fixed_cnt = b->use_fixed ? b->fixed_cnt.as<uint8_t>() : nullptr; d.fixed_epoch = b->use_fixed ? b->fixed_epoch : 0u;
     d.hit_count = b->hit_count.as<uint32_t>(); d.hit_begin = b->hit_begin.as<uint64_t>(); d.hit_cursor = b->hit_cursor.as<uint32_t>();
     d.raw_hits = b->raw_hits.as<GmRawHit>(); d.raw_cap = b->raw_cap;
     d.counters = b->counters.as<unsigned long long>();
@@ -628,8 +640,11 @@ extern "C" int gm_batch_upload(gm_batch* b, const gm_params* p, const gm_reads* 
     size_t bytes = (size_t)r->n * r->stride;
     if (b->bases.ensure(bytes + 16) || b->quals.ensure(bytes + 16) || b->len.ensure((size_t)r->n * 2 + 16)) return GM_E_NOMEM;
     b->len_host.assign(r->len, r->len + r->n);
-    for (uint32_t i = 0; i < r->n; ++i)
+    b->len_max = 0;
+    for (uint32_t i = 0; i < r->n; ++i) {
         if (r->len[i] > r->stride) { gm_set_error("read longer than stride"); return GM_E_ARG; }
+        b->len_max = std::max<uint32_t>(b->len_max, r->len[i]);
+    }
     // --illumina with automatic fallback (SeqReader.cpp:1171-1180): reads before the first one that shows a
     // quality below '@' keep Phred+64, that read and all later ones use Phred+33
     b->illumina_until = 0;
@@ -822,9 +837,9 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
                    dp.kmer_ctab && dp.kmer_T == p->mer && p->mer <= 16 && p->jump >= 1 && !(dp.dbg & 128);
         // ... or in the bucket table (one read per wave, both strands; handles -h and k-mers that do not occur by walking again):
         // every seed is ONE random line
-        const uint32_t lastmax = b->stride > (uint32_t)p->mer ? b->stride - (uint32_t)p->mer : 0;
+        const uint32_t lastmax = b->len_max > (uint32_t)p->mer ? b->len_max - (uint32_t)p->mer : 0;      // (the longest read of the block, not the row stride)
         const uint32_t max_reg = (lastmax + (uint32_t)p->jump - 1) / (uint32_t)p->jump;
-        use_bucket = dp.bucket && use_full && dp.kmer_tab && dp.kmer_T == p->mer && p->min_seed_hits >= 2 && max_reg <= 32 && b->max_seeds <= 34 && !gm_opt("GM_VOTE_KERNEL") &&
+        use_bucket = dp.bucket && use_full && dp.kmer_tab && dp.kmer_T == dp.bucket_T && (dp.bucket_ctx ? p->mer > dp.bucket_T && p->mer - dp.bucket_T <= 5 : dp.bucket_T == p->mer) && p->min_seed_hits >= 2 && max_reg <= 32 && b->max_seeds <= 34 && !gm_opt("GM_VOTE_KERNEL") &&
                      !gm_opt("GM_VOTE") && gm_opt_ll("GM_PIPELINE", 0) == 0 && !(dp.dbg & 128) && fused_env != 0;
         if (use_bucket) { dp.fused = 1; bucket_reg = max_reg; } else dp.bucket = nullptr;
         b->use_pack = dp.fused != 0;
@@ -843,8 +858,8 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
     }
     {
         char buf[160];
-        snprintf(buf, sizeof buf, "seeds=%s vote=%s locate=%s", use_bucket ? "bucket-table (in the vote kernel)" : dp.fused ? "k-mer table (in the vote kernel)" : "k_seed",
-                 use_bucket ? (bucket_reg <= 16 ? "k_vote_bucket<4>" : bucket_reg <= 24 ? "k_vote_bucket<6>" : "k_vote_bucket<8>")
+        snprintf(buf, sizeof buf, "seeds=%s vote=%s locate=%s", use_bucket ? (dp.bucket_ctx ? "bucket-table with context records (in the vote kernel)" : "bucket-table (in the vote kernel)") : dp.fused ? "k-mer table (in the vote kernel)" : "k_seed",
+                 use_bucket ? (bucket_reg <= 8 ? "k_vote_bucket<2>" : bucket_reg <= 16 ? "k_vote_bucket<4>" : bucket_reg <= 24 ? "k_vote_bucket<6>" : "k_vote_bucket<8>")
                             : dense == 0 ? "sparse" : dense == 3 ? "k_vote_block" : dense == 2 ? "k_vote_slots<64>" : slots_hint == 0 ? "k_vote_tiny" : slots_hint < 0 ? "k_vote_tiny2" : "k_vote_slots",
                  use_full ? "full-SA" : "sampled-SA");
         b->path = buf;
@@ -935,7 +950,8 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         HIPCHK(hipMemsetAsync(b->rs_overflow.p, 0, 2 * (size_t)b->n, st));
         HIPCHK(hipMemsetAsync(b->counters.as<unsigned long long>() + GMK_HEAVY_SLOTS, 0, 8, st));
         HIPCHK(hipMemsetAsync(b->counters.as<unsigned long long>() + GMK_OVERFLOW_RS, 0, 8, st));
-        if (b->use_fixed && use_bucket) {           // own-slot candidates carry the launch's stamp: nothing to zero
+        if (b->use_fixed && use_bucket) {           // own-slot candidates carry the launch's stamp: nothing to zero but the flags "goes to the list kernel"
+            HIPCHK(hipMemsetAsync(b->fixed_cnt.p, 0, 2 * (size_t)b->n + 8, st));
             if (++b->epoch_ctr == 0) { HIPCHK(hipMemsetAsync(b->fixed_cands.p, 0, b->fixed_cands.cap, st)); b->epoch_ctr = 1; }
             b->fixed_epoch = b->epoch_ctr;
             fill_dev_batch(b);

@@ -45,6 +45,7 @@ struct GmDevParams {
     const float2* lut;              // [0..255] Phred+33, [256..511] Phred+64: (p, (1-p)/3) as fp32; p = NaN when negative
     const uint4* bucket;            // direct-addressed k-mer -> positions table (gm_bucket.hip): 128 bytes per mer-mer code, or null
     uint32_t bucket_ecap, bucket_ovcap;   // k_vote_bucket votes itself on a strand with at most this many SA hits / seeds beyond 28 hits; more -> list kernel
+    int bucket_T, bucket_ctx;       // the table's k-mer length; 1 = context records: seeds of bucket_T + 1 .. bucket_T + 5 characters (k_build_bucket_ctx)
 };
 
 struct GmSeed { uint32_t k, l, pos; };
@@ -171,7 +172,7 @@ int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, in
 int gmk_cand_gather(const GmDevBatch& b, void* stream);
 int gmk_shard_stats(const GmDevBatch& b, uint32_t* out /* {total, max} in device memory */, void* stream);
 // gm_bucket.hip: the bucket table and the one-wave-per-read vote kernel that looks its seeds up in it
-int gmk_build_bucket(const uint2* tab, const uint32_t* full_sa, uint4* bucket, int T, void* stream);
+int gmk_build_bucket(const uint2* tab, const uint32_t* full_sa, const uint8_t* pac, uint4* bucket, int T, int ctx, void* stream);
 int gmk_vote_bucket(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint32_t max_reg, void* stream);
 int gmk_vote_list(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, void* stream);     // k_vote_fast_list over b.big_list
 // gm_heavy.hip: read x strands with more than heavy_min SA hits (sorted-key vote path)

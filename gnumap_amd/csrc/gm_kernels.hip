@@ -2303,10 +2303,14 @@ __global__ void __launch_bounds__(256) k_cand_gather(GmDevBatch b) {
 __global__ void __launch_bounds__(256) k_shard_stats(GmDevBatch b, uint32_t* out /* {total, max} */) {
     __shared__ uint32_t s_sum[4], s_max[4];
     uint32_t sum = 0, mx = 0;
-    for (uint32_t q = threadIdx.x; q < GM_NSHARD; q += 256) { const uint32_t c = b.shard_cnt[(size_t)q * GM_SHARD_STRIDE]; sum += c; mx = c > mx ? c : mx; }
+    unsigned long long dropped = 0;                       // word 1 of a shard: k-mers tried and dropped by the walks of k_vote_bucket (taken out as they are summed)
+    for (uint32_t q = threadIdx.x; q < GM_NSHARD; q += 256) {
+        const uint32_t c = b.shard_cnt[(size_t)q * GM_SHARD_STRIDE]; sum += c; mx = c > mx ? c : mx;
+        const uint32_t d = b.shard_cnt[(size_t)q * GM_SHARD_STRIDE + 1]; if (d) { dropped += d; b.shard_cnt[(size_t)q * GM_SHARD_STRIDE + 1] = 0; }
+    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { sum += __shfl_xor(sum, off); const uint32_t o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
-    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = sum; s_max[threadIdx.x >> 6] = mx; }
+    for (int off = 32; off > 0; off >>= 1) { sum += __shfl_xor(sum, off); const uint32_t o = __shfl_xor(mx, off); mx = o > mx ? o : mx; dropped += __shfl_xor(dropped, off); }
+    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = sum; s_max[threadIdx.x >> 6] = mx; if (dropped) { atomicAdd(&b.counters[GMK_KMERS], dropped); atomicAdd(&b.counters[GMK_TAB_LOOKUPS], dropped); } }
     __syncthreads();
     if (threadIdx.x == 0) {
         out[0] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
@@ -2821,8 +2825,27 @@ int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, in
     return (int)hipGetLastError();
 }
 
+// read x strands flagged for the list kernel (k_vote_bucket: b.fixed_cnt[rs] = 1) -> b.big_list, one atomic per wavefront that has any
+__global__ void __launch_bounds__(256) k_big_collect(GmDevBatch b) {
+    const uint32_t n4 = (2u * b.n + 3u) >> 2;
+    for (uint32_t base = blockIdx.x * 256u; base < n4; base += gridDim.x * 256u) {      // (whole waves stay in the loop together)
+        const uint32_t q = base + threadIdx.x;
+        uint32_t w = q < n4 ? reinterpret_cast<const uint32_t*>(b.fixed_cnt)[q] : 0u;    // four flags; the buffer is padded beyond 2n
+        if (4u * q + 3u >= 2u * b.n) { const uint32_t keep = 2u * b.n > 4u * q ? 2u * b.n - 4u * q : 0u; w &= keep >= 4u ? 0xFFFFFFFFu : ((1u << (8u * keep)) - 1u); }
+        const uint32_t c = (w & 1u) + ((w >> 8) & 1u) + ((w >> 16) & 1u) + ((w >> 24) & 1u);
+        if (__builtin_amdgcn_ballot_w64(c != 0u) == 0ull) continue;
+        const uint32_t incl = gm_wave_scan_incl(c);
+        uint32_t at = 0;
+        if (gm_lane() == 63) at = atomicAdd(b.n_big, incl);
+        at = (uint32_t)__builtin_amdgcn_readlane((int)at, 63) + incl - c;
+        for (uint32_t t = 0; t < 4u; ++t) if ((w >> (8u * t)) & 1u) b.big_list[at++] = 4u * q + t;
+    }
+}
+
 int gmk_vote_list(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, void* stream) {
     if (b.n == 0) return 0;
+    if (p.bucket != nullptr && b.fixed_cnt != nullptr)
+        hipLaunchKernelGGL(k_big_collect, dim3((uint32_t)std::min<uint64_t>(cdiv((2ull * b.n + 3) / 4, 256), 2048)), dim3(256), 0, S_(stream), b);
     const uint32_t lgrid = (uint32_t)std::min<uint64_t>(cdiv(2ull * b.n, 4), 256 * 20);
     if (b.max_seeds > 32) hipLaunchKernelGGL(k_vote_fast_list<true>, dim3(lgrid), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
     else hipLaunchKernelGGL(k_vote_fast_list<false>, dim3(lgrid), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
