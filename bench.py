@@ -226,10 +226,11 @@ def cpu_baseline_port(fa, B, Q, L, kw, target_s, threads):
                        f"index preloaded, sampled-SA LF-walk locate as in the reference), {st.map_seconds:.1f} s")
 
 
-def abi_rate(g, ix, p, B, Q, Ln, n_reads, block, n_threads, torch, in_flight=3):
+def abi_rate(g, ix, p, B, Q, Ln, n_reads, block, n_threads, torch, in_flight=3, passes=3):
     """gm_map_batch + gm_output_batch on page-locked HOST buffers: `n_threads` caller threads, each keeping `in_flight` blocks queued
     through the enqueue / wait forms of the two calls (gm_map_batch_enqueue, gm_output_batch_enqueue, gm_batch_wait) on as many
-    gm_batch + HIP stream pairs; in_flight = 1: the synchronous calls"""
+    gm_batch + HIP stream pairs; in_flight = 1: the synchronous calls.  The blocks are gone through `passes` times (a 4 M-read leg is a
+    40-ms measurement, +-40 % from run to run; three passes are steady state)"""
     n_reads = min(n_reads, len(B)) // block * block
     if n_reads == 0:
         return None
@@ -248,7 +249,7 @@ def abi_rate(g, ix, p, B, Q, Ln, n_reads, block, n_threads, torch, in_flight=3):
 
     def work(k):
         try:
-            mine = blocks[k::n_threads]
+            mine = blocks[k::n_threads] * passes
             if in_flight == 1:
                 for s in mine:
                     m, nr = runners[k][0].run(Bp[s:s + block], Qp[s:s + block], Lp[s:s + block])
@@ -276,6 +277,7 @@ def abi_rate(g, ix, p, B, Q, Ln, n_reads, block, n_threads, torch, in_flight=3):
     dt = time.perf_counter() - t0
     if err:
         raise err[0]
+    n_reads *= passes
     return dict(reads_per_s=n_reads / dt, reads=n_reads, block=block, host_threads=n_threads, blocks_in_flight_per_thread=in_flight, seconds=dt,
                 matches=sum(t[0] for t in totals), sam_records=sum(t[1] for t in totals))
 

@@ -2138,7 +2138,7 @@ __global__ void __launch_bounds__(256, NCH > 0 ? (LDSR ? 2 : 3) : GM_NW_OCC) k_n
             const uint8_t* rq = b.quals + (size_t)r * b.stride;
             const int Li = (int)L;
             // band row of i+1: P[d] = nm[i+1][i+1+delta], delta = d-3.  Row L: gGAP * (L - j) for j <= L (bin_seq.cpp:805-808)
-            float P[7], C[7];
+            float P[7];
 #pragma unroll
             for (int d = 0; d < 7; ++d) P[d] = d <= 3 ? __fmul_rn(gap, (float)(3 - d)) : GM_NEG_INF;
             // window bases of the current row: W[d] = w[i+delta]; start with row L-1
@@ -2160,15 +2160,30 @@ __global__ void __launch_bounds__(256, NCH > 0 ? (LDSR ? 2 : 3) : GM_NW_OCC) k_n
             const int src0 = strand ? 0 : Li - 1, cstep = strand ? 1 : -1, nchunk = (Li + 7) >> 3;
             int chunk = src0 >> 3;
             uint2 RB[(NCH > 0 && !LDSR) ? NCH : 1], RQ[(NCH > 0 && !LDSR) ? NCH : 1];
-            auto pick = [&](int cch, uint2& bo, uint2& qo) {           // mask-and-or: keeps the rows in registers (a select chain became a scratch array)
+            auto pick = [&](int cch, uint2& bo, uint2& qo) {           // keeps the rows in registers (a chain of `cch == k ?` selects became a scratch array)
                 if constexpr (LDSR) { bo = s_rows[(size_t)cch * 256 + threadIdx.x]; qo = s_rows[(size_t)(NCH + cch) * 256 + threadIdx.x]; return; }
-                uint32_t bx = 0, by = 0, qx = 0, qy = 0;
+                // a binary tree of selects over the bits of the chunk number: 12 selects per word for 13 chunks, where OR-ing the
+                // chunks under 13 compare masks took 9 instructions per chunk (229 per pick, a sixth of the kernel)
+                constexpr int N = NCH > 0 ? NCH : 1;
+                uint32_t out[4];
 #pragma unroll
-                for (int k = 0; k < (NCH > 0 ? NCH : 1); ++k) {
-                    const uint32_t mk = cch == k ? 0xFFFFFFFFu : 0u;
-                    bx |= RB[k].x & mk; by |= RB[k].y & mk; qx |= RQ[k].x & mk; qy |= RQ[k].y & mk;
+                for (int c = 0; c < 4; ++c) {          // one word at a time: the tree's intermediate values of one word only are alive
+                    uint32_t t[N];
+#pragma unroll
+                    for (int k = 0; k < N; ++k) t[k] = c == 0 ? RB[k].x : c == 1 ? RB[k].y : c == 2 ? RQ[k].x : RQ[k].y;
+                    int n = N;
+#pragma unroll
+                    for (int lvl = 0; lvl < 5; ++lvl) {
+                        if (n <= 1) break;
+                        const bool hi = (((uint32_t)cch >> lvl) & 1u) != 0u;
+                        const int m = (n + 1) / 2;
+#pragma unroll
+                        for (int i = 0; i < m; ++i) t[i] = (2 * i + 1 < n) ? (hi ? t[2 * i + 1] : t[2 * i]) : t[2 * i];
+                        n = m;
+                    }
+                    out[c] = t[0];
                 }
-                bo = make_uint2(bx, by); qo = make_uint2(qx, qy);
+                bo = make_uint2(out[0], out[1]); qo = make_uint2(out[2], out[3]);
             };
             uint2 bw, qw, bn, qn;
             if constexpr (NCH > 0 && LDSR) {
@@ -2197,6 +2212,8 @@ __global__ void __launch_bounds__(256, NCH > 0 ? (LDSR ? 2 : 3) : GM_NW_OCC) k_n
             }
             // one DP row.  EDGE = the row touches column L, row L or column -1 (the first 4 and the last 3 rows); the rows in
             // between - nearly all of them - need none of those tests
+            // (Measured and dropped: rows taken seven at a time with the cells moving over fixed selector slots instead of the selectors
+            // sliding - 24 moves per row less, but seven copies of the row body: 4.50 -> 4.83 ms per 10.7 M candidates.)
             auto dp_row = [&](const int i, auto edge_tag) {
                 constexpr bool EDGE = decltype(edge_tag)::value;
                 // PWM row i in strand orientation (reverse_comp_cpy SequenceOperations.h:149-161)
@@ -2226,19 +2243,19 @@ __global__ void __launch_bounds__(256, NCH > 0 ? (LDSR ? 2 : 3) : GM_NW_OCC) k_n
                     const uint32_t lo = __builtin_amdgcn_perm(__float_as_uint(v4[1]), __float_as_uint(v4[0]), S1[d]);
                     const uint32_t hi = __builtin_amdgcn_perm(__float_as_uint(v4[3]), __float_as_uint(v4[2]), S1[d]);
                     const float val = __uint_as_float(__builtin_amdgcn_perm(hi, lo, S2[d]));
+                    // the row is updated in place, from the last column down: P[d] (diagonal) and P[d - 1] (above) still hold row i + 1,
+                    // P[d + 1] already row i
                     const float up = d > 0 ? P[d - 1] : ((EDGE && i + 1 == Li) ? gap4 : GM_NEG_INF);        // nm[i+1][j]
-                    const float left = d < 6 ? C[d + 1] : ((EDGE && j + 1 == Li) ? gap4 : GM_NEG_INF);       // nm[i][j+1]
+                    const float left = d < 6 ? P[d + 1] : ((EDGE && j + 1 == Li) ? gap4 : GM_NEG_INF);       // nm[i][j+1]
                     const float mm = __fadd_rn(P[d], val);
                     const float g1 = __fadd_rn(up, gap);
                     const float g2 = __fadd_rn(left, gap);
                     // bin_seq::max_flt (src/bin_seq.cpp:1013-1026) is a compare chain; on finite, never-negative-zero operands it
                     // returns the same bits as max(): one v_max3_f32
                     const float best = fmaxf(fmaxf(mm, g1), g2);
-                    if (EDGE) C[d] = (j >= 0 && j < Li) ? best : (j == Li ? lastcol : GM_NEG_INF);
-                    else C[d] = best;
+                    if (EDGE) P[d] = (j >= 0 && j < Li) ? best : (j == Li ? lastcol : GM_NEG_INF);
+                    else P[d] = best;
                 }
-#pragma unroll
-                for (int d = 0; d < 7; ++d) P[d] = C[d];
                 // slide the window bases to row i-1
 #pragma unroll
                 for (int d = 6; d >= 1; --d) { S1[d] = S1[d - 1]; S2[d] = S2[d - 1]; }
