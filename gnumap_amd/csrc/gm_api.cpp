@@ -116,6 +116,9 @@ struct gm_index {
     std::map<int, DevBuf> kmer_tabs;        // memoised backward search of the last T characters of a seed, per T
     std::map<int, DevBuf> kmer_ctabs;       // its compact form (16 B per 8 codes), per T
     std::map<int, DevBuf> buckets;          // k-mer -> positions records (128 B per code; gm_bucket.hip), per T; empty DevBuf = tried, no room
+    struct CapSet { DevBuf table; uint32_t bits = 0; };
+    std::map<int, DevBuf> kbits;            // one bit per W-mer code: it occurs (gm_capset.hip), per W; empty DevBuf = tried, no room
+    std::map<unsigned long long, CapSet> capsets;      // the k-mers beyond -h (gm_capset.hip), per (mer, T, -h); bits = 0: tried, not built
     std::mutex mu;
     uint64_t hbm_bytes = 0;
 };
@@ -392,6 +395,71 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
             }
         }
     }
+    // the k-mers that exceed -h, for seeds longer than the table (gm_capset.hip): k_seed drops them with one probe.  Opt-in (GM_CAPSET=1):
+    // exact, but measured at human scale (-m 20 -j 10 -h 150) the per-k-mer code + probe costs every walk more than the search steps saved on
+    // the capped ones (5 % of the k-mers tried on the repeat-rich reference): k_seed 19.6 -> 26.0 ms i.i.d., 35.1 -> 33.0 ms repeat-rich.
+    dp.capset = nullptr; dp.capset_bits = 0; dp.kbit = nullptr; dp.kbit_W = 0;
+    // which W-mers occur at all (gm_capset.hip; GM_KBIT=<W>, 8 .. 18, opt-in): a k-mer whose last W characters do not occur is dropped
+    // after one bit.  Exact, and it saves a quarter of the rank queries at -m 20 on 3.1 Gbp (most k-mers k_seed tries there are dead ones: the
+    // read's wrong strand) - but those are not where the lines go (64 of the 91 rank queries per read are the 8 seeds of the right strand),
+    // the skip behind a dead 18-suffix is shorter than behind the depth the search dies at (38 k-mers tried per read instead of 29), and
+    // k_seed got slower: 26.0 -> 43.6 ms.
+    if (dp.kmer_tab && ix->full_sa && gm_opt("GM_KBIT")) {
+        const int W = std::min(p->mer, (int)gm_opt_ll("GM_KBIT", 0));
+        if (W >= 8 && W <= 18 && W > dp.kmer_T && ix->h.seq_len == ix->h.l_pac) {
+            std::lock_guard<std::mutex> lk(ix->mu);
+            auto it = ix->kbits.find(W);
+            if (it == ix->kbits.end()) {
+                DevBuf bb;
+                const size_t need = ((size_t)1 << (2 * W)) / 8;
+                size_t fr = 0, tot = 0;
+                if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr >= need + ((size_t)16 << 30) && bb.ensure(need) == GM_OK) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    HIPCHK(hipMemsetAsync(bb.p, 0, need, st));
+                    KCHK(gmk_kbit_build(ix->dev.pac, ix->h.l_pac, W, bb.as<uint32_t>(), st));
+                    HIPCHK(hipStreamSynchronize(st));
+                    ix->hbm_bytes += bb.cap;
+                    GM_TRACE("bitmap of the %d-mers that occur: %.1f GB, built in %.0f ms", W, need / 1e9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+                }
+                it = ix->kbits.emplace(W, bb).first;
+            }
+            if (it->second.p) { dp.kbit = it->second.as<uint32_t>(); dp.kbit_W = W; }
+        }
+    }
+    if (p->max_kmer_hits > 0 && dp.kmer_tab && p->mer > dp.kmer_T && p->mer - dp.kmer_T <= 8 && p->mer <= 31 && gm_opt_is("GM_CAPSET", "1")) {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        const unsigned long long key = ((unsigned long long)p->mer << 48) | ((unsigned long long)dp.kmer_T << 40) | (unsigned long long)(uint32_t)p->max_kmer_hits;
+        auto it = ix->capsets.find(key);
+        if (it == ix->capsets.end()) {
+            gm_index::CapSet cs;
+            const auto t0 = std::chrono::steady_clock::now();
+            const unsigned long long cap = 1ull << 25;                  // 32 M k-mers (256 MB of codes while they are collected); more: no set
+            DevBuf list, cnt;
+            unsigned long long n = 0;
+            if (list.ensure(cap * 8) == GM_OK && cnt.ensure(8) == GM_OK) {
+                HIPCHK(hipMemsetAsync(cnt.p, 0, 8, st));
+                KCHK(gmk_capset_collect(ix->dev, dp.kmer_tab, dp.kmer_T, p->mer - dp.kmer_T, (uint32_t)p->max_kmer_hits, list.as<unsigned long long>(), cap, cnt.as<unsigned long long>(), st));
+                HIPCHK(hipMemcpyAsync(&n, cnt.p, 8, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                if (n <= cap) {
+                    uint32_t bits = 10;
+                    while ((1ull << bits) < 2 * n + 16) ++bits;
+                    if (cs.table.ensure((8ull << bits)) == GM_OK) {
+                        HIPCHK(hipMemsetAsync(cs.table.p, 0, 8ull << bits, st));
+                        KCHK(gmk_capset_insert(list.as<unsigned long long>(), n, cs.table.as<unsigned long long>(), bits, st));
+                        HIPCHK(hipStreamSynchronize(st));
+                        cs.bits = bits;
+                        ix->hbm_bytes += cs.table.cap;
+                    }
+                }
+            }
+            list.release(); cnt.release();
+            GM_TRACE("k-mers beyond -h %d (mer %d over the %d-character table): %llu%s, %.0f ms", p->max_kmer_hits, p->mer, dp.kmer_T, n, cs.bits ? "" : " - no set kept",
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+            it = ix->capsets.emplace(key, cs).first;
+        }
+        if (it->second.bits) { dp.capset = it->second.table.as<unsigned long long>(); dp.capset_bits = it->second.bits; }
+    }
     dp.hcap = p->max_kmer_hits; dp.gap = p->gap; dp.align_score = p->align_score; dp.cutoff = p->cutoff;
     dp.S256 = d_tab;
     dp.lut = reinterpret_cast<const float2*>(d_tab + 1024);
@@ -502,6 +570,8 @@ extern "C" void gm_index_close(gm_index* ix) {
         for (auto& kv : ix->kmer_tabs) kv.second.release();
         for (auto& kv : ix->kmer_ctabs) kv.second.release();
         for (auto& kv : ix->buckets) kv.second.release();
+        for (auto& kv : ix->capsets) kv.second.table.release();
+        for (auto& kv : ix->kbits) kv.second.release();
     }
     delete ix;
 }
