@@ -317,8 +317,9 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
         if (const char* e = gm_opt("GM_KMER_TABLE")) { if (*e) T = std::min(std::min(atoi(e), p->mer), 16); }
         // seeds longer than a direct-addressed table of whole seeds can be (-m 16 .. 20 at human scale): the bucket table of their last
         // GM_BUCKET_T=<t> characters with context records (gm_bucket.hip) - the k-mer table is then the one of that length.  Opt-in:
-        // correct, but with 1 % sequencing errors 60 % of the strands of 100-bp reads hold a 20-mer that does not occur and walk again,
-        // which one read per wavefront does 3.5 x slower than k_seed's one read x strand per lane (84 against 24 ms per 10 M reads).
+        // correct, but a 20-mer of the read's WRONG strand does not occur anywhere, so that strand fails at every regular position and all of
+        // its ~80 positions have to be asked about (a record cannot say after how many characters a k-mer dies, so nothing is skipped): one read
+        // per wavefront does that 3.5 x slower than k_seed's one read x strand per lane (84 against 23 ms per 10 M reads).
         const long long bucket_opt = gm_opt_ll("GM_SEED_BUCKET", -1);
         int ctx_T = 0;
         if (want_bucket && bucket_opt != 0 && ix->full_sa && ix->h.seq_len < 0xFFFFE000ull && !gm_opt("GM_KMER_TABLE")) {

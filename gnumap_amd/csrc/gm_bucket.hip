@@ -179,13 +179,13 @@ __device__ __forceinline__ bool gmb_extend(const GmDevIndex& ix, uint32_t& k, ui
 // Which set:
 //   whole-seed records   every position from there to the end of the read not asked yet (a strand fails here because it lies in a
 //                        repeat - capped k-mers, position after position: one round trip, however many)
-//   context records      long seeds fail because of a sequencing error (a 20-mer with an error does not occur; 60 % of the strands of
-//                        100-bp reads with 1 % errors have one): the slide (:213-226) ends right behind the error, at most 2 jump - 1
-//                        positions on, so those are asked (up to the first position known to be good).  Behind it the walk is regular
-//                        again: unless this is the last call (`final`), the positions p + jump, p + 2 jump .. are ASSUMED good and handed
-//                        to the kernel as seeds - it fetches their records anyway, and comes back with the answers only if one of them
-//                        fails (a second error).  The last call asks about the grid, and then about everything still open.
-//                        Lines per failing strand: ~19 + its seeds, round trips: 2, instead of 80 lines.
+//   context records      long seeds fail because of a sequencing error (a 20-mer with an error does not occur): the slide (:213-226)
+//                        ends right behind the error, at most 2 jump - 1 positions on, so those are asked (up to the first position
+//                        known to be good).  Behind it the walk is regular again: unless this is the last call (`final`), the
+//                        positions p + jump, p + 2 jump .. are ASSUMED good and handed to the kernel as seeds - it fetches their
+//                        records anyway, and comes back with the answers only if one of them fails (a second error).  A slide that
+//                        finds nothing in its window (the read's wrong strand: no 20-mer of it occurs), and the last call: everything
+//                        still open.
 // A position of a context-record table is asked about by 8 lanes (the record, one 16-byte load each; the matches of the seed's
 // context are counted with a ballot); a record that holds its k-mer's SA interval instead of positions goes to a list, and the
 // intervals of the list are extended by the context characters one lane each.
