@@ -527,7 +527,7 @@ def build_parser():
     ap.add_argument("--abi-reads", type=int, default=4_194_304, help="reads of the gm_map_batch + gm_output_batch leg (0 = skip)")
     ap.add_argument("--abi-block", type=int, default=262144)
     ap.add_argument("--abi-threads", type=int, default=2)
-    ap.add_argument("--abi-in-flight", type=int, default=3, help="blocks each caller thread keeps queued (enqueue / wait forms); 1 = the synchronous calls")
+    ap.add_argument("--abi-in-flight", type=int, default=6, help="blocks each caller thread keeps queued (enqueue / wait forms); 1 = the synchronous calls")
     ap.add_argument("--parity-sample", type=int, default=64, help="reads of the benchmark compared with the oracle outside the timed region (0 = skip)")
     ap.add_argument("--workdir", default=os.environ.get("GM_BENCH_DIR", "/tmp/gnumap_bench"))
     ap.add_argument("--opt", action="append", default=[], metavar="GM_X=V", help="library run-time switch for this flag set (gm_set_option), e.g. --opt GM_SEED_FUSED=0")
