@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import gnumap_amd as g
-from test_gpu_parity import _compare, _oracle_results
+from test_gpu_parity import _compare, _long_reads, _oracle_results
 
 pytestmark = pytest.mark.gpu
 
@@ -153,3 +153,28 @@ def test_switches_are_read_on_every_call(ix_full, syn_reads, packed):
     g.set_option("GM_SEED_BUCKET", None)
     assert "k_vote_bucket" in out[0][0] and "k_vote_bucket" not in out[1][0]
     assert out[0][1:] == out[1][1:]
+
+
+@pytest.mark.parametrize("L,T,kw", [(250, None, dict(mer=12, jump=8)),                        # 30 seeds per strand: <8>; 12-mers with an error do not occur: both strands walk
+                                    (330, None, dict(mer=12, jump=10, max_kmer_hits=3)),      # > 300 positions per strand: several rounds of 96 questions
+                                    (420, 14, dict(mer=14, jump=13)),
+                                    (250, None, dict(_T=8, mer=12, jump=8)),                  # context records over long reads
+                                    (330, None, dict(_T=7, mer=10, jump=10, max_kmer_hits=20))])
+def test_bucket_kernel_on_long_reads(L, T, kw, bucket_on, ix_full, oracle, oix, syn_fa):
+    """the walk of a strand asks about at most 96 positions per half and round: reads of 250 .. 420 bases need several"""
+    kw = dict(kw)
+    ctx_T = kw.pop("_T", None)
+    reads = _long_reads(syn_fa, L, 24, L + 7)
+    B, Q, Ln = g.pack_reads([r[1] for r in reads], [r[2] for r in reads])
+    p = g.Params(**kw)
+    g.set_option("GM_KMER_TABLE", str(T) if T else None)
+    g.set_option("GM_BUCKET_T", str(ctx_T) if ctx_T else None)
+    try:
+        batch = g.Batch(ix_full, len(reads), B.shape[1])
+        res = batch.map(p, B, Q, Ln)
+        path = batch.path()
+        batch.destroy()
+    finally:
+        g.set_option("GM_KMER_TABLE", None); g.set_option("GM_BUCKET_T", None)
+    assert "k_vote_bucket" in path and ("context records" in path) == (ctx_T is not None), path
+    _compare(res, _oracle_results(oracle, oix, oracle.params(**kw), reads), reads)
