@@ -1022,7 +1022,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         HIPCHK(hipMemsetAsync(b->counters.as<unsigned long long>() + GMK_HEAVY_SLOTS, 0, 8, st));
         HIPCHK(hipMemsetAsync(b->counters.as<unsigned long long>() + GMK_OVERFLOW_RS, 0, 8, st));
         if (b->use_fixed && use_bucket) {           // own-slot candidates carry the launch's stamp: nothing to zero but the flags "goes to the list kernel"
-            HIPCHK(hipMemsetAsync(b->fixed_cnt.p, 0, 2 * (size_t)b->n + 8, st));
+            HIPCHK(hipMemsetAsync(b->fixed_cnt.p, 0, 2 * (size_t)b->n + 32, st));
             if (++b->epoch_ctr == 0) { HIPCHK(hipMemsetAsync(b->fixed_cands.p, 0, b->fixed_cands.cap, st)); b->epoch_ctr = 1; }
             b->fixed_epoch = b->epoch_ctr;
             fill_dev_batch(b);

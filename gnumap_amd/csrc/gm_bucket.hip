@@ -761,7 +761,7 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
             c.rs = rs; c.b = key; c.step = (uint16_t)step; c.flags = 4; c.pad = 0; c.score = 0.0f;           // key = (position + 1) - (read offset + 1): the window start
             if (p.dbg & 2048) { if (c.b == 0x7FFFFFF1u) b.counters[GMK_DBG1] = 1; }      // (GM_DBG 2048: timing experiment, no candidate stores)
             else if (em && b.fixed_cands != nullptr && n_em_h == 0u) first_c = c;          // slot 0 is stored last, with the count (one store for the usual single candidate)
-            else if (em && b.fixed_cands != nullptr && n_em_h < GM_FIXED_C) b.fixed_cands[(size_t)rs * GM_FIXED_C + n_em_h] = c;
+            else if (em && b.fixed_cands != nullptr && n_em_h < GM_FIXED_C) b.fixed_cands[GM_FIXED_AT(b, rs, n_em_h)] = c;
             else if (em) {                            // more candidates than own slots (or no own slots): the shared list
                 const uint32_t at = atomicAdd(&b.shard_cnt[shard * GM_SHARD_STRIDE], 1u);
                 if (at < b.cand_region) b.cands[(size_t)shard * b.cand_region + at] = c;
@@ -773,7 +773,7 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
     if (jj == 0u && b.fixed_cands != nullptr && n_em_h != 0u && !(p.dbg & 2048)) {
         first_c.pad = (uint8_t)(n_em_h < GM_FIXED_C ? n_em_h : GM_FIXED_C);
         first_c.score = __uint_as_float(b.fixed_epoch);                            // k_cand_gather takes slots stamped with this launch only: no count array to zero, no second store
-        b.fixed_cands[(size_t)rs * GM_FIXED_C] = first_c;
+        b.fixed_cands[GM_FIXED_AT(b, rs, 0u)] = first_c;
     }
 }
 

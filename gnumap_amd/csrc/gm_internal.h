@@ -55,6 +55,8 @@ struct GmDevParams {
 struct GmSeed { uint32_t k, l, pos; };
 
 #define GM_FIXED_C 4
+// own candidate slots of read x strand rs
+#define GM_FIXED_AT(b, rs, idx) ((size_t)(rs) * GM_FIXED_C + (size_t)(idx))
 #define GM_GROUP_BIG 64          // accepted hits per read above which grouping takes the hash-set + sort path
 #define GM_NSHARD 1024
 #define GM_SHARD_STRIDE 32

@@ -1525,7 +1525,7 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
                     const uint32_t idx = nb[q] + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk[q] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk[q], 0u));
                     GmCand c;
                     c.rs = rs; c.b = ky[q]; c.step = (uint16_t)st[q]; c.flags = 4; c.pad = 0; c.score = 0.0f;
-                    b.fixed_cands[(size_t)rs * GM_FIXED_C + idx] = c;
+                    b.fixed_cands[GM_FIXED_AT(b, rs, idx)] = c;
                 }
             if (lane == 0) b.fixed_cnt[rs] = (uint8_t)total;
         } else if (total != 0u) {                    // wave-uniform
@@ -1710,7 +1710,7 @@ __device__ __forceinline__ void gm_vote_tiny_body(const GmDevIndex& ix, const Gm
                     const uint32_t idx = (q ? n0 : 0u) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
                     GmCand c;
                     c.rs = rs; c.b = ky[q]; c.step = (uint16_t)st[q]; c.flags = 4; c.pad = 0; c.score = 0.0f;
-                    b.fixed_cands[(size_t)rs * GM_FIXED_C + idx] = c;
+                    b.fixed_cands[GM_FIXED_AT(b, rs, idx)] = c;
                 }
             if (lane == 0) b.fixed_cnt[rs] = (uint8_t)(n0 + n1);
         } else if (n0 + n1 != 0u) {                  // wave-uniform
@@ -1933,7 +1933,7 @@ __global__ void __launch_bounds__(64, 6) k_vote_tiny2(GmDevIndex ix, GmDevParams
                     const uint32_t idx = nb[q] + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk[q] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk[q], 0u));
                     GmCand c;
                     c.rs = rs; c.b = ky[q]; c.step = (uint16_t)st[q]; c.flags = 4; c.pad = 0; c.score = 0.0f;
-                    b.fixed_cands[(size_t)rs * GM_FIXED_C + idx] = c;
+                    b.fixed_cands[GM_FIXED_AT(b, rs, idx)] = c;
                 }
             if (lane == 0) b.fixed_cnt[rs] = (uint8_t)total;
         } else if (total != 0u) {                    // wave-uniform
@@ -2381,7 +2381,7 @@ __global__ void __launch_bounds__(256) k_cand_gather(GmDevBatch b) {
     const int lane = gm_lane();
     uint32_t c = 0;
     if (rs < 2 * b.n) {
-        if (b.fixed_epoch) { const GmCand c0 = b.fixed_cands[(size_t)rs * GM_FIXED_C]; c = __float_as_uint(c0.score) == b.fixed_epoch ? c0.pad : 0u; }      // k_vote_bucket: count + launch stamp in slot 0
+        if (b.fixed_epoch) { const GmCand c0 = b.fixed_cands[GM_FIXED_AT(b, rs, 0u)]; c = __float_as_uint(c0.score) == b.fixed_epoch ? c0.pad : 0u; }      // k_vote_bucket: count + launch stamp in slot 0
         else c = b.fixed_cnt[rs];
     }
     const uint32_t incl = gm_wave_scan_incl(c);
@@ -2392,7 +2392,7 @@ __global__ void __launch_bounds__(256) k_cand_gather(GmDevBatch b) {
     if (lane == 0) base = atomicAdd(&b.shard_cnt[shard * GM_SHARD_STRIDE], total);
     base = __builtin_amdgcn_readfirstlane(base) + incl - c;
     for (uint32_t k = 0; k < c; ++k)
-        if (base + k < b.cand_region) { GmCand cc = b.fixed_cands[(size_t)rs * GM_FIXED_C + k]; cc.pad = 0; cc.score = 0.0f; b.cands[(size_t)shard * b.cand_region + base + k] = cc; }
+        if (base + k < b.cand_region) { GmCand cc = b.fixed_cands[GM_FIXED_AT(b, rs, k)]; cc.pad = 0; cc.score = 0.0f; b.cands[(size_t)shard * b.cand_region + base + k] = cc; }
 }
 
 // total and maximum of the candidate shards' fill counts, for the host's sizing decision: 8 bytes come back instead of the 128 KB the
@@ -2922,27 +2922,34 @@ int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, in
     return (int)hipGetLastError();
 }
 
-// read x strands flagged for the list kernel (k_vote_bucket: b.fixed_cnt[rs] = 1) -> b.big_list, one atomic per wavefront that has any
+// read x strands flagged for the list kernel (k_vote_bucket: b.fixed_cnt[rs] = 1) -> b.big_list: one thread per 16 flags (one 16-byte
+// load, no loop: the flags are few and the kernel is all latency), one atomic per wavefront that has any
 __global__ void __launch_bounds__(256) k_big_collect(GmDevBatch b) {
-    const uint32_t n4 = (2u * b.n + 3u) >> 2;
-    for (uint32_t base = blockIdx.x * 256u; base < n4; base += gridDim.x * 256u) {      // (whole waves stay in the loop together)
-        const uint32_t q = base + threadIdx.x;
-        uint32_t w = q < n4 ? reinterpret_cast<const uint32_t*>(b.fixed_cnt)[q] : 0u;    // four flags; the buffer is padded beyond 2n
-        if (4u * q + 3u >= 2u * b.n) { const uint32_t keep = 2u * b.n > 4u * q ? 2u * b.n - 4u * q : 0u; w &= keep >= 4u ? 0xFFFFFFFFu : ((1u << (8u * keep)) - 1u); }
-        const uint32_t c = (w & 1u) + ((w >> 8) & 1u) + ((w >> 16) & 1u) + ((w >> 24) & 1u);
-        if (__builtin_amdgcn_ballot_w64(c != 0u) == 0ull) continue;
-        const uint32_t incl = gm_wave_scan_incl(c);
-        uint32_t at = 0;
-        if (gm_lane() == 63) at = atomicAdd(b.n_big, incl);
-        at = (uint32_t)__builtin_amdgcn_readlane((int)at, 63) + incl - c;
-        for (uint32_t t = 0; t < 4u; ++t) if ((w >> (8u * t)) & 1u) b.big_list[at++] = 4u * q + t;
-    }
+    const uint32_t n2 = 2u * b.n, q = blockIdx.x * 256u + threadIdx.x;
+    uint4 w = make_uint4(0u, 0u, 0u, 0u);
+    if (16u * q < n2) w = reinterpret_cast<const uint4*>(b.fixed_cnt)[q];                // (the buffer is padded beyond 2n and zeroed with it)
+    const uint32_t any = (w.x | w.y | w.z | w.w) & 0x01010101u;
+    if (__builtin_amdgcn_ballot_w64(any != 0u) == 0ull) return;                           // wave-uniform: nearly every wave
+    const uint32_t ws[4] = { w.x & 0x01010101u, w.y & 0x01010101u, w.z & 0x01010101u, w.w & 0x01010101u };
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c += (uint32_t)__popc(ws[k]);
+    uint32_t left = 16u * q < n2 ? n2 - 16u * q : 0u;                                     // flags of this thread that are read x strands
+    if (left < 16u) {                                                                      // the last thread: count only those
+        c = 0;
+        for (uint32_t t = 0; t < left; ++t) c += (ws[t >> 2] >> (8u * (t & 3u))) & 1u;
+    } else left = 16u;
+    const uint32_t incl = gm_wave_scan_incl(c);
+    uint32_t at = 0;
+    if (gm_lane() == 63) at = atomicAdd(b.n_big, incl);
+    at = (uint32_t)__builtin_amdgcn_readlane((int)at, 63) + incl - c;
+    for (uint32_t t = 0; t < left; ++t) if ((ws[t >> 2] >> (8u * (t & 3u))) & 1u) b.big_list[at++] = 16u * q + t;
 }
 
 int gmk_vote_list(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, void* stream) {
     if (b.n == 0) return 0;
     if (p.bucket != nullptr && b.fixed_cnt != nullptr)
-        hipLaunchKernelGGL(k_big_collect, dim3((uint32_t)std::min<uint64_t>(cdiv((2ull * b.n + 3) / 4, 256), 2048)), dim3(256), 0, S_(stream), b);
+        hipLaunchKernelGGL(k_big_collect, dim3((uint32_t)cdiv((2ull * b.n + 15) / 16, 256)), dim3(256), 0, S_(stream), b);
     const uint32_t lgrid = (uint32_t)std::min<uint64_t>(cdiv(2ull * b.n, 4), 256 * 20);
     if (b.max_seeds > 32) hipLaunchKernelGGL(k_vote_fast_list<true>, dim3(lgrid), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
     else hipLaunchKernelGGL(k_vote_fast_list<false>, dim3(lgrid), dim3(256), 0, S_(stream), ix, p, b, use_full_sa);
