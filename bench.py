@@ -524,7 +524,7 @@ def build_parser():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline leg (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-kind", choices=["auto", "reference", "port"], default="auto")
-    ap.add_argument("--abi-reads", type=int, default=4_194_304, help="reads of the gm_map_batch + gm_output_batch leg (0 = skip)")
+    ap.add_argument("--abi-reads", type=int, default=8_388_608, help="reads of the gm_map_batch + gm_output_batch leg (0 = skip)")
     ap.add_argument("--abi-block", type=int, default=262144)
     ap.add_argument("--abi-threads", type=int, default=2)
     ap.add_argument("--abi-in-flight", type=int, default=6, help="blocks each caller thread keeps queued (enqueue / wait forms); 1 = the synchronous calls")
