@@ -435,7 +435,8 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
             gm_index::CapSet cs;
             const auto t0 = std::chrono::steady_clock::now();
             const unsigned long long cap = 1ull << 25;                  // 32 M k-mers (256 MB of codes while they are collected); more: no set
-            DevBuf list, cnt;
+            struct Scratch { DevBuf list, cnt; ~Scratch() { list.release(); cnt.release(); } } tmp;      // (freed on every way out)
+            DevBuf& list = tmp.list; DevBuf& cnt = tmp.cnt;
             unsigned long long n = 0;
             if (list.ensure(cap * 8) == GM_OK && cnt.ensure(8) == GM_OK) {
                 HIPCHK(hipMemsetAsync(cnt.p, 0, 8, st));
@@ -454,7 +455,6 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
                     }
                 }
             }
-            list.release(); cnt.release();
             GM_TRACE("k-mers beyond -h %d (mer %d over the %d-character table): %llu%s, %.0f ms", p->max_kmer_hits, p->mer, dp.kmer_T, n, cs.bits ? "" : " - no set kept",
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
             it = ix->capsets.emplace(key, cs).first;
