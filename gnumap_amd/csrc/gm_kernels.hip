@@ -2185,8 +2185,10 @@ __global__ void __launch_bounds__(256) k_nw(GmDevIndex ix, GmDevParams p, GmDevB
 // LDSR (NCH > 0): the candidate's read row waits in LDS instead of 4 NCH registers - [chunk][thread] 8-byte slots, so that a thread's
 // own slot of ANY chunk sits on the same two banks (conflict-free whatever chunk each lane is at) and the row pick of every eighth DP
 // row is two ds_read_b64 instead of a 13-way mask-and-or over 52 registers (229 vector instructions per pick, a sixth of the kernel)
+// Waves per SIMD (NCH = 13): the kernel is a chain of dependent adds and max3 (a row's cells depend on each other), so it needs waves to
+// fill the issue slots more than it needs registers - 4 waves with 12 spilled registers: 4.19 ms, 3 waves without spills: 4.52 ms.
 template <int NCH, bool LDSR>
-__global__ void __launch_bounds__(256, NCH > 0 ? (LDSR ? 2 : 3) : GM_NW_OCC) k_nw_lane(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
+__global__ void __launch_bounds__(256, NCH > 0 ? (LDSR ? 2 : NCH <= 13 ? 4 : 3) : GM_NW_OCC) k_nw_lane(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
     extern __shared__ __attribute__((aligned(16))) uint2 s_rows[];          // LDSR: [2][NCH][256] bases, then qualities
     __shared__ float2 s_lut[512];
     __shared__ uint32_t s_coff[GM_NW_NCOFF];
