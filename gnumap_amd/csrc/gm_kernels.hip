@@ -1243,32 +1243,7 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
     uint32_t wcount = 0;                             // wave-uniform fill of this wave's list segment
     uint32_t nnz = 0;                                // non-zero window starts of this wave (scalar)
     const int lorg = wave ? LCAP - 1 : 0, ldir = wave ? -1 : 1;       // the list is two stacks (see below)
-    // The forms of up to 40 slots (round 3): ONE bit per window start and a RETURNING atomic - a hit that finds its bit set is a second
-    // or later arrival and goes to the list at once (~3 % of the hits: the true locus' and chance pairs in the 65 536 bits; the
-    // counting filter sent every fifth hit through a compaction pass, a second filter and the table).  The first arrival of a window
-    // start is not in the list, so the votes are counted in a second pass over the hits - they are still in registers - against the
-    // table of the list's keys: per slot 11 + 8 instructions instead of 9 + 15 + the list stages.
-    const bool onebit = !BIG && filter;
-    if (onebit) {
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const uint32_t h = bpv[j];
-            const bool nz = h != 0u;
-            nnz += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(nz));
-            uint32_t* const word = nz ? s_r0 + ((h >> 5) & 2047u) : &s_cnt0[lane];       // (lanes without a hit OR 0 into a word of their own)
-            const uint32_t old = atomicOr(word, nz ? 1u << (h & 31u) : 0u);
-            const bool dup = nz & (((old >> (h & 31u)) & 1u) != 0u);
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(dup);
-            if (m != 0ull) {                         // wave-uniform, ~one step in two
-                if (dup) {
-                    uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, wcount));
-                    at = at < (uint32_t)LCAP ? at : (uint32_t)LCAP - 1u;
-                    s_lbp[(uint32_t)(lorg + ldir * (int)at)] = h;
-                }
-                wcount += (uint32_t)__popcll(m);
-            }
-        }
-    } else if (filter) {
+    if (filter) {
         // ---- pass 1: one non-returning ds_add per hit into the counting filter
 #pragma unroll
         for (int j = 0; j < U; ++j) {
@@ -1299,63 +1274,6 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
             if (lane == 0 && z != 0ull) atomicAdd(&s_cnt0[t], (uint32_t)__popcll(z));
         }
     }
-    constexpr int T2 = 256;
-    uint32_t* const keys = BIG ? s_tab : s_r0 + 1024; uint32_t* const vals = keys + T2; uint32_t* const mlo = keys + 2 * T2; uint32_t* const mhi = keys + 3 * T2;
-    const uint32_t thr = (uint32_t)(p.kmin < 1 ? 1 : p.kmin);
-    bool lfull;
-    if (onebit) {
-        if (lane == 0) s_lcnt[wave] = wcount;
-        __syncthreads();
-        tick(2);
-        // the filter is dead; its upper half becomes the empty table (key 0 = empty: b = 0 never gets here)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) s_r0v[256 + tid + NT * k] = make_uint4(0u, 0u, 0u, 0u);
-        __syncthreads();
-        tick(3);
-        lfull = s_lcnt[0] + s_lcnt[1] > (uint32_t)LCAP;
-        const uint32_t n_l = lfull ? 0u : s_lcnt[wave];
-        {   // the keys of the list
-            bool full = false;
-            uint32_t nfresh = 0;
-            for (uint32_t i0 = 0; i0 < n_l; i0 += 64) {
-                const uint32_t i = i0 + (uint32_t)lane;
-                const uint32_t bp = i < n_l ? s_lbp[wave ? LCAP - 1 - i : i] : 0u;
-                bool fresh = false;
-                if (bp != 0u) {
-                    uint32_t slot = (bp * 0x9E3779B1u) >> 24, old;
-                    int probes = 0;
-                    while ((old = atomicCAS(&keys[slot], 0u, bp)) != 0u && old != bp && ++probes < T2) slot = (slot + 1) & (T2 - 1);
-                    fresh = old == 0u;
-                    if (old != 0u && old != bp) full = true;
-                }
-                nfresh += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(fresh));
-            }
-            if (lane == 0 && nfresh) atomicAdd(&s_nkeys, nfresh);
-            if (full) s_full = 1;
-        }
-        __syncthreads();
-        tick(4);
-        if (!lfull && !s_full && s_nkeys <= (uint32_t)(T2 * 3 / 4)) {      // block-uniform (else: the retry kernel, below)
-            // ---- pass 2: every hit against the keys; a hit that is one votes with its seed's tag (wave-uniform per slot)
-            uint32_t kq[U], sq[U];
-#pragma unroll
-            for (int j = 0; j < U; ++j) { sq[j] = (bpv[j] * 0x9E3779B1u) >> 24; kq[j] = keys[sq[j]]; }
-#pragma unroll
-            for (int j = 0; j < U; ++j) {
-                const uint32_t h = bpv[j];
-                uint32_t slot = sq[j], key = kq[j];
-                const bool live = h != 0u;
-                if (__builtin_amdgcn_ballot_w64(live && key != 0u) == 0ull) continue;        // (wave-uniform) nobody's slot is in use
-                while (live && key != 0u && key != h) { slot = (slot + 1) & (T2 - 1); key = keys[slot]; }      // linear probing; the table is at most 3/4 full
-                if (live && key == h) {
-                    const uint32_t t = (meta[j] >> 16) & 63u;
-                    atomicAdd(&vals[slot], 1u);
-                    if (t < 32) atomicOr(&mlo[slot], 1u << t);
-                    else if (MASK64) atomicOr(&mhi[slot], 1u << (t - 32));
-                }
-            }
-        }
-    } else {
     if (filter) {
         __syncthreads();
         tick(2);
@@ -1412,10 +1330,13 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
     // second slot was hit again enter the exact table, which then stays nearly empty.
     // Both live in the zeroed filter memory: words [0,1024) = the second filter (16 384 slots of two bits), words [1024,2048) = 256 slots of
     // key | votes | low step mask | high step mask (key 0 = empty; b = 0 never gets here).
+    constexpr int T2 = 256;
     constexpr uint32_t F2W = BIG ? 2047u : 1023u;     // second filter: words of sixteen 2-bit slots
     constexpr int F2S = BIG ? 11 : 10;
-    lfull = s_lcnt[0] + s_lcnt[1] > (uint32_t)LCAP;       // block-uniform
+    uint32_t* const keys = BIG ? s_tab : s_r0 + 1024; uint32_t* const vals = keys + T2; uint32_t* const mlo = keys + 2 * T2; uint32_t* const mhi = keys + 3 * T2;
+    const bool lfull = s_lcnt[0] + s_lcnt[1] > (uint32_t)LCAP;       // block-uniform
     const uint32_t n_l = lfull ? 0u : s_lcnt[wave];
+    const uint32_t thr = (uint32_t)(p.kmin < 1 ? 1 : p.kmin);
     for (uint32_t i0 = 0; i0 < n_l; i0 += 256) {     // four wave steps at a time: their list reads are in flight together
         uint32_t bp4[4];
 #pragma unroll
@@ -1475,7 +1396,6 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
         }
         if (lane == 0 && nfresh) atomicAdd(&s_nkeys, nfresh);
         if (full) s_full = 1;
-    }
     }
     __syncthreads();
     tick(6);
