@@ -922,7 +922,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         b->use_fixed = fixed_ok && (use_bucket || ((dense == 1 || dense == 2) && !gm_opt("GM_VOTE_KERNEL")));      // k_vote_bucket, k_vote_tiny*, k_vote_slots (all forms)
         if (b->use_fixed) {
             const void* before = b->fixed_cands.p;
-            if (b->fixed_cands.ensure(2 * (size_t)b->n * GM_FIXED_C * sizeof(GmCand)) || b->fixed_cnt.ensure(2 * (size_t)b->n + 64)) return GM_E_NOMEM;
+            if (b->fixed_cands.ensure(((2 * (size_t)b->n + 63) / 64) * 64 * GM_FIXED_C * sizeof(GmCand)) || b->fixed_cnt.ensure(2 * (size_t)b->n + 64)) return GM_E_NOMEM;
             if (b->fixed_cands.p != before) { HIPCHK(hipMemsetAsync(b->fixed_cands.p, 0, b->fixed_cands.cap, st)); b->epoch_ctr = 0; }      // new memory: no stale launch stamps
         }
         b->fixed_epoch = 0;

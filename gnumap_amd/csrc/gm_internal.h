@@ -55,8 +55,9 @@ struct GmDevParams {
 struct GmSeed { uint32_t k, l, pos; };
 
 #define GM_FIXED_C 4
-// own candidate slots of read x strand rs
-#define GM_FIXED_AT(b, rs, idx) ((size_t)(rs) * GM_FIXED_C + (size_t)(idx))
+// own candidate slots of read x strand rs, in blocks of 64 read x strands: the 64 slots 0 side by side (what k_cand_gather reads of
+// EVERY read x strand: one 1 KB stretch per wavefront instead of 16 bytes out of every 64), slots 1 .. 3 behind them
+#define GM_FIXED_AT(b, rs, idx) (((size_t)(rs) >> 6) * (64 * GM_FIXED_C) + ((idx) == 0 ? ((size_t)(rs) & 63) : 64 + ((size_t)(rs) & 63) * (GM_FIXED_C - 1) + (size_t)(idx) - 1))
 #define GM_GROUP_BIG 64          // accepted hits per read above which grouping takes the hash-set + sort path
 #define GM_NSHARD 1024
 #define GM_SHARD_STRIDE 32
