@@ -78,7 +78,7 @@ SAM_DTYPE = np.dtype([("read", "<u4"), ("pos", "<u8"), ("contig", "<u4"), ("chr_
                       ("a_score", "<f4"), ("post_prob", "<f4"), ("sim_matches", "<i4"), ("cigar_off", "<u4")], align=True)
 
 # every symbol include/gnumap_hip.h declares
-EXPORTS = ["gm_last_error", "gm_version", "gm_set_option", "gm_index_build", "gm_index_build_on", "gm_index_open", "gm_index_close", "gm_index_prepare", "gm_index_get_info", "gm_index_contig_name",
+EXPORTS = ["gm_last_error", "gm_version", "gm_set_option", "gm_selftest_pass_parallel", "gm_index_build", "gm_index_build_on", "gm_index_open", "gm_index_close", "gm_index_prepare", "gm_index_get_info", "gm_index_contig_name",
            "gm_index_contig_offset", "gm_index_window", "gm_params_default", "gm_params_finalize", "gm_params_load_subst", "gm_batch_create", "gm_batch_destroy",
            "gm_batch_upload", "gm_map_batch_device", "gm_batch_counters", "gm_batch_path", "gm_batch_set_profiling", "gm_batch_kernel_times", "gm_kernel_name",
            "gm_batch_raw_hits", "gm_stream_create", "gm_stream_destroy", "gm_host_alloc", "gm_host_free", "gm_map_batch", "gm_output_batch",

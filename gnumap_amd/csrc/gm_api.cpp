@@ -10,6 +10,7 @@
 #include <cstring>
 #include <chrono>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <atomic>
 #include <condition_variable>
@@ -44,7 +45,7 @@ static double gm_trace_ms() { static const auto t0 = std::chrono::steady_clock::
 #define GM_TRACE(...) do { if (gm_trace_on()) { fprintf(stderr, "[gm_trace %9.1f ms] ", gm_trace_ms()); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 void gm_set_error(const std::string& s) { g_err = s; }
 extern "C" const char* gm_last_error(void) { return g_err.c_str(); }
-extern "C" const char* gm_version(void) { return "gnumap-mi355x 0.1 (gfx950)"; }
+extern "C" const char* gm_version(void) { return "gnumap-mi355x 0.2 (gfx950)"; }
 
 #define HIPCHK(expr)                                                                                          \
     do {                                                                                                      \
@@ -116,9 +117,6 @@ struct gm_index {
     std::map<int, DevBuf> kmer_tabs;        // memoised backward search of the last T characters of a seed, per T
     std::map<int, DevBuf> kmer_ctabs;       // its compact form (16 B per 8 codes), per T
     std::map<int, DevBuf> buckets;          // k-mer -> positions records (128 B per code; gm_bucket.hip), per T; empty DevBuf = tried, no room
-    struct CapSet { DevBuf table; uint32_t bits = 0; };
-    std::map<int, DevBuf> kbits;            // one bit per W-mer code: it occurs (gm_capset.hip), per W; empty DevBuf = tried, no room
-    std::map<unsigned long long, CapSet> capsets;      // the k-mers beyond -h (gm_capset.hip), per (mer, T, -h); bits = 0: tried, not built
     std::mutex mu;
     uint64_t hbm_bytes = 0;
 };
@@ -385,8 +383,13 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
                     size_t fr = 0, tot = 0;
                     if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr >= need + ((size_t)24 << 30) && bb.ensure(need) == GM_OK) {
                         const auto t0 = std::chrono::steady_clock::now();
-                        KCHK(gmk_build_bucket(tb.as<uint2>(), ix->d_full.as<uint32_t>(), ix->dev.pac, bb.as<uint4>(), T, ctx ? 1 : 0, st));
-                        HIPCHK(hipStreamSynchronize(st));
+                        // a failed build: the memory goes back and the empty entry is recorded, so that it is neither leaked nor tried again on every call
+                        if (gmk_build_bucket(tb.as<uint2>(), ix->d_full.as<uint32_t>(), ix->dev.pac, bb.as<uint4>(), T, ctx ? 1 : 0, st) != 0 || hipStreamSynchronize(st) != hipSuccess) {
+                            bb.release();
+                            ix->buckets.emplace(T + (ctx ? 100 : 0), DevBuf());
+                            gm_set_error("k-mer -> positions table construction failed");
+                            return GM_E_HIP;
+                        }
                         ix->hbm_bytes += bb.cap;
                         GM_TRACE("bucket table: %d-mers%s, %.1f GB, built in %.0f ms", T, ctx ? " + context" : "", need / 1e9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
                     }
@@ -395,71 +398,6 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
                 dp.bucket = it->second.as<uint4>(); dp.bucket_T = T; dp.bucket_ctx = ctx ? 1 : 0;
             }
         }
-    }
-    // the k-mers that exceed -h, for seeds longer than the table (gm_capset.hip): k_seed drops them with one probe.  Opt-in (GM_CAPSET=1):
-    // exact, but measured at human scale (-m 20 -j 10 -h 150) the per-k-mer code + probe costs every walk more than the search steps saved on
-    // the capped ones (5 % of the k-mers tried on the repeat-rich reference): k_seed 19.6 -> 26.0 ms i.i.d., 35.1 -> 33.0 ms repeat-rich.
-    dp.capset = nullptr; dp.capset_bits = 0; dp.kbit = nullptr; dp.kbit_W = 0;
-    // which W-mers occur at all (gm_capset.hip; GM_KBIT=<W>, 8 .. 18, opt-in): a k-mer whose last W characters do not occur is dropped
-    // after one bit.  Exact, and it saves a quarter of the rank queries at -m 20 on 3.1 Gbp (most k-mers k_seed tries there are dead ones: the
-    // read's wrong strand) - but those are not where the lines go (64 of the 91 rank queries per read are the 8 seeds of the right strand),
-    // the skip behind a dead 18-suffix is shorter than behind the depth the search dies at (38 k-mers tried per read instead of 29), and
-    // k_seed got slower: 26.0 -> 43.6 ms.
-    if (dp.kmer_tab && ix->full_sa && gm_opt("GM_KBIT")) {
-        const int W = std::min(p->mer, (int)gm_opt_ll("GM_KBIT", 0));
-        if (W >= 8 && W <= 18 && W > dp.kmer_T && ix->h.seq_len == ix->h.l_pac) {
-            std::lock_guard<std::mutex> lk(ix->mu);
-            auto it = ix->kbits.find(W);
-            if (it == ix->kbits.end()) {
-                DevBuf bb;
-                const size_t need = ((size_t)1 << (2 * W)) / 8;
-                size_t fr = 0, tot = 0;
-                if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr >= need + ((size_t)16 << 30) && bb.ensure(need) == GM_OK) {
-                    const auto t0 = std::chrono::steady_clock::now();
-                    HIPCHK(hipMemsetAsync(bb.p, 0, need, st));
-                    KCHK(gmk_kbit_build(ix->dev.pac, ix->h.l_pac, W, bb.as<uint32_t>(), st));
-                    HIPCHK(hipStreamSynchronize(st));
-                    ix->hbm_bytes += bb.cap;
-                    GM_TRACE("bitmap of the %d-mers that occur: %.1f GB, built in %.0f ms", W, need / 1e9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-                }
-                it = ix->kbits.emplace(W, bb).first;
-            }
-            if (it->second.p) { dp.kbit = it->second.as<uint32_t>(); dp.kbit_W = W; }
-        }
-    }
-    if (p->max_kmer_hits > 0 && dp.kmer_tab && p->mer > dp.kmer_T && p->mer - dp.kmer_T <= 8 && p->mer <= 31 && gm_opt_is("GM_CAPSET", "1")) {
-        std::lock_guard<std::mutex> lk(ix->mu);
-        const unsigned long long key = ((unsigned long long)p->mer << 48) | ((unsigned long long)dp.kmer_T << 40) | (unsigned long long)(uint32_t)p->max_kmer_hits;
-        auto it = ix->capsets.find(key);
-        if (it == ix->capsets.end()) {
-            gm_index::CapSet cs;
-            const auto t0 = std::chrono::steady_clock::now();
-            const unsigned long long cap = 1ull << 25;                  // 32 M k-mers (256 MB of codes while they are collected); more: no set
-            struct Scratch { DevBuf list, cnt; ~Scratch() { list.release(); cnt.release(); } } tmp;      // (freed on every way out)
-            DevBuf& list = tmp.list; DevBuf& cnt = tmp.cnt;
-            unsigned long long n = 0;
-            if (list.ensure(cap * 8) == GM_OK && cnt.ensure(8) == GM_OK) {
-                HIPCHK(hipMemsetAsync(cnt.p, 0, 8, st));
-                KCHK(gmk_capset_collect(ix->dev, dp.kmer_tab, dp.kmer_T, p->mer - dp.kmer_T, (uint32_t)p->max_kmer_hits, list.as<unsigned long long>(), cap, cnt.as<unsigned long long>(), st));
-                HIPCHK(hipMemcpyAsync(&n, cnt.p, 8, hipMemcpyDeviceToHost, st));
-                HIPCHK(hipStreamSynchronize(st));
-                if (n <= cap) {
-                    uint32_t bits = 10;
-                    while ((1ull << bits) < 2 * n + 16) ++bits;
-                    if (cs.table.ensure((8ull << bits)) == GM_OK) {
-                        HIPCHK(hipMemsetAsync(cs.table.p, 0, 8ull << bits, st));
-                        KCHK(gmk_capset_insert(list.as<unsigned long long>(), n, cs.table.as<unsigned long long>(), bits, st));
-                        HIPCHK(hipStreamSynchronize(st));
-                        cs.bits = bits;
-                        ix->hbm_bytes += cs.table.cap;
-                    }
-                }
-            }
-            GM_TRACE("k-mers beyond -h %d (mer %d over the %d-character table): %llu%s, %.0f ms", p->max_kmer_hits, p->mer, dp.kmer_T, n, cs.bits ? "" : " - no set kept",
-                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-            it = ix->capsets.emplace(key, cs).first;
-        }
-        if (it->second.bits) { dp.capset = it->second.table.as<unsigned long long>(); dp.capset_bits = it->second.bits; }
     }
     dp.hcap = p->max_kmer_hits; dp.gap = p->gap; dp.align_score = p->align_score; dp.cutoff = p->cutoff;
     dp.S256 = d_tab;
@@ -571,8 +509,6 @@ extern "C" void gm_index_close(gm_index* ix) {
         for (auto& kv : ix->kmer_tabs) kv.second.release();
         for (auto& kv : ix->kmer_ctabs) kv.second.release();
         for (auto& kv : ix->buckets) kv.second.release();
-        for (auto& kv : ix->capsets) kv.second.table.release();
-        for (auto& kv : ix->kbits) kv.second.release();
     }
     delete ix;
 }
@@ -921,9 +857,9 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         const bool fixed_ok = !gm_opt_is("GM_VOTE_FIXED", "0");
         b->use_fixed = fixed_ok && (use_bucket || ((dense == 1 || dense == 2) && !gm_opt("GM_VOTE_KERNEL")));      // k_vote_bucket, k_vote_tiny*, k_vote_slots (all forms)
         if (b->use_fixed) {
-            const void* before = b->fixed_cands.p;
+            const size_t cap_before = b->fixed_cands.cap;       // by CAPACITY: hipFree + a larger hipMalloc may hand back the same base address
             if (b->fixed_cands.ensure(((2 * (size_t)b->n + 63) / 64) * 64 * GM_FIXED_C * sizeof(GmCand)) || b->fixed_cnt.ensure(2 * (size_t)b->n + 64)) return GM_E_NOMEM;
-            if (b->fixed_cands.p != before) { HIPCHK(hipMemsetAsync(b->fixed_cands.p, 0, b->fixed_cands.cap, st)); b->epoch_ctr = 0; }      // new memory: no stale launch stamps
+            if (b->fixed_cands.cap != cap_before) { HIPCHK(hipMemsetAsync(b->fixed_cands.p, 0, b->fixed_cands.cap, st)); b->epoch_ctr = 0; }      // new memory: no stale launch stamps
         }
         b->fixed_epoch = 0;
     }
@@ -1272,14 +1208,18 @@ template <class F> void pass_parallel(uint32_t n, uint32_t grain, F&& fn) {
     const unsigned parts = (unsigned)std::min<uint64_t>(pool.n + 1, std::max<uint32_t>(1, n / std::max<uint32_t>(1, grain)));
     if (parts <= 1) { fn(0u, n); return; }
     const uint64_t per = (n + parts - 1) / parts;
-    std::atomic<unsigned> left{ parts - 1 };
-    std::mutex done_mu; std::condition_variable done_cv;
+    // completion state lives on the heap and is shared with every job: the last helper touches the mutex / condition variable AFTER the
+    // count reaches zero, so they must outlive the caller's frame (the caller may already have seen zero and returned)
+    struct Done { std::mutex mu; std::condition_variable cv; unsigned left; };
+    auto done = std::make_shared<Done>();
+    done->left = parts - 1;
     {
         std::lock_guard<std::mutex> lk(pool.mu);
         for (unsigned c = 1; c < parts; ++c)
-            pool.q.emplace_back([&, c] {
+            pool.q.emplace_back([&fn, done, n, per, c] {
                 fn((uint32_t)std::min<uint64_t>(n, c * per), (uint32_t)std::min<uint64_t>(n, (c + 1) * per));
-                if (left.fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk2(done_mu); done_cv.notify_one(); }
+                std::lock_guard<std::mutex> lk2(done->mu);          // decrement UNDER the mutex: the waiter cannot leave before the notify
+                if (--done->left == 0) done->cv.notify_one();
             });
     }
     pool.cv.notify_all();
@@ -1290,10 +1230,32 @@ template <class F> void pass_parallel(uint32_t n, uint32_t grain, F&& fn) {
         { std::lock_guard<std::mutex> lk(pool.mu); if (pool.q.empty()) break; job = std::move(pool.q.front()); pool.q.pop_front(); }
         job();
     }
-    std::unique_lock<std::mutex> lk(done_mu);
-    done_cv.wait(lk, [&] { return left.load() == 0; });
+    std::unique_lock<std::mutex> lk(done->mu);
+    done->cv.wait(lk, [&] { return done->left == 0; });
 }
 }  // namespace
+
+// host-only self test of the slice pool (no device): `callers` threads each run `iters` passes over [0, n) at once and check that
+// every item was visited exactly once per pass.  Returns 0, or the number of passes that came out wrong.
+extern "C" int gm_selftest_pass_parallel(uint32_t n, uint32_t grain, uint32_t callers, uint32_t iters) {
+    std::atomic<int> bad{ 0 };
+    auto run = [&] {
+        std::vector<uint8_t> seen(n);
+        for (uint32_t it = 0; it < iters; ++it) {
+            std::fill(seen.begin(), seen.end(), (uint8_t)0);
+            std::atomic<uint64_t> sum{ 0 };
+            pass_parallel(n, grain, [&](uint32_t lo, uint32_t hi) { uint64_t s2 = 0; for (uint32_t i = lo; i < hi; ++i) { ++seen[i]; s2 += i; } sum += s2; });
+            bool ok = sum.load() == (uint64_t)n * (n ? n - 1 : 0) / 2;
+            for (uint32_t i = 0; i < n && ok; ++i) ok = seen[i] == 1;
+            if (!ok) ++bad;
+        }
+    };
+    std::vector<std::thread> th;
+    for (uint32_t c = 1; c < callers; ++c) th.emplace_back(run);
+    run();
+    for (auto& t : th) t.join();
+    return bad.load();
+}
 
 struct PhaseClock {                         // GM_TIMING=1: host-side phase times of the two batch calls on stderr
     bool on; const char* what; std::chrono::steady_clock::time_point t0; std::string line;
@@ -1348,6 +1310,7 @@ static_assert(sizeof(gm_sam_rec) == sizeof(GmDevSamRec) && offsetof(gm_sam_rec, 
 // ------------------------------------------------------------------------------------------------
 extern "C" int gm_map_batch(gm_index* ix, const gm_params* p, gm_batch* b, const gm_reads* reads, gm_hits* out, void* stream) {
     if (!ix || !p || !b || !reads || !out) return GM_E_ARG;
+    out->stamp = 0;                                            // every return path that does not leave a resident result leaves "none"
     PhaseClock pc("gm_map_batch");
     hipStream_t st = S_(stream);
     int rc;
@@ -1454,8 +1417,15 @@ extern "C" int gm_map_batch(gm_index* ix, const gm_params* p, gm_batch* b, const
     HIPCHK(hipStreamSynchronize(st));
     b->cache_hits = n_hits; b->cache_matches = n_m;          // h_exp / h_ord / h_mhit describe this result
     {
+        // a stamp a caller's uninitialised memory does not hit by accident: per-process random base (clock + address entropy through
+        // the 64-bit mixer) + counter, with the batch's address mixed in; never 0
+        static const uint64_t stamp_base = [] {
+            uint64_t x = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() ^ ((uint64_t)(uintptr_t)&gm_set_option << 17) ^ ((uint64_t)getpid() << 48);
+            x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33; return x | (1ull << 63);
+        }();
         static std::atomic<uint64_t> next_stamp{ 1 };
-        b->stamp = next_stamp.fetch_add(1);
+        b->stamp = (stamp_base + next_stamp.fetch_add(1) * 0x9e3779b97f4a7c15ull) ^ ((uint64_t)(uintptr_t)b >> 4);
+        if (b->stamp == 0) b->stamp = stamp_base;
         out->stamp = b->stamp;
     }
     pc.lap("records");
@@ -1877,11 +1847,12 @@ static inline char* put_long(char* w, long v) {
 // bins [0, nb) in slabs: host_threads() threads format one slice of a slab each (emit(k, w) appends the line of bin k, if it has
 // one), the pieces are written with pwrite() at their offsets by the same threads
 template <class Emit> static int write_track_text(const char* path, int append, uint64_t nb, size_t max_line, Emit&& emit) {
-    const int fd = ::open(path, O_WRONLY | O_CREAT | (append ? O_APPEND : O_TRUNC), 0644);
+    // no O_APPEND: on Linux pwrite() on an O_APPEND descriptor ignores its offset, and the slices below are written concurrently
+    const int fd = ::open(path, O_WRONLY | O_CREAT | (append ? 0 : O_TRUNC), 0644);
     if (fd < 0) { gm_set_error(std::string("cannot write ") + path); return GM_E_IO; }
     uint64_t file_off = append ? (uint64_t)lseek(fd, 0, SEEK_END) : 0;
     const unsigned T = host_threads();
-    const uint64_t per = 1u << 20;                               // bins per slice
+    const uint64_t per = (uint64_t)std::max<long long>(1, gm_opt_ll("GM_TRACK_SLICE", 1ll << 20));      // bins per slice (the option: tests with several slices on a small index)
     std::vector<std::vector<char>> buf(T);
     std::vector<size_t> used(T);
     std::atomic<int> bad{ 0 };

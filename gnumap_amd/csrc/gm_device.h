@@ -147,65 +147,7 @@ __device__ __forceinline__ void gm_seed_walk(const GmDevIndex& ix, const GmDevPa
                                              unsigned long long& ntab, unsigned long long& nseed, unsigned long long& nent) {
     uint32_t last = L - (uint32_t)p.mer;
     uint32_t i = 0;
-    // (gm_capset.hip) the k-mers that exceed -h are known: such a k-mer is dropped with one probe of their table instead of a table
-    // lookup and mer - T search steps.  cap_code = the 2 mer-bit code of the k-mer at i (first character highest) while cap_at == i.
-    unsigned long long cap_code = 0;
-    uint32_t cap_at = 0xFFFFFFFFu;
-    const unsigned long long cap_mask = p.mer >= 32 ? ~0ull : ((1ull << (2 * p.mer)) - 1ull);
     while (i < last) {
-        if (p.capset) {
-            bool have = cap_at == i;
-            if (!have) {
-                cap_code = 0; have = true;
-                for (int q = 0; q < p.mer; ++q) {
-                    const uint32_t pos = i + (uint32_t)q;
-                    uint32_t c = gm_nt4(strand ? rb[L - 1 - pos] : rb[pos]);
-                    if (c > 3) { have = false; break; }             // a non-ACGT base: the search below finds where
-                    if (strand) c = 3 - c;
-                    cap_code = (cap_code << 2) | c;
-                }
-            }
-            if (have) {
-                const uint32_t cmask = (1u << p.capset_bits) - 1u;
-                uint32_t s = (uint32_t)((cap_code * 0x9E3779B97F4A7C15ull) >> (64u - p.capset_bits));
-                bool member = false;
-                for (;;) {
-                    const unsigned long long key = p.capset[s];
-                    if (key == 0ull) break;
-                    if (key == cap_code + 1ull) { member = true; break; }
-                    s = (s + 1u) & cmask;
-                }
-                if (member) {                                      // too many hits: slide by one (:213-217)
-                    ++nk;
-                    cap_at = 0xFFFFFFFFu;
-                    const uint32_t pos = i + (uint32_t)p.mer;      // the character that enters
-                    if (pos < L) {
-                        uint32_t c = gm_nt4(strand ? rb[L - 1 - pos] : rb[pos]);
-                        if (c <= 3) { if (strand) c = 3 - c; cap_code = ((cap_code << 2) | c) & cap_mask; cap_at = i + 1u; }
-                    }
-                    i += 1;
-                    continue;
-                }
-            }
-        }
-        if (p.kbit) {
-            // do the last kbit_W characters occur at all?  One bit of a direct-addressed bitmap; if not, every k-mer that contains them
-            // fails: the same skip as below, where the search says after how many characters the k-mer died
-            unsigned long long wcode = 0;
-            bool have = true;
-            for (int q = 0; q < p.kbit_W; ++q) {
-                const uint32_t pos = i + (uint32_t)(p.mer - 1 - q);
-                uint32_t c = gm_nt4(strand ? rb[L - 1 - pos] : rb[pos]);
-                if (c > 3) { have = false; break; }
-                if (strand) c = 3 - c;
-                wcode |= (unsigned long long)c << (2 * q);
-            }
-            if (have && !((p.kbit[wcode >> 5] >> (wcode & 31ull)) & 1u)) {
-                ++nk; ++ntab;
-                i += (uint32_t)(p.mer - p.kbit_W) + 1u;
-                continue;
-            }
-        }
         // bwt_match_exact on the k-mer at [i, i+mer), right to left
         uint32_t k = 0, l = ix.seq_len;
         int t = p.mer - 1;

@@ -46,10 +46,6 @@ struct GmDevParams {
     const uint4* bucket;            // direct-addressed k-mer -> positions table (gm_bucket.hip): 128 bytes per mer-mer code, or null
     uint32_t bucket_ecap, bucket_ovcap;   // k_vote_bucket votes itself on a strand with at most this many SA hits / seeds beyond 28 hits; more -> list kernel
     int bucket_T, bucket_ctx;       // the table's k-mer length; 1 = context records: seeds of bucket_T + 1 .. bucket_T + 5 characters (k_build_bucket_ctx)
-    const unsigned long long* capset;     // the k-mers (2 mer-bit code + 1; 0 = empty slot) that exceed -h, or null (gm_capset.hip): open addressing, 2^capset_bits slots
-    uint32_t capset_bits;
-    int kbit_W;                           // characters of the codes of kbit, 0 = none
-    const uint32_t* kbit;                 // one bit per kbit_W-mer code: it occurs in the reference (gm_capset.hip), or null
 };
 
 struct GmSeed { uint32_t k, l, pos; };
@@ -170,9 +166,6 @@ int gmk_expand_full_sa(const GmDevIndex& ix, uint32_t* full_sa, void* stream);
 int gmk_build_occ_planes(const GmDevIndex& ix, uint4* planes, uint32_t nblk, void* stream);
 int gmk_build_kmer_table(const GmDevIndex& ix, uint2* tab, int T, void* stream);
 int gmk_build_kmer_compact(const uint2* tab, uint4* ctab, int T, void* stream);
-int gmk_capset_collect(const GmDevIndex& ix, const uint2* tab, int T, int D, uint32_t hcap, unsigned long long* out, unsigned long long cap, unsigned long long* n_out, void* stream);
-int gmk_kbit_build(const uint8_t* pac, unsigned long long text_len, int W, uint32_t* bits, void* stream);
-int gmk_capset_insert(const unsigned long long* list, unsigned long long n, unsigned long long* table, uint32_t bits, void* stream);
 int gmk_extend_kmer_table(const GmDevIndex& ix, const uint2* prev, uint2* next, int T, void* stream);
 int gmk_prep(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream);
 int gmk_seed(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream);

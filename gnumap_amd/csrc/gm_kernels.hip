@@ -2303,7 +2303,7 @@ __global__ void __launch_bounds__(256) k_cand_gather(GmDevBatch b) {
     const int lane = gm_lane();
     uint32_t c = 0;
     if (rs < 2 * b.n) {
-        if (b.fixed_epoch) { const GmCand c0 = b.fixed_cands[GM_FIXED_AT(b, rs, 0u)]; c = __float_as_uint(c0.score) == b.fixed_epoch ? c0.pad : 0u; }      // k_vote_bucket: count + launch stamp in slot 0
+        if (b.fixed_epoch) { const GmCand c0 = b.fixed_cands[GM_FIXED_AT(b, rs, 0u)]; c = __float_as_uint(c0.score) == b.fixed_epoch ? min((uint32_t)c0.pad, (uint32_t)GM_FIXED_C) : 0u; }      // k_vote_bucket: count + launch stamp in slot 0
         else c = b.fixed_cnt[rs];
     }
     const uint32_t incl = gm_wave_scan_incl(c);

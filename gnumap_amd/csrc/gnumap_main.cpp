@@ -489,7 +489,7 @@ static int process_block(Worker& w, const Options& o, Block& b) {
     gm_reads reads; reads.n = n; reads.stride = b.stride; reads.bases = b.bases.data(); reads.quals = b.qbuf.data(); reads.len = b.plen.data();
     w.status.ensure(n); w.self_score.ensure(n); w.top.ensure(n); w.den.ensure(n); w.mbegin.ensure((size_t)n + 1);
     w.matches.ensure(2 * (size_t)n + 64); w.positions.ensure(2 * (size_t)n + 64);
-    gm_hits hits;
+    gm_hits hits{};
     auto c1 = std::chrono::steady_clock::now();
     for (;;) {
         hits.n = n; hits.status = w.status.data(); hits.self_score = w.self_score.data(); hits.top_score = w.top.data();

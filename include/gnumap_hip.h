@@ -130,7 +130,8 @@ typedef struct {
     uint64_t stamp;             /* set by gm_map_batch: names the result that is still resident in the batch's HBM.  gm_output_batch given the
                                    same stamp uses the resident matches / positions as they are (no upload, no re-validation); a caller
                                    that EDITS matches / positions / match_begin sets stamp = 0 (status, denominator and top_score are always
-                                   taken from the host arrays) */
+                                   taken from the host arrays).  A gm_hits the caller builds by hand must be ZERO-INITIALISED (stamp = 0 =
+                                   "nothing resident"); gm_map_batch sets it to 0 first thing on every call (ABI 0.2) */
 } gm_hits;
 
 /* one SAM record (TopReadOutput, inc/const_include.h:193-206) */
@@ -169,6 +170,10 @@ const char* gm_version(void);
  * on each call that uses it - from this table first, then from the environment - so a long-lived host can change a choice
  * between two batches.  value = NULL removes the override (back to the environment); "" hides an environment variable. */
 int gm_set_option(const char* name, const char* value);
+
+/* host-only self test of the library's slice pool (the fp64 passes of the two batch calls are cut over it): `callers` threads run
+ * `iters` passes over [0, n) each, at once; returns the number of passes in which an item was not visited exactly once (0 = fine) */
+int gm_selftest_pass_parallel(uint32_t n, uint32_t grain, uint32_t callers, uint32_t iters);
 
 /* ---- index ---- */
 int gm_index_build(const char* fasta_path);                      /* writes <fa>.gnumap.{pac,ann,amb,bwt,sa}; = gm_index_build_on(fa, GM_BUILD_AUTO, 0) */

@@ -81,3 +81,15 @@ def test_product_does_not_touch_the_oracle():
                 if fn.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
                     txt = open(os.path.join(dirpath, fn), errors="ignore").read()
                     assert "gm_oracle" not in txt and "libgnumap_ref" not in txt and "oracle/" not in txt, os.path.join(dirpath, fn)
+
+
+def test_slice_pool_survives_concurrent_callers():
+    """pass_parallel (gm_api.cpp): the fp64 passes of gm_map_batch / gm_output_batch cut a block over a process-wide helper pool from
+    several calling threads at once; the completion state must outlive the caller's frame (a helper notifying a condition
+    variable on a dead stack).  Many short passes from 6 callers - items visited exactly once, nothing hangs."""
+    L = g.load_library()
+    L.gm_selftest_pass_parallel.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.gm_selftest_pass_parallel.restype = C.c_int
+    assert L.gm_selftest_pass_parallel(4096, 256, 6, 3000) == 0
+    assert L.gm_selftest_pass_parallel(100, 256, 2, 10) == 0          # below the grain: the caller alone
+    assert L.gm_selftest_pass_parallel(0, 256, 2, 10) == 0

@@ -48,6 +48,16 @@ def test_sgr_and_gmp_text_equal_printf(syn_fa, tmp_path):
         # appending writes behind what is there
         assert L.gm_coverage_write_sgr(h, bins.ctypes.data, out.encode(), 1) == 0
         assert open(out).read() == 2 * "".join(want)
+        # several slices written concurrently (slices of 4096 bins), new file and append: the text does not depend on the slicing
+        assert L.gm_set_option(b"GM_TRACK_SLICE", b"4096") == 0
+        try:
+            assert L.gm_coverage_write_sgr(h, bins.ctypes.data, out.encode(), 0) == 0
+            assert open(out).read() == "".join(want)
+            assert L.gm_coverage_write_sgr(h, bins.ctypes.data, out.encode(), 1) == 0
+            assert L.gm_coverage_write_sgr(h, bins.ctypes.data, out.encode(), 1) == 0
+            assert open(out).read() == 3 * "".join(want)
+        finally:
+            assert L.gm_set_option(b"GM_TRACK_SLICE", None) == 0
     # .gmp: bin size 1, only the positions whose reference base is 'c' (-b), "%f" for the total, "%.5f" for the five tracks
     p = g.Params(mode=1)
     assert L.gm_coverage_reset(h, 1) == 0
