@@ -201,9 +201,58 @@ def cpu_baseline_reference(fa, B, Q, L, a, target_s, threads, wd):
     except Exception as e:                                    # the reference could not run here: say so, fall back to the port
         log(f"[bench] reference program not usable as CPU baseline: {e}")
         return None
-    return dict(value=n / t_map, unit="reads/s", cores=threads, kind="reference",
+    return dict(value=n / t_map, unit="reads/s", cores=threads, kind="reference", **host_cpu_info(),
                 sample=f"first {n} of the benchmark reads through oracle/_ref/gnumap_ref (the unmodified reference program, -c {threads} pthreads, "
-                       f"flags {' '.join(flags)}), mapping time {t_map:.1f} s = its 'Time since start' minus that of a 1-read run ({t_load:.1f} s of index load)")
+                       f"flags {' '.join(flags)}), mapping time {t_map:.1f} s = its 'Time since start' minus that of a 1-read run ({t_load:.1f} s of index load)",
+                _n=n, _fq=fq, _sam=os.path.join(wd, "cpu_ref_out.sam"), _flags=[x for x in flags])
+
+
+def host_cpu_info():
+    """model string and core count of the box the CPU baseline ran on (BASELINE.md asks for both beside the rate)"""
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return dict(host_cpu=model, host_cores=os.cpu_count())
+
+
+def sam_records(path):
+    """the alignment lines of a SAM file, sorted (the reference with -c > 1 writes them in thread order)"""
+    with open(path, "rb") as f:
+        return sorted(l for l in f if not l.startswith(b"@"))
+
+
+def parity_reference(cpu, fa, wd):
+    """The reference-program run the CPU baseline just paid for IS a parity sample at the bench's own size: the same FASTQ (the first n
+    benchmark reads) goes through the product's driver binary (gnumap_amd/bin/gnumap -> C ABI -> HIP kernels, default dispatch: the
+    same kernel family the timed steps ran) with the same flags, and the two SAM record sets are compared BYTE FOR BYTE (sorted: the
+    reference ran with -c > 1).  src/Driver.cpp:2146-2217 is what wrote the reference's side."""
+    exe = os.path.join(ROOT, "gnumap_amd", "bin", "gnumap")
+    if not cpu or cpu.get("kind") != "reference" or not os.path.exists(exe) or not os.path.exists(cpu["_sam"]):
+        return None
+    out = os.path.join(wd, "parity_mine")
+    flags = [x for x in cpu["_flags"]]
+    t0 = time.perf_counter()
+    r = subprocess.run([exe, "-g", fa, "-o", out] + flags + [cpu["_fq"]], capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:
+        raise SystemExit(f"[bench] parity_reference: the driver binary failed (rc {r.returncode}): {r.stderr[-600:]}")
+    dt = time.perf_counter() - t0
+    ref = sam_records(cpu["_sam"]); mine = sam_records(out + ".sam")
+    bad = 0; first = None
+    if ref != mine:
+        sr, sm = set(ref), set(mine)
+        diff = sorted(sr ^ sm)
+        bad = len(diff)
+        first = diff[0][:300].decode("latin1") if diff else "duplicate records differ"
+        bad = bad or abs(len(ref) - len(mine)) or 1
+    names = {l.split(b"\t", 1)[0] for l in ref}
+    return dict(n=int(cpu["_n"]), records=len(ref), mapped_reads=len(names), mismatches=int(bad), first_difference=first, seconds=round(dt, 1),
+                checked="every SAM record (QNAME FLAG RNAME POS MAPQ CIGAR SEQ QUAL XA XP X0) of the reference program's output on these reads, "
+                        "byte for byte, against gnumap_amd/bin/gnumap with the same flags")
 
 
 def cpu_baseline_port(fa, B, Q, L, kw, target_s, threads):
@@ -221,7 +270,7 @@ def cpu_baseline_port(fa, B, Q, L, kw, target_s, threads):
             break
         rate = n / max(st.map_seconds, 1e-6)
         n = int(min(len(B), max(2 * n, rate * target_s)))
-    return dict(value=n / st.map_seconds, unit="reads/s", cores=threads, kind="port",
+    return dict(value=n / st.map_seconds, unit="reads/s", cores=threads, kind="port", **host_cpu_info(),
                 sample=f"first {n} of the benchmark reads, oracle/gm_oracle.c gmo_run with {threads} pthreads (mapping loop only, "
                        f"index preloaded, sampled-SA LF-walk locate as in the reference), {st.map_seconds:.1f} s")
 
@@ -466,6 +515,15 @@ def run_config(a, g, gd, torch, ix, fa, wd, B, Q, Ln, dev, rank, world, t_setup)
                 cpu = cpu_baseline_reference(fa, B, Q, a.read_len, a, a.cpu_seconds, threads, wd)
             if cpu is None and a.cpu_kind != "reference":
                 cpu = cpu_baseline_port(fa, B, Q, a.read_len, kw, a.cpu_seconds, threads)
+        # the reference program's SAM of that same run, against the product's driver binary on the same FASTQ and flags
+        parity_ref = None
+        if cpu is not None and a.parity_reference:
+            parity_ref = parity_reference(cpu, fa, wd)
+            log(f"[bench] parity vs the reference program: {parity_ref}")
+            if parity_ref and parity_ref["mismatches"]:
+                raise SystemExit(f"[bench] PARITY FAILURE against the reference program: {parity_ref}")
+        if cpu is not None:
+            cpu = {k: v for k, v in cpu.items() if not k.startswith("_")}
         # which BASELINE.json configuration the run has the shape of
         if a.genome_mbp >= 3000 and not a.no_nw:
             shape = "the metric's configuration (human-scale reference, 100-bp reads, NormalScoredSeq NW)" if a.read_len == 100 else "human-scale reference"
@@ -490,6 +548,7 @@ def run_config(a, g, gd, torch, ix, fa, wd, B, Q, Ln, dev, rank, world, t_setup)
             "kernel_path": kernel_path,
             "cpu_baseline": cpu,
             "parity_sample": parity,
+            "parity_reference": parity_ref,
             "abi_reads_per_s": round(abi["reads_per_s"], 1) if abi else None,
             "abi": abi,
             "kernels": {k: {"ms_per_step": round(v["ms_per_step"], 4), "launches_per_step": v["launches"] // a.steps, "alg_GBps": round(v["GBps"], 2)} for k, v in per_kernel.items()},
@@ -529,6 +588,7 @@ def build_parser():
     ap.add_argument("--abi-threads", type=int, default=2)
     ap.add_argument("--abi-in-flight", type=int, default=6, help="blocks each caller thread keeps queued (enqueue / wait forms); 1 = the synchronous calls")
     ap.add_argument("--parity-sample", type=int, default=64, help="reads of the benchmark compared with the oracle outside the timed region (0 = skip)")
+    ap.add_argument("--parity-reference", type=int, default=1, help="compare the reference program's SAM of the CPU-baseline run with the driver binary's, byte for byte (0 = skip)")
     ap.add_argument("--workdir", default=os.environ.get("GM_BENCH_DIR", "/tmp/gnumap_bench"))
     ap.add_argument("--opt", action="append", default=[], metavar="GM_X=V", help="library run-time switch for this flag set (gm_set_option), e.g. --opt GM_SEED_FUSED=0")
     ap.add_argument("--also", action="append", default=[], metavar="FLAGS",

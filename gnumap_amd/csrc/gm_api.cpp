@@ -870,6 +870,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
                             : dense == 0 ? "sparse" : dense == 3 ? "k_vote_block" : dense == 2 ? "k_vote_slots<64>" : slots_hint == 0 ? "k_vote_tiny" : slots_hint < 0 ? "k_vote_tiny2" : "k_vote_slots",
                  use_full ? "full-SA" : "sampled-SA");
         b->path = buf;
+        GM_TRACE("path: %s", buf);
     }
     fill_dev_batch(b);
     HIPCHK(hipMemsetAsync(b->counters.p, 0, GMK_N * 8, st));

@@ -65,3 +65,23 @@ def read_fastq(path):
 @pytest.fixture(scope="session")
 def syn_reads(syn_fq):
     return read_fastq(syn_fq)
+
+
+CELGEN = os.path.join(GOLDEN, "celgen")
+
+
+@pytest.fixture(scope="session")
+def celgen(tmp_path_factory):
+    """the real-sequence fixture (tests/golden/celgen/, BASELINE configs[0]): genome + reads unpacked into a session directory and indexed
+    there with the library's own builder (host SA-IS: no device needed; byte-compatible with bwa_index, tests/test_index_build.py).
+    Returns (fasta path, fastq path)."""
+    import gzip
+    import shutil
+    import gnumap_amd as g
+    d = tmp_path_factory.mktemp("celgen")
+    fa, fq = str(d / "celgen.fa"), str(d / "reads.fq")
+    for src, dst in ((os.path.join(CELGEN, "celgen.fa.gz"), fa), (os.path.join(CELGEN, "reads.fq.gz"), fq)):
+        with gzip.open(src, "rb") as f, open(dst, "wb") as o:
+            shutil.copyfileobj(f, o)
+    g.index_build(fa, g.GM_BUILD_HOST)
+    return fa, fq

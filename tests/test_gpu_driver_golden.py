@@ -66,6 +66,49 @@ def test_cli_equals_reference_program(mode, extra, tmp_path):
         compare_tracks(open(out + ".gmp").read(), ref_text(mode, "gmp"), 8)
 
 
+def _seed_flags(argv):
+    """(mer, jump, -k) a reference command line ends up with (src/Driver.cpp:1163-1171: --fast = -m 14 unless given, jump = mer)"""
+    mer, jump, k, fast = 10, None, 2, "--fast" in argv
+    for i, x in enumerate(argv):
+        if x == "-m": mer = int(argv[i + 1])
+        if x == "-j": jump = int(argv[i + 1])
+        if x == "-k": k = int(argv[i + 1])
+    if fast:
+        mer = mer if "-m" in argv else 14
+        jump = mer
+    return mer, jump if jump else mer // 2, k
+
+
+@pytest.mark.parametrize("mode", sorted(MANIFEST))
+def test_cli_through_the_bucket_kernel_equals_reference_program(mode, tmp_path):
+    """k_vote_bucket - the kernel the human-scale headline runs - against the reference PROGRAM's own output, directly: on the 400 kbp
+    fixture the default dispatch never picks the k-mer -> positions records (a 10-mer occurs 0.4 times), GM_SEED_BUCKET=1 builds and
+    uses them whenever the kernel's preconditions hold (-k >= 2, the table as long as the seed, <= 32 seeds per strand).  The trace line
+    of the library proves which kernel ran."""
+    m = MANIFEST[mode]
+    mer, jump, k = _seed_flags(m["argv"])
+    longest = 150 if m["fastq"] == "syn.fq" else 104
+    if k < 2 or mer > 15 or (longest - mer + jump - 1) // jump > 32:
+        pytest.skip("outside k_vote_bucket's preconditions (the default dispatch covers the mode)")
+    out = str(tmp_path / "mine")
+    argv = [os.path.join(GOLDEN, a) if a == "subst.txt" else a for a in m["argv"]]
+    env = dict(os.environ, GM_SEED_BUCKET="1", GM_TRACE="1")
+    if mer > 12:
+        env["GM_KMER_TABLE"] = str(mer)              # the table of whole seeds (small references stop at 12 characters by default)
+    r = subprocess.run([EXE, "-g", os.path.join(GOLDEN, "syn.fa"), "-o", out, "-a", "0.9"] + argv + [os.path.join(GOLDEN, m["fastq"])],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "vote=k_vote_bucket" in r.stderr, r.stderr[-1500:]
+    sam = "".join(l for l in open(out + ".sam") if not l.startswith("@PG"))
+    ref = ref_text(mode, "sam")
+    if sam != ref:
+        a, b = sam.splitlines(), ref.splitlines()
+        first = next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), min(len(a), len(b)))
+        pytest.fail(f"{mode}: {len(a)} vs {len(b)} lines, first difference at line {first}:\n  mine {a[first] if first < len(a) else None}\n  ref  {b[first] if first < len(b) else None}")
+    ext = "sgr" if "sgr" in m["tracks"] else "gmp"
+    compare_tracks(open(out + "." + ext).read(), ref_text(mode, ext), 3 if ext == "sgr" else 8)
+
+
 @pytest.mark.parametrize("mode", ["default", "bs_all", "k1_all", "no_nw"])
 def test_cli_with_the_group_traceback_form(mode, tmp_path):
     """reads up to 511 bases take the lane-per-sequence traceback kernel; GM_TRACEBACK=group forces the 8-lane form (the one long
