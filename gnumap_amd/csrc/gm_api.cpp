@@ -125,6 +125,7 @@ struct gm_batch {
     gm_index* ix = nullptr;
     uint32_t max_reads = 0, max_len = 0;
     uint32_t len_max = 0;                 // longest read of the uploaded block
+    uint32_t len_min = 0;                 // and the shortest
     uint32_t n = 0, stride = 0, max_seeds = 0, illumina_until = 0;
     DevBuf bases, quals, len, status, self_score, min_score, top_score, seeds, n_seeds, n_entries, entry_off, coords,
         rs_overflow, retry_list, retry_off, gtab_keys, gtab_vals, cands, fixed_cands, fixed_cnt, heavy_list, heavy_off, heavy_k0, heavy_k1, heavy_tmp, hit_count, hit_begin, hit_cursor, raw_hits, counters, small, shards, big_list,
@@ -267,8 +268,9 @@ static void build_lut(float* lut /* 512 x 2 */) {
     for (int which = 0; which < 2; ++which)
         for (int ch = 0; ch < 256; ++ch) {
             double p;
-            if (which == 0) { int Q = ch - 33; p = 1 - exp((-(double)Q / 10.0) * log(10.0)); }
-            else { int Q = ch - 64; p = 1.0 - 1.0 / (pow(10.0, ((double)Q / 10.0))); }
+            const int sc = ch >= 128 ? ch - 256 : ch;                // `int Q = (int)fastq[i]` (SeqReader.cpp:1155): the character is a signed char,
+            if (which == 0) { int Q = sc - 33; p = 1 - exp((-(double)Q / 10.0) * log(10.0)); }       // a byte above 127 a negative quality -> "Invalid Fastq Character"
+            else { int Q = sc - 64; p = 1.0 - 1.0 / (pow(10.0, ((double)Q / 10.0))); }
             if (p > 1.0) p = 1.0;
             double other = (1 - p) / 3;
             float* o = lut + ((size_t)which * 256 + ch) * 2;
@@ -647,10 +649,11 @@ extern "C" int gm_batch_upload(gm_batch* b, const gm_params* p, const gm_reads* 
     size_t bytes = (size_t)r->n * r->stride;
     if (b->bases.ensure(bytes + 16) || b->quals.ensure(bytes + 16) || b->len.ensure((size_t)r->n * 2 + 16)) return GM_E_NOMEM;
     b->len_host.assign(r->len, r->len + r->n);
-    b->len_max = 0;
+    b->len_max = 0; b->len_min = r->n ? 0xFFFFFFFFu : 0u;
     for (uint32_t i = 0; i < r->n; ++i) {
         if (r->len[i] > r->stride) { gm_set_error("read longer than stride"); return GM_E_ARG; }
         b->len_max = std::max<uint32_t>(b->len_max, r->len[i]);
+        b->len_min = std::min<uint32_t>(b->len_min, r->len[i]);
     }
     // --illumina with automatic fallback (SeqReader.cpp:1171-1180): reads before the first one that shows a
     // quality below '@' keep Phred+64, that read and all later ones use Phred+33
@@ -659,7 +662,7 @@ extern "C" int gm_batch_upload(gm_batch* b, const gm_params* p, const gm_reads* 
         uint32_t until = r->n;
         for (uint32_t i = 0; i < r->n && until == r->n; ++i) {
             const uint8_t* q = r->quals + (size_t)i * r->stride;
-            for (uint32_t t = 0; t < r->len[i]; ++t) if (q[t] < 64) { until = i; break; }
+            for (uint32_t t = 0; t < r->len[i]; ++t) if ((int8_t)q[t] < 64) { until = i; break; }      // `int Q = (int)fastq[i]` (SeqReader.cpp:1155): a signed char
         }
         b->illumina_until = until;
     }
@@ -735,7 +738,7 @@ static int map_pipelined(gm_index* ix, const gm_params* p, const GmDevParams& dp
         }
         if (mx > region) { overflow = true; return GM_OK; }
         ncand[i] = (uint32_t)total;
-        { KTimer t(b, GM_K_NW, ss); KCHK(gmk_nw(ix->dev, dp, view[i], ncand[i], ss)); }
+        { KTimer t(b, GM_K_NW, ss); KCHK(gmk_nw(ix->dev, dp, view[i], ncand[i], (b->len_min == b->len_max && !ctr[GMK_HIGH_QUAL]) ? b->len_max : 0u, ss)); }
         return GM_OK;
     };
     uint32_t next_finish = 0;
@@ -1052,7 +1055,10 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
     if (b->raw_cap < b->n_cands + 16ull) b->raw_cap = b->n_cands + 16ull;
     if (b->raw_hits.ensure(b->raw_cap * sizeof(GmRawHit))) return GM_E_NOMEM;
     fill_dev_batch(b);
-    { KTimer t(b, GM_K_NW, st); KCHK(gmk_nw(ix->dev, dp, b->dev, b->n_cands, st)); }
+    // one read length in the block and no quality character above 127 (k_prep counted them): the DP kernel with the rows in DP order
+    const uint32_t nw_rows_len = (b->len_min == b->len_max && ctr[GMK_HIGH_QUAL] == 0) ? b->len_max : 0u;
+    b->path += std::string(" nw=") + gmk_nw_form(dp, b->dev, b->n_cands, nw_rows_len);
+    { KTimer t(b, GM_K_NW, st); KCHK(gmk_nw(ix->dev, dp, b->dev, b->n_cands, nw_rows_len, st)); }
     { KTimer t(b, GM_K_COMPACT, st); KCHK(gmk_compact(b->dev, st)); }
     if (gm_trace_on()) { HIPCHK(hipStreamSynchronize(st)); GM_TRACE("NW + compaction done"); }
     b->mapped = true;
@@ -1725,7 +1731,9 @@ extern "C" int gm_dev_nw_score(gm_index* ix, const gm_params* p, const gm_reads*
         if (n && hipMemcpy(b->cands.p, c.data(), (size_t)n * sizeof(GmCand), hipMemcpyHostToDevice) != hipSuccess) { rc = GM_E_HIP; break; }
         if (hipMemset(b->shards.p, 0, (size_t)GM_NSHARD * GM_SHARD_STRIDE * 4) != hipSuccess) { rc = GM_E_HIP; break; }
         if (hipMemcpy(b->shards.p, &n, 4, hipMemcpyHostToDevice) != hipSuccess) { rc = GM_E_HIP; break; }
-        if (gmk_nw(ix->dev, dp, b->dev, n, nullptr)) { rc = GM_E_HIP; break; }
+        uint32_t rows_len = (b->len_min == b->len_max) ? b->len_max : 0u;          // (no k_prep here: the quality characters are looked at on the host)
+        for (size_t q = 0; q < (size_t)reads->n * reads->stride && rows_len; ++q) if (reads->quals[q] >= 128) rows_len = 0;
+        if (gmk_nw(ix->dev, dp, b->dev, n, rows_len, nullptr)) { rc = GM_E_HIP; break; }
         if (n && hipMemcpy(c.data(), b->cands.p, (size_t)n * sizeof(GmCand), hipMemcpyDeviceToHost) != hipSuccess) { rc = GM_E_HIP; break; }
     } while (0);
     gm_batch_destroy(b);

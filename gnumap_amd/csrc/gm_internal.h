@@ -74,6 +74,7 @@ struct GmRawHit { uint32_t read; uint32_t pos; float score; uint16_t step; uint8
 enum {
     GMK_KMERS = 0, GMK_OCC, GMK_SEEDS, GMK_SA_HITS, GMK_LF_STEPS, GMK_CANDS, GMK_NW_CELLS, GMK_ACCEPTED,
     GMK_OVERFLOW_RS, GMK_BAD_QUAL, GMK_HEAVY_SLOTS, GMK_OCC_BLOCKS, GMK_TAB_LOOKUPS,
+    GMK_HIGH_QUAL,                  // k_prep: reads with a quality character above 127 (k_nw_rows' value table stops there)
     GMK_DBG0, GMK_DBG1, GMK_DBG2, GMK_DBG3, GMK_DBG4, GMK_DBG5, GMK_DBG6, GMK_DBG7, GMK_DBG8,      // GM_DBG & 64: sampled phase clocks of the vote kernel
     GMK_N
 };
@@ -187,7 +188,10 @@ int gmk_heavy_chunk(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch
                     const unsigned long long* key_off, unsigned long long* keys0, unsigned long long* keys1, unsigned long long n_keys, void* tmp,
                     size_t tmp_bytes, unsigned item_bits, void* stream);
 int gmk_vote_retry(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, uint32_t j0, uint32_t n_retry, void* stream);
-int gmk_nw(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint32_t n_cands, void* stream);
+// rows_len != 0: every read of the block has this length and no quality character is above 127 -> k_nw_rows (gm_nw.hip) may take it
+int gmk_nw(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint32_t n_cands, uint32_t rows_len, void* stream);
+const char* gmk_nw_form(const GmDevParams& p, const GmDevBatch& b, uint32_t n_cands, uint32_t rows_len);      // which DP kernel gmk_nw launches for these arguments
+int gmk_nw_rows(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint32_t n_cands, uint32_t L, void* stream);
 // gm_band.hip: the DP kernels for a band half-width other than 3 (-M)
 int gmk_nw_band(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint32_t n_cands, int G, void* stream);
 int gmk_traceback_band(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, const GmCand* items, uint32_t n, unsigned long long* ops,

@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(256) k_prep(GmDevIndex ix, GmDevParams p, GmDe
     // (measured: 13 x the useful HBM traffic).  So the 256 reads of a tile are staged into LDS with coalesced 16-byte loads.
     // tile_reads = reads per tile that fit the LDS budget (256 at 100 bp); 0 = rows too long to stage, lanes read HBM directly
     extern __shared__ __attribute__((aligned(16))) unsigned char s_tile[];          // bases of a tile, then quals
-    unsigned long long bad = 0;
+    unsigned long long bad = 0, high = 0;
     const bool staged = tile_reads != 0;
     const uint32_t TR = staged ? tile_reads : 256u;
     const uint32_t n_tiles = (b.n + TR - 1u) / TR;
@@ -244,6 +244,7 @@ __global__ void __launch_bounds__(256) k_prep(GmDevIndex ix, GmDevParams p, GmDe
                         v = gm_get_val(gm_nt4(ch), pq.x, pq.y, s4);
                     }
                     if (v != v) bad = 1;                     // negative probability (SeqReader.cpp:1171-1189)
+                    if (qc >= 128u) high = 1;                // (k_nw_rows' table of row values covers the characters below 128)
                     score = __fadd_rn(score, v);
                 }
             }
@@ -284,6 +285,7 @@ __global__ void __launch_bounds__(256) k_prep(GmDevIndex ix, GmDevParams p, GmDe
     }
     }
     gm_count(b, GMK_BAD_QUAL, bad);
+    gm_count(b, GMK_HIGH_QUAL, high);
 }
 
 
@@ -2897,10 +2899,22 @@ int gmk_vote_retry(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch&
 
 static inline uint32_t lp_of(uint32_t stride) { return (stride + 7u) & ~7u; }
 
-int gmk_nw(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint32_t n_cands, void* stream) {
+// blocks of ONE read length (what a sequencer writes): the rows-in-DP-order kernel of gm_nw.hip.  GM_NW=lane keeps k_nw_lane
+static bool nw_rows_ok(const GmDevParams& p, const GmDevBatch& b, uint32_t rows_len) {
+    return p.max_gap == 3 && p.nw && !gm_opt_is("GM_NW", "wave") && !gm_opt_is("GM_NW", "lane") && rows_len >= 24 && rows_len <= 152 && rows_len <= b.stride;
+}
+const char* gmk_nw_form(const GmDevParams& p, const GmDevBatch& b, uint32_t n_cands, uint32_t rows_len) {
+    (void)n_cands;
+    if (p.max_gap != 3) return "k_nw_band";
+    if (nw_rows_ok(p, b, rows_len)) return "k_nw_rows";
+    return gm_opt_is("GM_NW", "wave") ? "k_nw" : "k_nw_lane";
+}
+
+int gmk_nw(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint32_t n_cands, uint32_t rows_len, void* stream) {
     if (b.n == 0) return 0;
     if (p.max_gap != 3) return gmk_nw_band(ix, p, b, n_cands, p.max_gap, stream);
     const bool wave_form = gm_opt_is("GM_NW", "wave");
+    if (nw_rows_ok(p, b, rows_len)) return gmk_nw_rows(ix, p, b, n_cands, rows_len, stream);
     if (!wave_form) {
         // ~4 candidates per lane: fewer, larger workgroups leave a long tail (measured at 17 M candidates: 2048 workgroups 6.1 ms,
         // 16384 5.6 ms), more, smaller ones pay their set-up (LDS tables, shard prefix) too often (2 M candidates: 0.77 against 1.02 ms)

@@ -538,7 +538,7 @@ static int process_block_split(Worker& w, const Options& o, Block& b, int depth)
         c.qual_len.assign(b.qual_len.begin() + lo, b.qual_len.begin() + hi); c.len.assign(b.len.begin() + lo, b.len.begin() + hi);
         if (part && b.illumina) {                           // the fallback may have happened inside the first half
             for (uint32_t i = 0; i < half && c.illumina; ++i)
-                for (uint32_t t = 0; t < b.len[i]; ++t) if ((unsigned char)b.qual[i][t] < 64) { c.illumina = 0; break; }
+                for (uint32_t t = 0; t < b.len[i]; ++t) if ((signed char)b.qual[i][t] < 64) { c.illumina = 0; break; }      // (the reference's quality characters are signed chars)
         }
         rc = process_block_split(w, o, c, depth + 1);
         if (rc != GM_OK) return rc;
@@ -645,7 +645,7 @@ int main(int argc, char** argv) {
                 b->illumina = ill_state;
                 if (ill_state)                              // gILLUMINA is cleared for the rest of the run by the first quality below '@'
                     for (uint32_t i = 0; i < b->n && ill_state; ++i)
-                        for (uint32_t t = 0; t < b->len[i]; ++t) if ((unsigned char)b->qual[i][t] < 64) { ill_state = 0; break; }
+                        for (uint32_t t = 0; t < b->len[i]; ++t) if ((signed char)b->qual[i][t] < 64) { ill_state = 0; break; }
                 map_q.push(b);
             }
             map_q.close();
