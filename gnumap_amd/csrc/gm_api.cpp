@@ -986,6 +986,10 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         if (dp.fused) { rc = fetch_heavy(hs_small[3]); if (rc) return rc; }
         if (dp.dbg & 64) {                           // sampled phase clocks of the vote kernel (cycles of one lane per sampled workgroup)
             const double ns = (double)std::max<unsigned long long>(1, ctr[GMK_DBG8]);
+            if (use_bucket) fprintf(stderr, "[gm_dbg] k_vote_bucket phases (mean clock ticks of lane 0 per sampled read, %llu samples; reads that leave early do not reach the later marks): forms + codes %.0f, "
+                            "records %.0f, first walk %.0f, routing %.0f, filter pass %.0f, sweeps %.0f, store %.0f\n", ctr[GMK_DBG8], ctr[GMK_DBG0] / ns, ctr[GMK_DBG1] / ns, ctr[GMK_DBG2] / ns,
+                            ctr[GMK_DBG3] / ns, ctr[GMK_DBG4] / ns, ctr[GMK_DBG5] / ns, ctr[GMK_DBG6] / ns);
+            else
             fprintf(stderr, "[gm_dbg] vote phases (mean cycles per sampled read x strand, %llu samples): desc %.0f, loads+window %.0f, pass1 %.0f, pass2a %.0f, scan %.0f, "
                             "filter2 %.0f, table %.0f, emit %.0f\n", ctr[GMK_DBG8], ctr[GMK_DBG0] / ns, ctr[GMK_DBG1] / ns, ctr[GMK_DBG2] / ns, ctr[GMK_DBG3] / ns, ctr[GMK_DBG4] / ns,
                     ctr[GMK_DBG5] / ns, ctr[GMK_DBG6] / ns, ctr[GMK_DBG7] / ns);

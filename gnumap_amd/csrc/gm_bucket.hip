@@ -360,6 +360,15 @@ __device__ __forceinline__ int gmb_lane_again() {
     return l;
 }
 
+// four zero registers made HERE (an asm the compiler cannot hoist): inside the persistent loop of k_vote_bucket a plain zero vector is
+// lifted out of the loop as a 4-register tuple, which cannot be rematerialised, is spilled, and comes back through scratch memory behind
+// a wait for EVERY outstanding load - the prefetched words of the next read included
+__device__ __forceinline__ uint4 gmb_zero4() {
+    uint4 z;
+    asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(z.x), "=v"(z.y), "=v"(z.z), "=v"(z.w));
+    return z;
+}
+
 // inclusive prefix sum within each half (32 lanes) of the wave: gm_wave_scan_incl without its last step
 __device__ __forceinline__ uint32_t gmb_half_scan_incl(uint32_t x) {
     uint32_t v = x;
@@ -388,33 +397,49 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
     uint32_t* const s_filt = reinterpret_cast<uint32_t*>(S.filt);          // [2][GMB_FWORDS]
     uint32_t* const s_keys = reinterpret_cast<uint32_t*>(S.small);         // [2][GMB_LCAP]
     uint32_t* const s_tagm = s_keys + 2 * GMB_LCAP;                          // [2]
-    const uint32_t r = blockIdx.x;                     // grid = n reads
-    int lane = threadIdx.x;
-    uint32_t h = (uint32_t)lane >> 5, jj = (uint32_t)lane & 31u, g = jj >> 3, q = (uint32_t)lane & 7u;
-    uint32_t rs = 2u * r + h;
     const uint32_t m = (uint32_t)p.mer, jump = (uint32_t)p.jump, w2 = b.pack_w2;
     const uint32_t TB = CTX ? (uint32_t)p.bucket_T : m, nx = m - TB;      // the table's k-mer = the last TB characters of the seed; nx in front of it
     const uint32_t cmask = TB >= 16u ? 0xFFFFFFFFu : ((1u << (2u * TB)) - 1u), cxm = (1u << (2u * nx)) - 1u;
     const uint32_t zero_code = cmask + 1u;             // the all-zero record behind the table (TB <= 15)
     const uint4* const bucket = reinterpret_cast<const uint4*>(p.bucket);
+    // PERSISTENT waves: a wave takes reads blockIdx.x, blockIdx.x + gridDim.x, ..  What that buys: the header + form words of the NEXT
+    // read are requested at the top of an iteration and have a whole read's work to arrive (the first of the read's two dependent HBM
+    // trips disappears from the wave's lifetime), and the candidate stores of a read are not waited for - the wave goes on with the
+    // next read instead of holding its slot until they are acknowledged.
+    uint32_t n_hdr = 0, n_f0 = 0, n_f1 = 0, n_f2 = 0;
+    auto request_forms = [&](const uint32_t rr) {      // (the lane's word offsets are computed again each time: nothing per-lane lives across an iteration but these four words)
+        const int ln = gmb_lane_again();
+        const uint32_t hh = (uint32_t)ln >> 5, ireg = ((uint32_t)ln & 31u) * jump;
+        const uint32_t oo = ireg + m <= 16u * w2 ? 2u * (16u * w2 - ireg - m) : 0u;
+        const uint32_t* const rw = b.pack + (size_t)rr * b.pack_words;
+        const uint32_t* const fm_ = rw + (hh ? w2 + 2u : 1u);
+        n_hdr = rw[0]; n_f0 = fm_[oo >> 5]; n_f1 = fm_[(oo >> 5) + 1u];
+        if (CTX) n_f2 = fm_[(oo >> 5) + 2u];           // (2 m bits from an even bit offset: up to three words)
+    };
+    if (blockIdx.x < b.n) request_forms(blockIdx.x);
+    for (uint32_t r = blockIdx.x; r < b.n; r += gridDim.x) {
+    int lane = gmb_lane_again();
+    uint32_t h = (uint32_t)lane >> 5, jj = (uint32_t)lane & 31u, g = jj >> 3, q = (uint32_t)lane & 7u;
+    uint32_t rs = 2u * r + h;
 
     // GM_DBG 64: phase clocks of one read in 256 (cycles of lane 0: forms, first records, first walk, its records, second walk + records, rest)
-    const bool prof = (p.dbg & 64) && (blockIdx.x & 255u) == 0u && threadIdx.x == 0;
+    const bool prof = (p.dbg & 64) && (r & 255u) == 0u && lane == 0;
     long long tck = prof ? clock64() : 0;
     auto tick = [&](int slot) { if (prof) { const long long now = clock64(); atomicAdd(&b.counters[GMK_DBG0 + slot], (unsigned long long)(now - tck)); tck = now; } };
     if (prof) atomicAdd(&b.counters[GMK_DBG8], 1ull);
-    // ---- the read's header and the words that hold lane jj's regular k-mer: one round trip ----
+    // ---- the read's header and the words that hold lane jj's regular k-mer (requested one read ago), and the next read's ----
     const uint32_t* const row = b.pack + (size_t)r * b.pack_words;
     const uint32_t* const form = row + (h ? w2 + 2u : 1u);
     const uint32_t i_reg = jj * jump;
     const bool inrow = i_reg + m <= 16u * w2;
     const uint32_t o = inrow ? 2u * (16u * w2 - i_reg - m) : 0u;
-    const uint32_t hdr_v = row[0], f0 = form[o >> 5], f1 = form[(o >> 5) + 1u];
-    const uint32_t f2 = CTX ? form[(o >> 5) + 2u] : 0u;                    // (2 m bits from an even bit offset: up to three words)
-    // the LDS structures are zeroed under that trip
+    const uint32_t hdr_v = n_hdr, f0 = n_f0, f1 = n_f1, f2 = n_f2;
+    if (r + gridDim.x < b.n) request_forms(r + gridDim.x);
+    (void)form;
+    // the LDS structures are zeroed
     {
         static_assert(sizeof(S.filt) == 4 * 64 * 16 && sizeof(S.small) <= 64 * 16, "one wave zeroes the filter with four stores per lane");
-        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        const uint4 z = gmb_zero4();
 #pragma unroll
         for (int k = 0; k < 4; ++k) S.filt[lane + 64 * k] = z;
         if (lane < (int)(sizeof(S.small) / 16)) S.small[lane] = z;
@@ -424,7 +449,7 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
     const bool strand_on = h ? (p.neg_strand != 0) : (p.pos_strand != 0);
     if ((hdr >> 17) & 1u) {                           // status != 0 (too short / too poor): nothing to look up, on either strand
         if (lane == 0) { reinterpret_cast<uint32_t*>(b.n_seeds)[r] = 0u; reinterpret_cast<unsigned long long*>(b.n_entries)[r] = 0ull; }
-        return;
+        continue;
     }
     const uint32_t last = L - m;
     uint32_t ns_h;                                    // seeds of this lane's half
@@ -561,8 +586,8 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
             // million atomics per second at best, and with long seeds most reads come through here), and the filter's LDS zeroed again
             const int lane = gmb_lane_again();
             const uint32_t fl0 = s_filt[GMB_SCR_FAILED], fl1 = s_filt[GMB_SCR_FAILED + 1u];
-            if (lane == 0 && fl0 + fl1 != 0u) atomicAdd(&b.shard_cnt[(size_t)(blockIdx.x & (GM_NSHARD - 1)) * GM_SHARD_STRIDE + 1u], fl0 + fl1);
-            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+            if (lane == 0 && fl0 + fl1 != 0u) atomicAdd(&b.shard_cnt[(size_t)(r & (GM_NSHARD - 1)) * GM_SHARD_STRIDE + 1u], fl0 + fl1);
+            const uint4 z = gmb_zero4();
 #pragma unroll
             for (int k = 0; k < 4; ++k) S.filt[lane + 64 * k] = z;
         }
@@ -573,7 +598,7 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) acc ^= rc[st].x ^ rc[st].y ^ rc[st].z ^ rc[st].w;
         if (acc == 0x12345u) b.counters[GMK_DBG0] = acc;
-        return;
+        continue;
     }
     // ---- seeds and SA hits of the two read x strands (k_heavy_collect sums them into the work counters and routes the heavy ones) ----
     uint32_t c_lane;
@@ -599,7 +624,7 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
         reinterpret_cast<uint32_t*>(b.n_seeds)[r] = ns0 | (ns1 << 16);
         reinterpret_cast<unsigned long long*>(b.n_entries)[r] = (unsigned long long)E0 | ((unsigned long long)E1 << 32);
     }
-    if (ns0 + ns1 == 0u) return;
+    if (ns0 + ns1 == 0u) continue;
     // ---- routing of each half by what its seeds actually hold ----
     const uint32_t E_h = gmb_pick(h, E0, E1);
     const bool heavy_h = ns_h != 0u && E_h > p.heavy_min;                         // sorted-key path (gm_heavy.hip), routed by k_heavy_collect
@@ -650,9 +675,10 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
         if (jj == 0u && big_h) hand_over();
     }
     const unsigned long long vmask = __builtin_amdgcn_ballot_w64(vote_h);
-    if (vmask == 0ull || (p.dbg & 512)) return;      // (GM_DBG 512: timing experiment, stop before the votes)
+    if (vmask == 0ull || (p.dbg & 512)) continue;      // (GM_DBG 512: timing experiment, stop before the votes)
     const uint32_t no0 = (uint32_t)__builtin_amdgcn_readlane((int)(vote_h ? n_ov_h : 0u), 0), no1 = (uint32_t)__builtin_amdgcn_readlane((int)(vote_h ? n_ov_h : 0u), 32);
     const uint32_t no_max = no0 > no1 ? no0 : no1;
+    tick(3);
     __syncthreads();                                  // zeroed structures + descriptors (one wave: a wait, not a rendezvous)
 
     uint32_t* const filt = s_filt + h * GMB_FWORDS;
@@ -660,18 +686,26 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
     // ---- pass 1 ----
     uint32_t lc_h = 0;                                // keys in this half's list so far
     uint32_t known = 0;                               // the half's most recent key: the true locus' hits arrive one after the other, only the first is listed
-    // the filter atomic of a hit: slot = the low 14 bits of its window start (chance hits are uniform, equal window starts meet)
-    auto arrive = [&](const uint32_t v, const uint32_t bp) -> uint32_t {
-        uint32_t old = 0;
-        if (vote_h && v != 0u) old = atomicOr(&filt[__builtin_amdgcn_ubfe(bp, 5, 9)], 1u << (bp & 31u));
+    // the filter atomic of a hit: slot = the low 14 bits of its window start (chance hits are uniform, equal window starts meet).
+    // Written for the instruction count (the kernel runs at the vector issue rate): the compares are taken as lane masks directly
+    // (__builtin_amdgcn_uicmp: one v_cmp each, combined in scalar registers), the word's address is one shift + one and-or
+    const uint32_t filt_off = (uint32_t)(size_t)(reinterpret_cast<unsigned char*>(s_filt) - reinterpret_cast<unsigned char*>(&S)) + h * (GMB_FWORDS * 4u);      // (S sits at LDS address 0: asserted by the launcher's static LDS size)
+    auto arrive = [&](const uint32_t v, const uint32_t bp, uint32_t& bit) -> uint32_t {
+        uint32_t old = 0;                              // lanes without a hit: no bit of theirs was set before
+        bit = 1u << (bp & 31u);
+        if (vote_h && v != 0u) {
+            uint32_t addr;                             // byte address of the filter word: ((bp >> 3) & 0x7FC) | the half's base, as ONE and-or
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(addr) : "v"(bp >> 3), "s"(0x7FCu), "v"(filt_off));      // (no 32-bit literals in VOP3 on gfx9: the mask sits in a scalar register)
+            old = atomicOr(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(&S) + addr), bit);
+        }
         return old;
     };
     // what its answer means: the bit was set before -> a second or later arrival; its window start goes to the key list unless it
     // is the half's most recent key (the true locus' hits arrive one after the other: listed once)
-    auto settle = [&](const uint32_t bp, const uint32_t old) {
-        const bool dup = (old >> (bp & 31u) & 1u) != 0u && bp != known;
-        const unsigned long long dm = __builtin_amdgcn_ballot_w64(dup);
+    auto settle = [&](const uint32_t bp, const uint32_t old, const uint32_t bit) {
+        const unsigned long long dm = __builtin_amdgcn_uicmp(old & bit, 0u, 33 /* != */) & __builtin_amdgcn_uicmp(bp, known, 33 /* != */);
         if (dm != 0ull) {                             // wave-uniform; rare: once per distinct window start that is met again
+            const bool dup = (old & bit) != 0u && bp != known;
             const uint32_t at = lc_h + gmb_half_prefix(dm, h);
             if (dup && at < GMB_LCAP) keys[at] = bp;
             lc_h += (uint32_t)__popc(gmb_half_bits(dm, h));
@@ -682,21 +716,25 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
             if (nk != 0u) known = nk;
         }
     };
-    auto pass1 = [&](const uint32_t v, const uint32_t off1) { const uint32_t bp = v - off1; settle(bp, arrive(v, bp)); };
+    auto pass1 = [&](const uint32_t v, const uint32_t off1) {
+        const uint32_t bp = v - off1; uint32_t bit;
+        const uint32_t old = arrive(v, bp, bit);
+        settle(bp, old, bit);
+    };
     {   // registers 0 and 1 of every step (positions 0 .. 13 of a record: nearly always there): the eight atomics are issued together,
         // one wait for all of them instead of one LDS round trip per hit
-        uint32_t bx[STEPS], by[STEPS], ox[STEPS], oy[STEPS];
+        uint32_t bx[STEPS], by[STEPS], ox[STEPS], oy[STEPS], tx[STEPS], ty[STEPS];
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) { bx[st] = rc[st].x - of1[st]; by[st] = rc[st].y - of1[st]; }
 #pragma unroll
-        for (int st = 0; st < STEPS; ++st) { ox[st] = arrive(rc[st].x, bx[st]); oy[st] = arrive(rc[st].y, by[st]); }
+        for (int st = 0; st < STEPS; ++st) { ox[st] = arrive(rc[st].x, bx[st], tx[st]); oy[st] = arrive(rc[st].y, by[st], ty[st]); }
 #pragma unroll
-        for (int st = 0; st < STEPS; ++st) { settle(bx[st], ox[st]); settle(by[st], oy[st]); }
+        for (int st = 0; st < STEPS; ++st) { settle(bx[st], ox[st], tx[st]); settle(by[st], oy[st], ty[st]); }
     }
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
-        if (__builtin_amdgcn_ballot_w64(rc[st].z != 0u) != 0ull) pass1(rc[st].z, of1[st]);      // counts >= 15
-        if (__builtin_amdgcn_ballot_w64(rc[st].w != 0u) != 0ull) pass1(rc[st].w, of1[st]);      // counts >= 22
+        if (__builtin_amdgcn_uicmp(rc[st].z, 0u, 33) != 0ull) pass1(rc[st].z, of1[st]);      // counts >= 15
+        if (__builtin_amdgcn_uicmp(rc[st].w, 0u, 33) != 0ull) pass1(rc[st].w, of1[st]);      // counts >= 22
     }
     for (uint32_t d = 0; d < no_max; ++d) {           // seeds with more than GMB_C hits: 32 ranks of the suffix array per half and round
         const bool en = vote_h && d < n_ov_h;
@@ -706,8 +744,9 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
             pass1(idx < n ? ix.full_sa[k + idx] + 1u : 0u, ot & 0xFFFFu);
         }
     }
+    tick(4);
     const unsigned long long anyd = __builtin_amdgcn_ballot_w64(lc_h != 0u);
-    if (anyd == 0ull || (p.dbg & 1024)) return;      // (GM_DBG 1024: timing experiment, stop after pass 1)                         // no second arrival on either strand: no window start with two votes
+    if (anyd == 0ull || (p.dbg & 1024)) continue;      // (GM_DBG 1024: timing experiment, stop after pass 1)                         // no second arrival on either strand: no window start with two votes
     __syncthreads();
     if (__builtin_amdgcn_ballot_w64(vote_h && lc_h > GMB_LCAP) != 0ull) {
         // more second arrivals than the key list holds (a repeat-rich read): the half goes to the list kernel after all
@@ -715,13 +754,13 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
         write_rows(over_h);
         if (jj == 0u && over_h) hand_over();
         if (over_h) { vote_h = false; lc_h = 0; }
-        if (__builtin_amdgcn_ballot_w64(lc_h != 0u) == 0ull) return;
+        if (__builtin_amdgcn_ballot_w64(lc_h != 0u) == 0ull) continue;
     }
     // ---- sweeps: one per distinct key of a half's list (both halves in the same instructions) ----
     uint32_t mykey = jj < lc_h ? keys[jj] : 0u;       // lane jj holds list entry jj of its half; 0 = none / done
     uint32_t n_em_h = 0;                              // candidates of this half so far
     GmCand first_c; first_c.rs = rs; first_c.b = 0; first_c.step = 0; first_c.flags = 4; first_c.pad = 0; first_c.score = 0.0f;
-    const uint32_t shard = (2u * blockIdx.x + h) & (GM_NSHARD - 1);
+    const uint32_t shard = (2u * r + h) & (GM_NSHARD - 1);
     for (;;) {
         const unsigned long long rem = __builtin_amdgcn_ballot_w64(mykey != 0u);
         if (rem == 0ull) break;
@@ -770,11 +809,14 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
         }
         __syncthreads();
     }
+    tick(5);
     if (jj == 0u && b.fixed_cands != nullptr && n_em_h != 0u && !(p.dbg & 2048)) {
         first_c.pad = (uint8_t)(n_em_h < GM_FIXED_C ? n_em_h : GM_FIXED_C);
         first_c.score = __uint_as_float(b.fixed_epoch);                            // k_cand_gather takes slots stamped with this launch only: no count array to zero, no second store
         b.fixed_cands[GM_FIXED_AT(b, rs, 0u)] = first_c;
     }
+    tick(6);
+    }   // next read of this wave
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------------------------------------
@@ -790,11 +832,22 @@ int gmk_build_bucket(const uint2* tab, const uint32_t* full_sa, const uint8_t* p
 
 int gmk_bucket_max_seeds(void) { return 32; }
 
+static uint32_t gm_bucket_grid(const GmDevParams& p, uint32_t max_reg) {
+    const long long fixed = gm_opt_ll("GM_BUCKET_GRID", 0);
+    if (fixed > 0) return (uint32_t)fixed;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+    const uint32_t per_simd = p.bucket_ctx ? 5u : max_reg <= 24 ? 8u : 6u;          // the kernels' launch bounds
+    return (uint32_t)cus * 4u * per_simd * 4u;
+}
+
 // seeds per strand the launch has to hold: max_reg = ceil((longest read - mer) / jump)
 int gmk_vote_bucket(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint32_t max_reg, void* stream) {
     if (b.n == 0) return 0;
     if (max_reg > 32 || (p.bucket_ctx && (p.mer <= p.bucket_T || p.mer - p.bucket_T > GMB_NX)) || (!p.bucket_ctx && p.mer != p.bucket_T)) return (int)hipErrorInvalidValue;
-    const dim3 grid(b.n), blk(64);
+    // persistent waves, each taking every grid-th read: 4 x as many one-wave workgroups as the chip holds at once (measured at 10 M reads:
+    // exactly resident 10.3 ms - the dispatcher's placement is then final and uneven -, 2 x 9.7, 4 x 9.25, one read per wave 9.65)
+    const dim3 grid(std::min<uint32_t>(b.n, gm_bucket_grid(p, max_reg))), blk(64);
     if (!p.bucket_ctx) {
         if (max_reg <= 8) hipLaunchKernelGGL((k_vote_bucket<2, false>), grid, blk, 0, S_(stream), ix, p, b);
         else if (max_reg <= 16) hipLaunchKernelGGL((k_vote_bucket<4, false>), grid, blk, 0, S_(stream), ix, p, b);
