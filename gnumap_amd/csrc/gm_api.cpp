@@ -887,7 +887,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         if (b->coords.ensure((size_t)ctr[GMK_SA_HITS] * 4 + 64)) return GM_E_NOMEM;
         fill_dev_batch(b);
         KCHK(gmk_scan_entries(b->dev, st));
-        { KTimer t(b, GM_K_LOCATE, st); KCHK(gmk_locate_sampled(ix->dev, b->dev, st)); }
+        { KTimer t(b, GM_K_LOCATE, st); KCHK(gmk_locate_sampled(ix->dev, b->dev, ctr[GMK_SA_HITS], st)); }
     }
     std::vector<uint32_t> heavy;                     // {rs, n_seeds, SA hits} triples
     if (b->heavy_list.ensure(3 * 2 * (size_t)b->n * 4 + 64)) return GM_E_NOMEM;

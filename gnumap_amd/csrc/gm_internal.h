@@ -171,7 +171,7 @@ int gmk_extend_kmer_table(const GmDevIndex& ix, const uint2* prev, uint2* next, 
 int gmk_prep(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream);
 int gmk_seed(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream);
 int gmk_scan_entries(const GmDevBatch& b, void* stream);
-int gmk_locate_sampled(const GmDevIndex& ix, const GmDevBatch& b, void* stream);
+int gmk_locate_sampled(const GmDevIndex& ix, const GmDevBatch& b, unsigned long long n_entries /* SA hits of the block = entries of coords[] */, void* stream);
 int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, int dense, int slots_hint, void* stream);
 int gmk_cand_gather(const GmDevBatch& b, void* stream);
 int gmk_shard_stats(const GmDevBatch& b, uint32_t* out /* {total, max} in device memory */, void* stream);

@@ -423,6 +423,71 @@ __global__ void __launch_bounds__(256) k_locate_sampled(GmDevIndex ix, GmDevBatc
 }
 
 // ------------------------------------------------------------------------------------------------
+// faithful locate, the form that fills the lanes: k_locate_sampled above gives a wavefront to a read x strand and its lanes to the SA
+// ranks of ONE seed at a time - 12 of 64 lanes at -m 14 on 3.1 Gbp, 1 .. 4 at -m 20, and every seed waits for its longest walk (the
+// walks are geometric: mean 31 steps, the longest of 64 ~130).  Here the hits of the whole block are one flat list (coords[], filled
+// with the START RANKS by k_locate_ranks) and every LANE walks its own hit; a lane whose walk has reached a sampled rank stores the
+// coordinate over the rank and takes its next hit at once, so all lanes stay on LF steps until the list is empty.  One LF step
+// (bwt_invPsi, src/bwt.c:53-59: the base at k and bwt_occ(k, base)) reads the 64-byte occ block of k ONCE - the four 16-byte loads of
+// one line go out together, the base is picked out of the loaded words: one HBM round trip per step instead of two dependent ones.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_locate_ranks(GmDevBatch b) {
+    const uint32_t rs = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = (uint32_t)gm_lane();
+    if (rs >= 2 * b.n) return;
+    const uint32_t ns = b.n_seeds[rs];
+    const GmSeed* seeds = b.seeds + (size_t)rs * b.max_seeds;
+    uint64_t off = b.entry_off[rs];
+    for (uint32_t t = 0; t < ns; ++t) {
+        const GmSeed sd = seeds[t];
+        const uint32_t cnt = sd.l - sd.k + 1;
+        for (uint32_t idx = lane; idx < cnt; idx += 64) b.coords[off + idx] = sd.k + idx;
+        off += cnt;
+    }
+}
+
+// one LF step with one line fetch: k -> L2[c] + occ(k, c), c = the BWT character at k (k != primary is the caller's business)
+__device__ __forceinline__ uint32_t gm_lf_step(const GmDevIndex& ix, const uint32_t k) {
+    const uint32_t x = k - ((k > ix.primary) ? 1u : 0u);               // bwt_B0's index (bwt_invPsi :55)
+    // bwt_occ(k, c) :107-129 counts bases == c among x' = k - (k >= primary) .. that is x for k != primary: [block start, x]
+    const uint4* blk = reinterpret_cast<const uint4*>(ix.bwt + ((size_t)(x >> 7) << 4));
+    const uint4 c0 = blk[0], c1 = blk[1], w0 = blk[2], w1 = blk[3];    // cumulative counts A, C (lo, hi each) | G, T | 64 bases | 64 bases
+    const uint32_t wi = (x & 0x7fu) >> 4;
+    const uint32_t word = wi < 4u ? (wi == 0u ? w0.x : wi == 1u ? w0.y : wi == 2u ? w0.z : w0.w) : (wi == 4u ? w1.x : wi == 5u ? w1.y : wi == 6u ? w1.z : w1.w);
+    const uint32_t c = (word >> ((~x & 0xfu) << 1)) & 3u;
+    uint32_t n = c == 0u ? c0.x : c == 1u ? c0.z : c == 2u ? c1.x : c1.z;              // low halves of the u64 counts (seq_len < 2^32)
+    const int within = (int)(x & 127u) + 1;
+    n += gm_count_base(((unsigned long long)w0.x << 32) | w0.y, c, within);
+    n += gm_count_base(((unsigned long long)w0.z << 32) | w0.w, c, within - 32);
+    n += gm_count_base(((unsigned long long)w1.x << 32) | w1.y, c, within - 64);
+    n += gm_count_base(((unsigned long long)w1.z << 32) | w1.w, c, within - 96);
+    return gm_L2(ix, c) + n;
+}
+
+__global__ void __launch_bounds__(256) k_locate_flat(GmDevIndex ix, GmDevBatch b, const unsigned long long n_entries) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256ull;
+    unsigned long long e = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
+    unsigned long long steps_total = 0;
+    bool have = e < n_entries;
+    uint32_t k = have ? b.coords[e] : 0u, sa = 0;
+    while (__builtin_amdgcn_ballot_w64(have) != 0ull) {
+        if (have) {
+            if ((k & ix.sa_mask) == 0u || sa >= GM_WALK_CAP) {              // a sampled rank: bwt_sa's loop ends (src/bwt.c:89-95)
+                b.coords[e] = sa + ix.sa_samples[k >> ix.sa_shift];
+                steps_total += sa;
+                e += stride;
+                have = e < n_entries;
+                if (have) { k = b.coords[e]; sa = 0; }
+            } else {
+                k = (k == ix.primary) ? 0u : gm_lf_step(ix, k);             // bwt_invPsi: the rank of $ maps to 0
+                ++sa;
+            }
+        }
+    }
+    gm_count(b, GMK_LF_STEPS, steps_total);
+}
+
+// ------------------------------------------------------------------------------------------------
 // locate + vote.  One wavefront owns one read x strand.  Votes are counted in an LDS table; because nearly all
 // located positions are singletons, a two-level bit filter (A: seen, B: seen twice) keeps the exact table small:
 // only positions whose filter bit was hit at least twice can reach kmin >= 2 votes.
@@ -2786,9 +2851,17 @@ int gmk_scan_entries(const GmDevBatch& b, void* stream) {
     return scan_u32(b.n_entries, 2ull * b.n, b.entry_off, reinterpret_cast<unsigned long long*>(b.retry_off), stream);
 }
 
-int gmk_locate_sampled(const GmDevIndex& ix, const GmDevBatch& b, void* stream) {
+int gmk_locate_sampled(const GmDevIndex& ix, const GmDevBatch& b, unsigned long long n_entries, void* stream) {
     if (b.n == 0) return 0;
-    hipLaunchKernelGGL(k_locate_sampled, dim3(cdiv(2ull * b.n, 4)), dim3(256), 0, S_(stream), ix, b);
+    if (gm_opt_is("GM_LOCATE", "wave")) {           // the first form: a wavefront per read x strand, its lanes on one seed's ranks at a time
+        hipLaunchKernelGGL(k_locate_sampled, dim3(cdiv(2ull * b.n, 4)), dim3(256), 0, S_(stream), ix, b);
+        return (int)hipGetLastError();
+    }
+    if (n_entries == 0) return 0;
+    hipLaunchKernelGGL(k_locate_ranks, dim3(cdiv(2ull * b.n, 4)), dim3(256), 0, S_(stream), b);
+    // every lane walks: 8 workgroups of 256 lanes per CU resident, each lane taking every (grid x 256)-th hit of the list
+    const uint32_t grid = (uint32_t)std::min<unsigned long long>(cdiv(n_entries, 256ull), (unsigned long long)gm_opt_ll("GM_LOCATE_GRID", 256 * 8));
+    hipLaunchKernelGGL(k_locate_flat, dim3(grid), dim3(256), 0, S_(stream), ix, b, n_entries);
     return (int)hipGetLastError();
 }
 

@@ -19,8 +19,7 @@
 #include <hip/hip_runtime.h>
 #include "gm_device.h"
 
-namespace {
-inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 #define GM_NWR_NCOFF 1024u                  // contig offsets cached in LDS when there are at most this many
 #define GM_NWR_QSTRIDE 144u                 // bytes per quality character in the value table: 8 class records of 16 bytes + 16 bytes of skew (banks)
@@ -267,8 +266,6 @@ __global__ void __launch_bounds__(256, NCH <= 13 ? 4 : 3) k_nw_rows(GmDevIndex i
     gm_count(b, GMK_NW_CELLS, cells);
     gm_count(b, GMK_ACCEPTED, accepted);
 }
-
-}  // namespace
 
 // L = the one read length of the block; illumina = some reads of the block use the Phred+64 table (both tables are then resident)
 int gmk_nw_rows(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint32_t n_cands, uint32_t L, void* stream) {
