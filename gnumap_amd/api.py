@@ -83,7 +83,7 @@ EXPORTS = ["gm_last_error", "gm_version", "gm_set_option", "gm_selftest_pass_par
            "gm_batch_upload", "gm_map_batch_device", "gm_batch_counters", "gm_batch_path", "gm_batch_set_profiling", "gm_batch_kernel_times", "gm_kernel_name",
            "gm_batch_raw_hits", "gm_stream_create", "gm_stream_destroy", "gm_host_alloc", "gm_host_free", "gm_map_batch", "gm_output_batch",
            "gm_map_batch_enqueue", "gm_output_batch_enqueue", "gm_batch_wait",
-           "gm_dev_sa_interval", "gm_dev_locate", "gm_dev_nw_score", "gm_dev_traceback", "gm_coverage_reset", "gm_coverage_bins",
+           "gm_dev_sa_interval", "gm_dev_locate", "gm_dev_nw_score", "gm_dev_traceback", "gm_dev_pair_hmm", "gm_coverage_reset", "gm_coverage_bins",
            "gm_coverage_device_ptr", "gm_coverage_add", "gm_coverage_download", "gm_coverage_allreduce", "gm_coverage_write_sgr", "gm_coverage_enable_nuc", "gm_coverage_nuc_device_ptr",
            "gm_coverage_download_nuc", "gm_coverage_write_gmp"]
 
@@ -140,6 +140,7 @@ def load_library():
     L.gm_dev_nw_score.argtypes = [C.c_void_p, C.POINTER(gm_params), C.POINTER(gm_reads), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.gm_dev_traceback.argtypes = [C.c_void_p, C.POINTER(gm_params), C.POINTER(gm_reads), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                    C.c_void_p, C.c_uint32, C.c_void_p]
+    L.gm_dev_pair_hmm.argtypes = [C.c_void_p, C.POINTER(gm_params), C.POINTER(gm_reads), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.gm_coverage_reset.argtypes = [C.c_void_p, C.c_uint32]
     L.gm_coverage_bins.argtypes = [C.c_void_p]; L.gm_coverage_bins.restype = u64
     L.gm_coverage_device_ptr.argtypes = [C.c_void_p]; L.gm_coverage_device_ptr.restype = C.c_void_p
@@ -280,6 +281,14 @@ class Index:
                                     ops.ctypes.data, stride, ln.ctypes.data))
         return [ops[i, :ln[i]].tobytes() for i in range(n)]
 
+    def dev_pair_hmm(self, params, B, Q, Ln, read_idx, strand, pos):
+        """bin_seq::pairHMM of read read_idx[k] (oriented by strand[k]) against the window at pos[k]: [n][stride][5] floats"""
+        r = _reads_struct(B, Q, Ln)
+        read_idx = np.ascontiguousarray(read_idx, np.uint32); strand = np.ascontiguousarray(strand, np.uint8); pos = np.ascontiguousarray(pos, np.uint64)
+        out = np.zeros((len(read_idx), B.shape[1], 5), np.float32)
+        _chk(lib().gm_dev_pair_hmm(self.h, C.byref(params.c), C.byref(r), read_idx.ctypes.data, strand.ctypes.data, pos.ctypes.data, len(read_idx), out.ctypes.data))
+        return out
+
     # ---- coverage ----
     def coverage_reset(self, bin_size):
         _chk(lib().gm_coverage_reset(self.h, bin_size))
@@ -305,6 +314,12 @@ class Index:
     def coverage_download(self):
         out = np.zeros(self.coverage_bins(), np.float32)
         _chk(lib().gm_coverage_download(self.h, out.ctypes.data))
+        return out
+
+    def coverage_download_nuc(self):
+        """the five per-nucleotide tracks (a, c, g, t, n), [5 * bins]"""
+        out = np.zeros(5 * self.coverage_bins(), np.float32)
+        _chk(lib().gm_coverage_download_nuc(self.h, out.ctypes.data))
         return out
 
     def coverage_write_sgr(self, bins, path):

@@ -132,7 +132,8 @@ struct gm_batch {
         tb_items, tb_ops, tb_len, band_moves, pack,
         // grouping (process_hits' unique map) and output stage, gm_output.hip
         g_sorted, g_ord, g_lead, g_krank, g_khash, g_nmatch, g_mbegin, g_multi, g_big, g_bigdone, g_sk0, g_sk1, g_si0, g_si1, g_matches, g_mhit, g_positions, scan_tmp,
-        o_small, o_posmatch, o_post, o_mapq, o_emit, o_reccnt, o_cigcnt, o_cigall, o_recoff, o_cigoff, o_recs, o_pool, o_codes;
+        o_small, o_posmatch, o_post, o_mapq, o_emit, o_reccnt, o_cigcnt, o_cigall, o_recoff, o_cigoff, o_recs, o_pool, o_codes,
+        snp_scratch, snp_hmm;           // --snp: forward matrices of a chunk of kept sequences, their 5 floats per window position
     PinBuf h_top, h_hbegin, h_ord, h_post, h_mapq, h_emit, h_mhit, h_stat;      // h_stat: the small status words a phase reads back (page-locked: one short DMA)
     std::vector<double> h_exp;          // exp(score) of every accepted hit of the last gm_map_batch (reused by gm_output_batch)
     uint64_t cache_hits = 0, cache_matches = 0;
@@ -591,7 +592,7 @@ extern "C" void gm_batch_destroy(gm_batch* b) {
                       &b->tb_len, &b->band_moves, &b->pack,
                       &b->g_sorted, &b->g_ord, &b->g_lead, &b->g_krank, &b->g_khash, &b->g_nmatch, &b->g_mbegin, &b->g_multi, &b->g_big, &b->g_bigdone, &b->g_sk0, &b->g_sk1, &b->g_si0, &b->g_si1, &b->g_matches, &b->g_mhit, &b->g_positions,
                       &b->scan_tmp, &b->o_small, &b->o_posmatch, &b->o_post, &b->o_mapq, &b->o_emit, &b->o_reccnt, &b->o_cigcnt, &b->o_cigall, &b->o_recoff, &b->o_cigoff,
-                      &b->o_recs, &b->o_pool, &b->o_codes };
+                      &b->o_recs, &b->o_pool, &b->o_codes, &b->snp_scratch, &b->snp_hmm };
     for (DevBuf* d : all) d->release();
     PinBuf* pins[] = { &b->h_top, &b->h_hbegin, &b->h_ord, &b->h_post, &b->h_mapq, &b->h_emit, &b->h_mhit, &b->h_stat };
     for (PinBuf* d : pins) d->release();
@@ -1489,7 +1490,9 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
         if (b->cache_matches == n_m64 && b->cache_hits <= hits->positions_cap && b->cache_hits >= n_p) n_p = b->cache_hits;     // positions share the hit CSR
     }
     const uint32_t ops_words = gm_ops_words(b->stride), codes_stride = 32u * ops_words;
-    const bool nuc = p->mode != GM_MODE_NORMAL && ix->nuc_on;
+    const bool snp = p->mode == GM_MODE_SNP;
+    if (snp && !ix->nuc_on) { gm_set_error("GM_MODE_SNP deposits into the per-nucleotide tracks: call gm_coverage_enable_nuc first"); return GM_E_ARG; }
+    const bool nuc = p->mode != GM_MODE_NORMAL && !snp && ix->nuc_on;
     if (b->g_matches.ensure((size_t)n_m * sizeof(GmDevMatch)) || b->g_positions.ensure((size_t)(n_p + 1) * sizeof(GmDevPos)) ||
         b->o_posmatch.ensure((size_t)(n_p + 1) * 4) || b->o_post.ensure((size_t)n_m * 4) || b->o_mapq.ensure((size_t)n_m * 4) || b->o_emit.ensure(n_m) ||
         b->tb_items.ensure((size_t)n_m * sizeof(GmCand)) || b->tb_ops.ensure((size_t)n_m * ops_words * 8) || b->tb_len.ensure((size_t)n_m * 2) ||
@@ -1581,7 +1584,20 @@ extern "C" int gm_output_batch(gm_index* ix, const gm_params* p, gm_batch* b, co
         HIPCHK(hipMemcpyAsync(out->recs, b->o_recs.p, (size_t)n_recs * sizeof(gm_sam_rec), hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(out->cigar_pool, b->o_pool.p, (size_t)cig_len, hipMemcpyDeviceToHost, st));
     }
-    if (ix->cov_bins && n_p && max_span) {
+    if (snp && ix->cov_bins && n_p) {
+        // SNPScoredSeq::score: no traceback in the deposit - the pair HMM of every kept sequence against its window, chunk by chunk (a
+        // lane's forward matrix is (L+1)^2 x 3 doubles of scratch), then coverage + the five tracks at every place of the sequence
+        const uint32_t Lmax = b->stride;
+        const uint32_t chunk = (uint32_t)std::min<long long>(std::max<long long>(64, gm_opt_ll("GM_SNP_CHUNK", 16384)), n_m) / 64u * 64u + 64u;
+        const size_t cells = gmk_pair_hmm_cells(Lmax);
+        if (b->snp_scratch.ensure((size_t)((chunk + 63) / 64) * cells * 8) || b->snp_hmm.ensure((size_t)chunk * Lmax * 5 * 4)) return GM_E_NOMEM;
+        for (uint32_t m0 = 0; m0 < n_m; m0 += chunk) {
+            const uint32_t cnt = std::min<uint32_t>(chunk, n_m - m0);
+            KCHK(gmk_pair_hmm(ix->dev, dp, b->dev, b->tb_items.as<GmCand>() + m0, cnt, b->snp_scratch.as<double>(), Lmax, b->snp_hmm.as<float>(), st));
+            KCHK(gmk_snp_deposit(ix->d_cov.as<float>(), ix->d_nuc.as<float>(), ix->cov_bins, ix->cov_bin_size, b->dev, d_m, d_p, m0, cnt, b->o_post.as<float>(),
+                                 b->snp_hmm.as<float>(), Lmax, st));
+        }
+    } else if (ix->cov_bins && n_p && max_span) {
         if (nuc) KCHK(gmk_out_codes(b->dev, dp, d_m, n_m, b->tb_ops.as<unsigned long long>(), ops_words, b->tb_len.as<uint16_t>(), b->o_codes.as<uint8_t>(), codes_stride, st));
         KCHK(gmk_out_deposit(ix->d_cov.as<float>(), ix->cov_bins, ix->cov_bin_size, d_m, d_p, b->o_posmatch.as<uint32_t>(), n_p, b->tb_len.as<uint16_t>(),
                              b->o_post.as<float>(), max_span, nuc ? ix->d_nuc.as<float>() : nullptr, nuc ? b->o_codes.as<uint8_t>() : nullptr, codes_stride, st));
@@ -1780,6 +1796,33 @@ extern "C" int gm_dev_traceback(gm_index* ix, const gm_params* p, const gm_reads
     return GM_OK;
 }
 
+extern "C" int gm_dev_pair_hmm(gm_index* ix, const gm_params* p, const gm_reads* reads, const uint32_t* read_idx, const uint8_t* strand, const uint64_t* pos,
+                               uint32_t n, float* out) {
+    if (!ix || !p || !reads || !read_idx || !strand || !pos || !out || !p->finalized) return GM_E_ARG;
+    if (ix->host_only) return GM_E_NO_DEVICE;
+    HIPCHK(hipSetDevice(ix->device));
+    gm_batch* b; GmDevParams dp;
+    int rc = unit_batch(ix, p, reads, &b, dp);
+    if (rc) return rc;
+    std::vector<GmCand> c(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (read_idx[i] >= reads->n || pos[i] + reads->len[read_idx[i]] > ix->h.l_pac) { gm_batch_destroy(b); return GM_E_ARG; }
+        c[i].rs = read_idx[i] * 2 + (strand[i] ? 1 : 0); c[i].b = (uint32_t)pos[i]; c[i].step = 0; c[i].flags = 0; c[i].pad = 0; c[i].score = 0;
+    }
+    const uint32_t Lmax = b->stride;
+    do {
+        if (b->tb_items.ensure((size_t)n * sizeof(GmCand) + 16) || b->snp_scratch.ensure((size_t)((n + 63) / 64) * gmk_pair_hmm_cells(Lmax) * 8 + 16) ||
+            b->snp_hmm.ensure((size_t)n * Lmax * 5 * 4 + 16)) { rc = GM_E_NOMEM; break; }
+        if (n && hipMemcpy(b->tb_items.p, c.data(), (size_t)n * sizeof(GmCand), hipMemcpyHostToDevice) != hipSuccess) { rc = GM_E_HIP; break; }
+        if (n && hipMemset(b->snp_hmm.p, 0, (size_t)n * Lmax * 5 * 4) != hipSuccess) { rc = GM_E_HIP; break; }
+        if (gmk_pair_hmm(ix->dev, dp, b->dev, b->tb_items.as<GmCand>(), n, b->snp_scratch.as<double>(), Lmax, b->snp_hmm.as<float>(), nullptr)) { rc = GM_E_HIP; break; }
+        if (n && hipMemcpy(out, b->snp_hmm.p, (size_t)n * Lmax * 5 * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = GM_E_HIP; break; }
+    } while (0);
+    gm_batch_destroy(b);
+    if (rc) { gm_set_error("gm_dev_pair_hmm: HIP failure"); return rc; }
+    return GM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // coverage track
 // ------------------------------------------------------------------------------------------------
@@ -1951,6 +1994,28 @@ extern "C" int gm_coverage_write_gmp(gm_index* ix, const gm_params* p, const flo
     if (!ix || !p || !bins || !nuc || !path || !ix->cov_bin_size || p->mode == GM_MODE_NORMAL) return GM_E_ARG;
     const GmHostIndex& h = ix->h;
     const uint64_t bs = ix->cov_bin_size, nb = ix->cov_bins;
+    if (p->mode == GM_MODE_SNP) {
+        // GenomeBwt::PrintFinalSNP src/GenomeBwt.cpp:930-1090 up to the per-nucleotide columns: every position whose total is above MIN_PRINT,
+        // "%.5f" for all six numbers.  PrintSNPCall's likelihood-ratio columns need gsl_cdf_chisq_P (GSL): not written, the line ends here.
+        const uint64_t nbk = (h.l_pac + bs - 1) / bs;
+        size_t max_name = 0;
+        for (const auto& c : h.contigs) max_name = std::max(max_name, c.name.size());
+        std::vector<int> cur(host_threads(), 0);
+        return write_track_text(path, append, nbk, max_name + 160, [&](uint64_t k, char* w, unsigned c, bool first) -> char* {
+            int& i = cur[c];
+            const uint64_t count = k * bs;
+            if (first) i = (int)host_pos2rid(h, count);
+            while ((size_t)i + 1 < h.contigs.size() && count >= h.contigs[(size_t)i + 1].offset) ++i;
+            if (!(bins[k] > 0.001f)) return w;
+            const GmContig& cg = h.contigs[(size_t)i];
+            memcpy(w, cg.name.data(), cg.name.size()); w += cg.name.size();
+            *w++ = '\t'; w = put_long(w, (long)(count - cg.offset) + 1); *w++ = '\t';
+            w = put_fixed(w, bins[k], 5);
+            for (int q = 0; q < 5; ++q) { *w++ = '\t'; w = put_fixed(w, nuc[(uint64_t)q * nb + k], 5); }
+            *w++ = '\n';
+            return w;
+        });
+    }
     const char want = p->mode == GM_MODE_BS ? 'c' : p->mode == GM_MODE_BS2 ? 'g' : p->mode == GM_MODE_ATOG ? 'a' : 't';
     const uint64_t nbk = (h.l_pac + bs - 1) / bs;
     size_t max_name = 0;

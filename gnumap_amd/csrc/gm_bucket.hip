@@ -681,7 +681,6 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
     tick(3);
     __syncthreads();                                  // zeroed structures + descriptors (one wave: a wait, not a rendezvous)
 
-    uint32_t* const filt = s_filt + h * GMB_FWORDS;
     uint32_t* const keys = s_keys + h * GMB_LCAP;
     // ---- pass 1 ----
     uint32_t lc_h = 0;                                // keys in this half's list so far

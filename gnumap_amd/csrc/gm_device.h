@@ -324,7 +324,7 @@ static_assert(sizeof(GmDevIndex) % 8 == 0 && sizeof(GmDevParams) % 8 == 0 && siz
 static_assert(offsetof(GmKArgs, p) == sizeof(GmDevIndex) && offsetof(GmKArgs, b) == sizeof(GmDevIndex) + sizeof(GmDevParams), "kernarg mirror: offsets");
 // one lane.  out = where the seeds go (LDS), or null: the read x strand's row in HBM, for the kernel it is handed to.  count = add the
 // failed k-mers to the work counters (k_heavy_collect counts one k-mer and one table probe per seed).  Returns the number of seeds.
-static __device__ __attribute__((noinline)) uint32_t gm_seed_walk_ool(const GmKArgs* a, const uint32_t rs, GmSeed* out, const int count) {
+static __device__ __attribute__((noinline)) __attribute__((unused)) uint32_t gm_seed_walk_ool(const GmKArgs* a, const uint32_t rs, GmSeed* out, const int count) {
     const GmDevBatch& b = a->b;
     unsigned long long nk = 0, nocc = 0, nblk = 0, ntab = 0, nseed = 0, nent = 0;
     const uint32_t r = rs >> 1;

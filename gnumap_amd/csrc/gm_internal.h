@@ -200,6 +200,11 @@ inline uint64_t gm_band_moves_words(uint32_t n, uint32_t stride) {          // a
     const uint64_t rows = (uint64_t)stride + 1, cap = (512ull << 20) / 8, all = (uint64_t)n * rows;
     return all < cap ? all : (cap > 128 * rows ? cap : 128 * rows);
 }
+// gm_snp.hip: --snp (SNPScoredSeq): pair HMM per kept sequence + the deposit of its posteriors
+size_t gmk_pair_hmm_cells(uint32_t Lmax);            // doubles of scratch per wavefront (64 kept sequences)
+int gmk_pair_hmm(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, const GmCand* items, uint32_t n, double* scratch, uint32_t Lmax, float* hmm, void* stream);
+int gmk_snp_deposit(float* cov, float* nuc, uint64_t bins, uint32_t bin_size, const GmDevBatch& b, const GmDevMatch* matches, const GmDevPos* positions,
+                    uint32_t m0, uint32_t count, const float* post, const float* hmm, uint32_t Lmax, void* stream);
 int gmk_compact(const GmDevBatch& b, void* stream);
 int gmk_scan_hits(const GmDevBatch& b, void* stream);
 int gmk_scatter(const GmDevBatch& b, uint32_t grid, void* stream);

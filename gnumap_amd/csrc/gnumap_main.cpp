@@ -65,6 +65,7 @@ static void usage(int rc, const char* msg) {
             "  -S, --subst_file=STRING      5 x 4 substitution matrix file (rows a c g t n; scores are then used unscaled)\n"
             "  -c, --num_proc=INT           accepted for compatibility (the GPU path ignores it)\n"
             "  -b, --bs_seq / --b2 / -d, --a_to_g   bisulfite / A-to-G scoring\n"
+            "      --snp                    pair-HMM per-nucleotide deposit (SNPScoredSeq); <out>.gmp without the likelihood-ratio columns\n"
             "      --no_nw                  use k-mer hit counts instead of Needleman-Wunsch alignments\n"
             "      --fast, --print_all_sam, --illumina, --up_strand, --down_strand, --bin_size=INT\n"
             "  MI355X options: --gpus=N  --batch=N (blocks of exactly N reads)  --chunk_reads=N  --workers=N  --fmt_threads=N  --locate=sampled|full\n");
@@ -101,6 +102,7 @@ static void parse_args(int argc, char** argv, Options& o) {
             else if (!strcmp(s, "bs_seq")) o.p.mode = GM_MODE_BS;
             else if (!strcmp(s, "b2")) o.p.mode = GM_MODE_BS2;
             else if (!strcmp(s, "a_to_g")) o.p.mode = GM_MODE_ATOG;
+            else if (!strcmp(s, "snp")) o.p.mode = GM_MODE_SNP;             // Driver.cpp:3207-3211: gSNP, bin size 1
             else if (!strcmp(s, "fast")) o.p.fast = 1;
             else if (starts(s, "bin_size=")) o.p.bin_size = atoi(s + 9);
             else if (starts(s, "jump=")) o.p.jump = atoi(s + 5);

@@ -52,7 +52,9 @@ typedef enum {
 
 /* per-read status, the reference's sentinel values (inc/const_include.h:183-186) */
 enum { GM_READ_OK = 0, GM_READ_TOO_MANY = 1, GM_READ_NONE = 2, GM_READ_TOO_SHORT = -2, GM_READ_TOO_POOR = -3 };
-enum { GM_MODE_NORMAL = 0, GM_MODE_BS = 1, GM_MODE_BS2 = 2, GM_MODE_ATOG = 3, GM_MODE_ATOG2 = 4 };
+enum { GM_MODE_NORMAL = 0, GM_MODE_BS = 1, GM_MODE_BS2 = 2, GM_MODE_ATOG = 3, GM_MODE_ATOG2 = 4,
+       GM_MODE_SNP = 5 /* --snp: SNPScoredSeq (src/SNPScoredSeq.cpp:25-109) - mapping as GM_MODE_NORMAL; gm_output_batch deposits the pair-HMM
+                          posteriors of every kept sequence into the five per-nucleotide tracks (bin size 1, gm_coverage_enable_nuc first) */ };
 enum { GM_POS_STRAND = 0, GM_NEG_STRAND = 1 };
 
 /* gm_index_open flags */
@@ -84,7 +86,7 @@ typedef struct {
     int fast;                   /* --fast */
     int unique_only;            /* -u */
     int pos_strand, neg_strand; /* --up_strand / --down_strand */
-    int mode;                   /* GM_MODE_* (-b, --b2, -d) */
+    int mode;                   /* GM_MODE_* (-b, --b2, -d, --snp) */
     float align_score;          /* -a  gALIGN_SCORE (0.9) */
     int align_is_fraction;      /* perc (1); 0 with -r */
     float cutoff;               /* -q  gCUTOFF_SCORE (0) */
@@ -256,6 +258,10 @@ int gm_dev_traceback(gm_index*, const gm_params*, const gm_reads*, const uint32_
                      const uint64_t* pos, uint32_t n, char* ops /* n x ops_stride, 'M','I','D', NUL padded */,
                      uint32_t ops_stride, uint16_t* ops_len);
 
+/* bin_seq::pairHMM (src/bin_seq.cpp:60-244) of read read_idx[k] in the orientation of strand[k] against the window at pos[k]:
+ * out[k][max_len][5] floats (a, c, g, t, n per window position), max_len = gm_reads.stride */
+int gm_dev_pair_hmm(gm_index*, const gm_params*, const gm_reads*, const uint32_t* read_idx, const uint8_t* strand, const uint64_t* pos, uint32_t n, float* out);
+
 /* ---- coverage track (amount_genome) ---- */
 int gm_coverage_reset(gm_index*, uint32_t bin_size);
 uint64_t gm_coverage_bins(const gm_index*);
@@ -271,6 +277,8 @@ int gm_coverage_enable_nuc(gm_index*);
 void* gm_coverage_nuc_device_ptr(gm_index*);
 int gm_coverage_download_nuc(gm_index*, float* host /* 5 x bins */);
 int gm_coverage_write_gmp(gm_index*, const gm_params*, const float* host_bins, const float* host_nuc, const char* path, int append);
+/* (GM_MODE_SNP: PrintFinalSNP src/GenomeBwt.cpp:930-1090 - every position above 0.001: contig, position, %.5f total, five %.5f sums.  The
+ * likelihood-ratio columns PrintSNPCall appends are NOT written: they need GSL's gsl_cdf_chisq_P, outside this hot path.) */
 
 #ifdef __cplusplus
 }

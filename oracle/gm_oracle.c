@@ -666,6 +666,73 @@ void gmo_map_read(const gmo_index* ix, const gmo_params* p, const float* pwm, co
     r->status = GMO_OK;
 }
 
+/* ---- --snp: the pair HMM of SNPScoredSeq::score (src/SNPScoredSeq.cpp:25-109) ----------------------------------------------------------
+ * bin_seq::pairHMM src/bin_seq.cpp:60-244 restated with the reference's types and operation order: the transition constants are FLOATs
+ * (inc/bin_seq.h:49-69; products such as PHMM_q*PHMM_Tmg are float products), the three (n+1) x (m+1) matrices doubles, p_seq (:41-57) a
+ * float sum of four float products times 3, the result rows floats that take `+= double` one read position at a time. */
+static const float PH_q = 0.25f, PH_t = 0.05f, PH_d = 0.0025f, PH_e = 0.5f;
+static float ph_score(char g, int x) {                         /* gPHMM_ALIGN_SCORES[genome char][read base], inc/a_matrices.c:92-120 */
+    const float match = 0.98f, syn = 0.01f, nsyn = 0.005f;     /* inc/const_define.h:79-81 */
+    int gi = g == 'a' || g == 'A' ? 0 : g == 'c' || g == 'C' ? 1 : g == 'g' || g == 'G' ? 2 : g == 't' || g == 'T' ? 3 : 4;
+    if (gi == 4) return nsyn;
+    if (gi == x) return match;
+    return (gi ^ x) == 2 ? syn : nsyn;                          /* a <-> g, c <-> t are the transitions */
+}
+static float ph_pseq(const float* x, char y) {
+    float sum = 0;
+    sum += x[0] * ph_score(y, 0); sum += x[1] * ph_score(y, 1); sum += x[2] * ph_score(y, 2); sum += x[3] * ph_score(y, 3);
+    return 3 * sum;
+}
+void gmo_pair_hmm(const float* pwm, int n, const char* cons, const char* genome, int m, float* out) {
+    const float Tmm = 1 - 2 * PH_d - PH_t, Tgm = 1 - PH_d - PH_t, Tmg = PH_d, Tgg = PH_e;
+    const int cs = (m + 1) * 3, pcs = m * 3;
+    const size_t sz = (size_t)(n + 1) * (size_t)(m + 1) * 3;
+    double* f = (double*)calloc(sz, sizeof(double)); double* b = (double*)calloc(sz, sizeof(double)); double* pp = (double*)calloc(sz, sizeof(double));
+    for (int i = 0; i < m * 5; ++i) out[i] = 0;
+    f[0] = 1;
+    for (int i = 1; i < n + 1; ++i)
+        for (int j = 1; j < m + 1; ++j) {
+            f[i * cs + 3 * j] = ph_pseq(pwm + 4 * (i - 1), genome[j - 1]) * (Tmm * f[(i - 1) * cs + 3 * (j - 1)] + Tgm * f[(i - 1) * cs + 3 * (j - 1) + 1] + Tgm * f[(i - 1) * cs + 3 * (j - 1) + 2]);
+            f[i * cs + 3 * j + 1] = PH_q * (Tmg * f[(i - 1) * cs + 3 * j] + Tgg * f[(i - 1) * cs + 3 * j + 1]);
+            f[i * cs + 3 * j + 2] = PH_q * (Tmg * f[i * cs + 3 * (j - 1)] + Tgg * f[i * cs + 3 * (j - 1) + 2]);
+        }
+    const double fE = PH_t * (f[n * cs + 3 * m] + f[n * cs + 3 * m + 1] + f[n * cs + 3 * m + 2]);
+    b[(n - 1) * cs + 3 * (m - 1)] = b[(n - 1) * cs + 3 * (m - 1) + 1] = b[(n - 1) * cs + 3 * (m - 1) + 2] = PH_t;
+    for (int i = n - 1; i >= 0; --i)
+        for (int j = m - 1; j >= 0; --j) {
+            if (j == m - 1 && i == n - 1) continue;
+            if (j == m - 1) {
+                b[i * cs + 3 * j] = PH_q * Tmg * b[(i + 1) * cs + 3 * j + 1];
+                b[i * cs + 3 * j + 1] = PH_q * Tgg * b[(i + 1) * cs + 3 * j + 1];
+                b[i * cs + 3 * j + 2] = 0;
+                continue;
+            }
+            if (i == n - 1) {
+                b[i * cs + 3 * j] = PH_q * Tmg * b[i * cs + 3 * (j + 1) + 2];
+                b[i * cs + 3 * j + 2] = PH_q * Tgg * b[i * cs + 3 * (j + 1) + 2];
+                b[i * cs + 3 * j + 1] = 0;
+                continue;
+            }
+            const float ps = ph_pseq(pwm + 4 * (i + 1), genome[j + 1]);
+            b[i * cs + 3 * j] = ps * Tmm * b[(i + 1) * cs + 3 * (j + 1)] + PH_q * Tmg * b[(i + 1) * cs + 3 * j + 1] + PH_q * Tmg * b[i * cs + 3 * (j + 1) + 2];
+            b[i * cs + 3 * j + 1] = ps * Tgm * b[(i + 1) * cs + 3 * (j + 1)] + PH_q * Tgg * b[(i + 1) * cs + 3 * j + 1];
+            b[i * cs + 3 * j + 2] = ps * Tgm * b[(i + 1) * cs + 3 * (j + 1)] + PH_q * Tgg * b[i * cs + 3 * (j + 1) + 2];
+        }
+    for (int i = 1; i < n + 1; ++i)
+        for (int j = 1; j < m + 1; ++j) {
+            pp[(i - 1) * pcs + 3 * (j - 1)] = f[i * cs + 3 * j] * b[(i - 1) * cs + 3 * (j - 1)] / fE;
+            pp[(i - 1) * pcs + 3 * (j - 1) + 1] = f[i * cs + 3 * j + 1] * b[(i - 1) * cs + 3 * (j - 1) + 1] / fE;
+            pp[(i - 1) * pcs + 3 * (j - 1) + 2] = f[i * cs + 3 * j + 2] * b[(i - 1) * cs + 3 * (j - 1) + 2] / fE;
+        }
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < n; ++j) {                           /* g_gen_CONVERSION[consensus[j]] (no _INDEL build: Makefile:60): M + Y of the cell */
+            const char c = cons[j];
+            const int idx = c == 'a' || c == 'A' ? 0 : c == 'c' || c == 'C' ? 1 : c == 'g' || c == 'G' ? 2 : c == 't' || c == 'T' ? 3 : 4;
+            out[i * 5 + idx] += pp[j * pcs + i * 3 + 2] + pp[j * pcs + i * 3];
+        }
+    free(f); free(b); free(pp);
+}
+
 /* ScoredSeq::max_char ScoredSeq.h:72-103 (argmax consensus, 'n' when all four equal) */
 static char max_char(const float* c) {
     if (c[0] == c[1] && c[0] == c[2] && c[0] == c[3]) return 'n';
@@ -729,14 +796,26 @@ int gmo_read_output(const gmo_index* ix, const gmo_params* p, const gmo_result* 
         const gmo_hit* hit = &r->hits[h];
         /* score(): span = aligned.size() of a traceback, weight = (float)(exp(score)/denom), every (pos,strand) */
         int alen = L; char cig[1024];
+        float* hmm = NULL; float* hmm_rev = NULL;
+        if (p->mode == GMO_MODE_SNP) {
+            /* SNPScoredSeq::score SNPScoredSeq.cpp:25-109: no traceback - the pair HMM of (first strand's PWM, its argmax consensus) against the
+             * window; span = the window's length; the other strand takes reverse_comp_cpy_phmm (SequenceOperations.h:164-181) */
+            hmm = (float*)malloc(sizeof(float) * 5 * (size_t)L); hmm_rev = (float*)malloc(sizeof(float) * 5 * (size_t)L);
+            if (hit->first_strand == 1) gmo_pair_hmm(rpwm, L, rcons, hit->seq, L, hmm); else gmo_pair_hmm(pwm, L, fcons, hit->seq, L, hmm);
+            for (int i = 0; i < L; ++i) { float* d = hmm_rev + 5 * (L - 1 - i); const float* q5 = hmm + 5 * i; d[0] = q5[3]; d[1] = q5[2]; d[2] = q5[1]; d[3] = q5[0]; d[4] = q5[4]; }
+        } else {
         if (hit->first_strand == 1) gmo_traceback(p, rpwm, L, rcons, hit->seq, aligned, &alen, cig);
         else gmo_traceback(p, pwm, L, fcons, hit->seq, aligned, &alen, cig);
         if (ctr) ctr->tracebacks++;
+        }
         double total = exp(hit->score) / r->denominator;
         for (int q = 0; q < hit->n_pos; ++q) {
             if (n_deps == cap_deps) { cap_deps = cap_deps ? cap_deps * 2 : 4; deps = (gmo_deposit*)realloc(deps, sizeof(gmo_deposit) * (size_t)cap_deps); }
-            deps[n_deps].pos = hit->pos[q].pos; deps[n_deps].span = (uint32_t)alen; deps[n_deps].w = (float)total; deps[n_deps].codes = NULL;
-            if (p->mode != GMO_MODE_NORMAL) {
+            deps[n_deps].pos = hit->pos[q].pos; deps[n_deps].span = (uint32_t)alen; deps[n_deps].w = (float)total; deps[n_deps].codes = NULL; deps[n_deps].hmm = NULL;
+            if (p->mode == GMO_MODE_SNP) {
+                deps[n_deps].hmm = (float*)malloc(sizeof(float) * 5 * (size_t)L);
+                memcpy(deps[n_deps].hmm, hit->pos[q].strand == hit->first_strand ? hmm : hmm_rev, sizeof(float) * 5 * (size_t)L);
+            } else if (p->mode != GMO_MODE_NORMAL) {
                 /* BSScoredSeq::score BSScoredSeq.cpp:24-88: the gapped read string for positions on the first strand, its
                  * reverse_comp for the others; AddSeqScore(pos+i, w, g_gen_CONVERSION[char]) */
                 uint8_t* codes = (uint8_t*)malloc((size_t)alen + 1);
@@ -759,6 +838,7 @@ int gmo_read_output(const gmo_index* ix, const gmo_params* p, const gmo_result* 
             }
             n_deps++;
         }
+        free(hmm); free(hmm_rev);
         if (p->print_all_sam) emit_sam(ix, p, r, hit, pwm, rpwm, cons, rcons, L, aligned, &recs, &n_recs, &cap_recs, ctr);
         if (exp(hit->score) > best_log) { best = hit; best_log = exp(hit->score); }     /* is_greater: strict, first wins */
     }
@@ -946,14 +1026,36 @@ int gmo_run(const gmo_index* ix, const gmo_params* p, const char* fastq, const c
                     /* AddSeqScore(pos, amt, which) GenomeBwt.cpp:556-603; which >= 5 ('\0' of the consense[i] quirk) indexes past
                      * reads[] in the reference (undefined behaviour): not deposited here */
                     if (ro->deps[d].codes && ro->deps[d].codes[t] < 5) nuc[ro->deps[d].codes[t]][bin] += ro->deps[d].w;
+                    /* AddSeqScore(pos, amt[], scale) GenomeBwt.cpp:496-551 (plain build): reads[c][loc] += amt[c] * scale, float product, float add */
+                    if (ro->deps[d].hmm) for (int c = 0; c < 5; ++c) nuc[c][bin] += ro->deps[d].hmm[5 * t + c] * ro->deps[d].w;
                 }
             }
-        for (int d = 0; d < ro->n_deps; ++d) free(ro->deps[d].codes);
+        for (int d = 0; d < ro->n_deps; ++d) { free(ro->deps[d].codes); free(ro->deps[d].hmm); }
         free(ro->sam); free(ro->deps);
     }
     st->n_reads = n;
     if (sam) fclose(sam);
-    if (out_prefix && p->mode != GMO_MODE_NORMAL) {       /* PrintFinalBisulfite GenomeBwt.cpp:1092-1210 (PrintFinal :915-926: .gmp INSTEAD of .sgr) */
+    if (out_prefix && p->mode == GMO_MODE_SNP) {
+        /* PrintFinalSNP GenomeBwt.cpp:930-1090 as far as it can be pinned here: chr, position, total, the five per-nucleotide sums of every
+         * position above MIN_PRINT.  The reference then appends PrintSNPCall's likelihood-ratio columns, which need gsl_cdf_chisq_P - the one
+         * symbol the reference build of oracle/Makefile leaves unresolved: not restated, the line ends after the eighth column. */
+        snprintf(fn, sizeof fn, "%s.gmp", out_prefix);
+        FILE* gm = fopen(fn, "w");
+        if (!gm) return -3;
+        uint64_t count = 0;
+        for (int i = 0; i < ix->n_seqs; ++i) {
+            uint64_t next = (i + 1 < ix->n_seqs) ? ix->contigs[i + 1].offset : ix->l_pac;
+            for (; count < next; count += (uint64_t)p->bin_size) {
+                uint64_t locus = count / (uint64_t)p->bin_size;
+                if (cov[locus] > MIN_PRINT) {
+                    fprintf(gm, "%s\t%ld\t%.5f", ix->contigs[i].name, (long)(count - ix->contigs[i].offset) + 1, cov[locus]);
+                    for (int c = 0; c < 5; ++c) fprintf(gm, "\t%.5f", nuc[c][locus]);
+                    fprintf(gm, "\n");
+                }
+            }
+        }
+        fclose(gm);
+    } else if (out_prefix && p->mode != GMO_MODE_NORMAL) {       /* PrintFinalBisulfite GenomeBwt.cpp:1092-1210 (PrintFinal :915-926: .gmp INSTEAD of .sgr) */
         snprintf(fn, sizeof fn, "%s.gmp", out_prefix);
         FILE* gm = fopen(fn, "w");
         if (!gm) return -3;

@@ -42,7 +42,7 @@ typedef struct {
     gmo_contig* contigs;
 } gmo_index;
 
-enum { GMO_MODE_NORMAL = 0, GMO_MODE_BS = 1, GMO_MODE_BS2 = 2, GMO_MODE_ATOG = 3, GMO_MODE_ATOG2 = 4 };
+enum { GMO_MODE_NORMAL = 0, GMO_MODE_BS = 1, GMO_MODE_BS2 = 2, GMO_MODE_ATOG = 3, GMO_MODE_ATOG2 = 4, GMO_MODE_SNP = 5 /* --snp: SNPScoredSeq */ };
 
 typedef struct {
     int mer, jump, min_seed_hits;
@@ -86,7 +86,8 @@ typedef struct {
     float a_score, post_prob; int sim_matches;
 } gmo_sam;
 
-typedef struct { uint64_t pos; uint32_t span; float w; uint8_t* codes; /* -b/-d: g_gen_CONVERSION of the gapped read string per base, else NULL */ } gmo_deposit;
+typedef struct { uint64_t pos; uint32_t span; float w; uint8_t* codes; /* -b/-d: g_gen_CONVERSION of the gapped read string per base, else NULL */
+                 float* hmm; /* --snp: span x 5 pair-HMM posteriors (a, c, g, t, n) in the orientation of this position, else NULL */ } gmo_deposit;
 
 /* ---- index ---- */
 gmo_index* gmo_index_load(const char* fasta_prefix);
@@ -95,6 +96,8 @@ uint64_t gmo_occ(const gmo_index*, uint64_t k, int c, gmo_counters*);
 int gmo_sa_interval(const gmo_index*, const char* kmer, int m, uint64_t* start, uint64_t* end, gmo_counters*);
 uint64_t gmo_locate(const gmo_index*, uint64_t k, gmo_counters*);
 int gmo_window(const gmo_index*, uint64_t begin, uint32_t L, char* out);
+/* bin_seq::pairHMM src/bin_seq.cpp:60-244: out[m][5] = per window position the posterior weight of a, c, g, t, n of the read (n x 4 PWM, argmax consensus) */
+void gmo_pair_hmm(const float* pwm, int n, const char* cons, const char* genome, int m, float* out);
 int gmo_pos2rid(const gmo_index*, int64_t pos);
 
 /* ---- params / scoring ---- */

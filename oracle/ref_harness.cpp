@@ -14,6 +14,7 @@
  *   bin_seq::get_align_score(…)     src/bin_seq.cpp:739,761
  *   bin_seq::get_align_score_w_traceback  src/bin_seq.cpp:445
  *   SeqReader (FASTQ -> PWM)        src/SeqReader.cpp:1023-1292
+ *   bin_seq::pairHMM                src/bin_seq.cpp:60-244 (the --snp deposit of SNPScoredSeq::score, src/SNPScoredSeq.cpp:25-109)
  *
  * The driver-level code (Driver.cpp, align_seq2_raw.cpp, ScoredSeq.h, GenomeBwt.cpp) cannot be
  * compiled here: it includes gsl/gsl_cdf.h (inc/Genome.h:45), an external library the image lacks.
@@ -192,6 +193,20 @@ void ref_traceback(const float* pwm, int L, const char* cons, const char* window
     memcpy(aligned, res.first.data(), res.first.size());   /* may contain '\0' (the consense[i] quirk) */
     aligned[res.first.size()] = 0;
     strcpy(cigar, res.second.c_str());
+    free_rows(rows, L);
+}
+
+/* bin_seq::pairHMM, bin_seq.cpp:60: out = window length x NUM_SNP_VALS (5: this build has no _INDEL) floats */
+void ref_pair_hmm(const float* pwm, int L, const char* cons, const char* window, float* out) {
+    static bool init = false;
+    if (!init) { InitProg(); init = true; }      /* the program's start-up (Driver.cpp main): fills g_gen_CONVERSION, which pairHMM indexes */
+    float** rows;
+    Read r = make_read(pwm, L, rows);
+    bin_seq bs;
+    const std::string g(window);
+    float** res = bs.pairHMM(r, std::string(cons), g);
+    for (size_t i = 0; i < g.size(); ++i) { for (int k = 0; k < NUM_SNP_VALS; ++k) out[i * NUM_SNP_VALS + k] = res[i][k]; delete[] res[i]; }
+    delete[] res;
     free_rows(rows, L);
 }
 

@@ -58,6 +58,8 @@ class RefLib:
         L.ref_self_score.argtypes = [fptr, C.c_int, C.c_char_p]; L.ref_self_score.restype = C.c_float
         L.ref_align_score_be.argtypes = [fptr, C.c_int, C.c_char_p, C.c_uint, C.c_uint]; L.ref_align_score_be.restype = C.c_float
         L.ref_traceback.argtypes = [fptr, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_char_p]
+        if hasattr(L, "ref_pair_hmm"):
+            L.ref_pair_hmm.argtypes = [fptr, C.c_int, C.c_char_p, C.c_char_p, fptr]
         L.ref_read_fastq.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, fptr,
                                      np.ctypeslib.ndpointer(np.int32), C.c_char_p, C.c_char_p, C.c_char_p]
         L.ref_reverse_comp.argtypes = [C.c_char_p, C.c_char_p]
@@ -106,6 +108,12 @@ class RefLib:
         al = C.create_string_buffer(2 * L + 8); n = C.c_int(); cg = C.create_string_buffer(1024)
         self.lib.ref_traceback(P, L, cons, w, al, C.byref(n), cg)
         return al.raw[:n.value], n.value, cg.value
+
+    def pair_hmm(self, P, cons: bytes, w: bytes):
+        P = np.ascontiguousarray(P, np.float32)
+        out = np.zeros((len(w), 5), np.float32)
+        self.lib.ref_pair_hmm(P, len(P), cons, w, out)
+        return out
 
     def read_fastq(self, fq, illumina, cap, max_len):
         pwm = np.zeros((cap, max_len, 4), np.float32); lens = np.zeros(cap, np.int32)
@@ -166,7 +174,7 @@ class GmoSam(C.Structure):
 
 
 class GmoDeposit(C.Structure):
-    _fields_ = [("pos", u64), ("span", C.c_uint32), ("w", C.c_float), ("codes", C.POINTER(C.c_uint8))]
+    _fields_ = [("pos", u64), ("span", C.c_uint32), ("w", C.c_float), ("codes", C.POINTER(C.c_uint8)), ("hmm", C.POINTER(C.c_float))]
 
 
 class GmoRunStats(C.Structure):
@@ -190,6 +198,7 @@ class OracleLib:
         L.gmo_align_score_be.argtypes = [C.POINTER(GmoParams), fptr, C.c_int, C.c_char_p, C.c_uint, C.c_uint]
         L.gmo_align_score_be.restype = C.c_float
         L.gmo_traceback.argtypes = [C.POINTER(GmoParams), fptr, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_char_p]
+        L.gmo_pair_hmm.argtypes = [fptr, C.c_int, C.c_char_p, C.c_char_p, C.c_int, fptr]
         L.gmo_fix_cigar.argtypes = [C.c_char_p]
         L.gmo_reverse_cigar.argtypes = [C.c_char_p, C.c_char_p]
         L.gmo_revcomp_str.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
@@ -251,6 +260,12 @@ class OracleLib:
         assert r == 0
         return P[:L]
 
+    def pair_hmm(self, P, cons: bytes, w: bytes):
+        P = np.ascontiguousarray(P, np.float32)
+        out = np.zeros((len(w), 5), np.float32)
+        self.lib.gmo_pair_hmm(P, len(P), cons, w, len(w), out)
+        return out
+
     def traceback(self, p, P, cons: bytes, w: bytes):
         P = np.ascontiguousarray(P, np.float32)
         L = len(P)
@@ -289,6 +304,9 @@ class OracleLib:
             for k in range(nd.value):
                 d = pd[k]
                 codes = bytes(d.codes[t] for t in range(d.span)) if d.codes else None
+                if d.hmm:               # --snp: span x 5 posteriors instead of codes
+                    codes = np.ctypeslib.as_array(d.hmm, shape=(d.span, 5)).copy()
+                    self.libc.free(d.hmm)
                 deps.append((d.pos, d.span, d.w, codes))
                 if d.codes:
                     self.libc.free(d.codes)

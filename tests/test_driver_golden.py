@@ -69,3 +69,19 @@ def test_fixtures_are_what_the_reference_program_writes_now(mode, tmp_path):
     assert sam == ref_text(mode, "sam")
     for ext in m["tracks"]:
         assert open(tmp_path / f"r.{ext}", "rb").read() == ref_text(mode, ext)
+
+
+def test_oracle_snp_mode_keeps_the_default_sam(oracle, oix, tmp_path):
+    """--snp (SNPScoredSeq) changes the deposit, not the mapping: the reference program's SAM with --snp is its default-mode SAM (it
+    then aborts in PrintFinalSNP on gsl_cdf_chisq_P - GSL is not in the image - so its .gmp cannot be a fixture; the deposit is pinned at
+    function level, tests/test_oracle_golden.py::test_pair_hmm_equals_reference_function).  The oracle's .gmp: one line per covered
+    position, the five per-nucleotide sums of a position adding up to about its coverage."""
+    out = str(tmp_path / "o")
+    oracle.run(oix, oracle.params(mode=5), os.path.join(GOLDEN, "syn.fq"), out, threads=2)
+    sam = b"".join(l for l in open(out + ".sam", "rb") if not l.startswith(b"@PG"))
+    assert sam == ref_text("default", "sam")
+    assert not os.path.exists(out + ".sgr")
+    rows = [l.split("\t") for l in open(out + ".gmp")]
+    assert len(rows) > 30000 and all(len(r) == 8 for r in rows)
+    ratio = [sum(float(x) for x in r[3:]) / float(r[2]) for r in rows[::50]]
+    assert 0.9 < sorted(ratio)[len(ratio) // 2] < 1.05

@@ -7,6 +7,9 @@ import ctypes as C
 import numpy as np
 import pytest
 
+import os
+
+from conftest import GOLDEN
 from reflib import revcomp_pwm, revcomp_str
 
 
@@ -142,3 +145,17 @@ def test_output_helpers_against_reference_vectors(oracle, golden):
         out = C.create_string_buffer(len(s) + 8)
         oracle.lib.gmo_revcomp_str(s, len(s), out)
         assert out.raw[:len(s)] == want, s
+
+
+def test_pair_hmm_equals_reference_function(oracle):
+    """--snp: bin_seq::pairHMM (src/bin_seq.cpp:60-244; vectors made by tests/golden/make_snp_fixtures.py through the unmodified function):
+    the oracle's restatement gives the same 5 floats per window position, bit for bit - fp64 forward / backward matrices, float
+    transition products, float accumulation in read order"""
+    v = np.load(os.path.join(GOLDEN, "ref_vectors_snp.npz"))
+    assert len(v["len"]) >= 80 and (v["strand"] == 1).sum() > 20
+    for i in range(len(v["len"])):
+        L = int(v["len"][i])
+        got = oracle.pair_hmm(v["pwm"][i, :L], bytes(v["cons"][i, :L]), bytes(v["window"][i, :L]))
+        np.testing.assert_array_equal(got.view(np.uint32), v["hmm"][i, :L].view(np.uint32), err_msg=f"vector {i}")
+    # the posteriors of a window position sum to ~1 at a true locus (the read explains the position), to less off it
+    assert 0.99 < float(v["hmm"][0, : int(v["len"][0])].sum(1).mean()) < 1.01
