@@ -133,6 +133,7 @@ struct gm_batch {
         // grouping (process_hits' unique map) and output stage, gm_output.hip
         g_sorted, g_ord, g_lead, g_krank, g_khash, g_nmatch, g_mbegin, g_multi, g_big, g_bigdone, g_sk0, g_sk1, g_si0, g_si1, g_matches, g_mhit, g_positions, scan_tmp,
         o_small, o_posmatch, o_post, o_mapq, o_emit, o_reccnt, o_cigcnt, o_cigall, o_recoff, o_cigoff, o_recs, o_pool, o_codes,
+        pair_fb, pair_list,             // k_vote_pair: the reads it leaves to k_vote_bucket (one byte each), their list + its counter
         snp_scratch, snp_hmm;           // --snp: forward matrices of a chunk of kept sequences, their 5 floats per window position
     PinBuf h_top, h_hbegin, h_ord, h_post, h_mapq, h_emit, h_mhit, h_stat;      // h_stat: the small status words a phase reads back (page-locked: one short DMA)
     std::vector<double> h_exp;          // exp(score) of every accepted hit of the last gm_map_batch (reused by gm_output_batch)
@@ -592,7 +593,7 @@ extern "C" void gm_batch_destroy(gm_batch* b) {
                       &b->tb_len, &b->band_moves, &b->pack,
                       &b->g_sorted, &b->g_ord, &b->g_lead, &b->g_krank, &b->g_khash, &b->g_nmatch, &b->g_mbegin, &b->g_multi, &b->g_big, &b->g_bigdone, &b->g_sk0, &b->g_sk1, &b->g_si0, &b->g_si1, &b->g_matches, &b->g_mhit, &b->g_positions,
                       &b->scan_tmp, &b->o_small, &b->o_posmatch, &b->o_post, &b->o_mapq, &b->o_emit, &b->o_reccnt, &b->o_cigcnt, &b->o_cigall, &b->o_recoff, &b->o_cigoff,
-                      &b->o_recs, &b->o_pool, &b->o_codes, &b->snp_scratch, &b->snp_hmm };
+                      &b->o_recs, &b->o_pool, &b->o_codes, &b->snp_scratch, &b->snp_hmm, &b->pair_fb, &b->pair_list };
     for (DevBuf* d : all) d->release();
     PinBuf* pins[] = { &b->h_top, &b->h_hbegin, &b->h_ord, &b->h_post, &b->h_mapq, &b->h_emit, &b->h_mhit, &b->h_stat };
     for (PinBuf* d : pins) d->release();
@@ -830,7 +831,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
     const uint32_t heavy_min = (uint32_t)gm_opt_ll("GM_HEAVY_MIN", 16384);
     const uint64_t heavy_budget = (uint64_t)gm_opt_ll("GM_HEAVY_BUDGET", 1ll << 27);
     dp.heavy_min = heavy_min;
-    bool use_bucket = false; uint32_t bucket_reg = 0;
+    bool use_bucket = false, use_pair = false; uint32_t bucket_reg = 0;
     // seed lookup inside the vote kernels that take one read x strand per wave / workgroup (full SA, the k-mer table covering the
     // whole seed): no k_seed launch, no seed rows through HBM.  A k-mer that does not occur changes the positions of all later ones;
     // the wave then walks again round by round (gm_seed_rewalk_ool), one probe round trip per failing k-mer.  That stays rare while
@@ -853,6 +854,9 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         use_bucket = dp.bucket && use_full && dp.kmer_tab && dp.kmer_T == dp.bucket_T && (dp.bucket_ctx ? p->mer > dp.bucket_T && p->mer - dp.bucket_T <= 5 : dp.bucket_T == p->mer) && p->min_seed_hits >= 2 && max_reg <= 32 && b->max_seeds <= 34 && !gm_opt("GM_VOTE_KERNEL") &&
                      !gm_opt("GM_VOTE") && gm_opt_ll("GM_PIPELINE", 0) == 0 && !(dp.dbg & 128) && fused_env != 0;
         if (use_bucket) { dp.fused = 1; bucket_reg = max_reg; } else dp.bucket = nullptr;
+        // ... two reads per wavefront (gm_pair.hip) where a strand has at most 16 seeds; GM_VOTE_PAIR=0: one read per wavefront always
+        use_pair = use_bucket && !dp.bucket_ctx && max_reg <= 16 && !(p->nw && p->fast) && !gm_opt_is("GM_VOTE_PAIR", "0") && !(dp.dbg & (64 | 256 | 512 | 1024 | 2048));       // (GM_DBG 4096 .. 32768: timing experiments of k_vote_pair)
+        if (use_pair && (b->pair_fb.ensure((size_t)b->n + 64) || b->pair_list.ensure(((size_t)b->n + 16) * 4))) return GM_E_NOMEM;
         b->use_pack = dp.fused != 0;
         if (b->use_pack && b->pack.ensure((size_t)b->n * gm_pack_words(b->stride) * 4 + 64)) return GM_E_NOMEM;
     }
@@ -868,9 +872,10 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         b->fixed_epoch = 0;
     }
     {
-        char buf[160];
+        char buf[224];
         snprintf(buf, sizeof buf, "seeds=%s vote=%s locate=%s", use_bucket ? (dp.bucket_ctx ? "bucket-table with context records (in the vote kernel)" : "bucket-table (in the vote kernel)") : dp.fused ? "k-mer table (in the vote kernel)" : "k_seed",
-                 use_bucket ? (bucket_reg <= 8 ? "k_vote_bucket<2>" : bucket_reg <= 16 ? "k_vote_bucket<4>" : bucket_reg <= 24 ? "k_vote_bucket<6>" : "k_vote_bucket<8>")
+                 use_pair ? (bucket_reg <= 8 ? "k_vote_pair<4> + k_vote_bucket<2>" : bucket_reg <= 14 ? "k_vote_pair<7> + k_vote_bucket<4>" : "k_vote_pair<8> + k_vote_bucket<4>")
+                 : use_bucket ? (bucket_reg <= 8 ? "k_vote_bucket<2>" : bucket_reg <= 16 ? "k_vote_bucket<4>" : bucket_reg <= 24 ? "k_vote_bucket<6>" : "k_vote_bucket<8>")
                             : dense == 0 ? "sparse" : dense == 3 ? "k_vote_block" : dense == 2 ? "k_vote_slots<64>" : slots_hint == 0 ? "k_vote_tiny" : slots_hint < 0 ? "k_vote_tiny2" : "k_vote_slots",
                  use_full ? "full-SA" : "sampled-SA");
         b->path = buf;
@@ -974,7 +979,14 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         }
         {
             KTimer t(b, GM_K_VOTE, st);
-            if (use_bucket) { KCHK(gmk_vote_bucket(ix->dev, dp, b->dev, bucket_reg, st)); KCHK(gmk_vote_list(ix->dev, dp, b->dev, use_full, st)); }
+            if (use_bucket && use_pair) {
+                // two reads per wavefront for the reads without complications; the flagged ones go through k_vote_bucket
+                HIPCHK(hipMemsetAsync(b->pair_fb.p, 0, (size_t)b->n + 16, st));
+                HIPCHK(hipMemsetAsync(b->pair_list.p, 0, 16, st));
+                KCHK(gmk_vote_pair(ix->dev, dp, b->dev, bucket_reg, b->pair_fb.as<uint8_t>(), b->pair_list.as<uint32_t>() + 4, b->pair_list.as<uint32_t>(), st));
+                KCHK(gmk_vote_bucket(ix->dev, dp, b->dev, bucket_reg, b->pair_list.as<uint32_t>() + 4, b->pair_list.as<uint32_t>(), st));
+                KCHK(gmk_vote_list(ix->dev, dp, b->dev, use_full, st));
+            } else if (use_bucket) { KCHK(gmk_vote_bucket(ix->dev, dp, b->dev, bucket_reg, nullptr, nullptr, st)); KCHK(gmk_vote_list(ix->dev, dp, b->dev, use_full, st)); }
             else KCHK(gmk_vote(ix->dev, dp, b->dev, use_full, dense, slots_hint, st));
             KCHK(gmk_cand_gather(b->dev, st));
         }

@@ -392,7 +392,7 @@ __device__ __forceinline__ uint32_t gmb_half_scan_incl(uint32_t x) {
 //            votes = popcount(tag mask), NW step = its -k-th lowest bit (inc/align_seq2_raw.cpp:262-274, process_hits :28-40).
 // A strand without a second arrival has no candidate with -k >= 2: the wrong strand of a read ends after pass 1.
 template <int STEPS, bool CTX>
-__global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucket(GmDevIndex ix, GmDevParams p, GmDevBatch b) {
+__global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucket(GmDevIndex ix, GmDevParams p, GmDevBatch b, const uint32_t* rlist, const uint32_t* n_rlist) {
     __shared__ GmBucketLds S;
     uint32_t* const s_filt = reinterpret_cast<uint32_t*>(S.filt);          // [2][GMB_FWORDS]
     uint32_t* const s_keys = reinterpret_cast<uint32_t*>(S.small);         // [2][GMB_LCAP]
@@ -416,8 +416,12 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
         n_hdr = rw[0]; n_f0 = fm_[oo >> 5]; n_f1 = fm_[(oo >> 5) + 1u];
         if (CTX) n_f2 = fm_[(oo >> 5) + 2u];           // (2 m bits from an even bit offset: up to three words)
     };
-    if (blockIdx.x < b.n) request_forms(blockIdx.x);
-    for (uint32_t r = blockIdx.x; r < b.n; r += gridDim.x) {
+    // rlist: only the reads of this list (the ones k_vote_pair, gm_pair.hip, flagged and left alone): their words are requested when their turn comes
+    const uint32_t n_items = rlist ? *n_rlist : b.n;
+    if (!rlist && blockIdx.x < n_items) request_forms(blockIdx.x);
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const uint32_t r = rlist ? rlist[item] : item;
+    if (rlist) request_forms(r);
     int lane = gmb_lane_again();
     uint32_t h = (uint32_t)lane >> 5, jj = (uint32_t)lane & 31u, g = jj >> 3, q = (uint32_t)lane & 7u;
     uint32_t rs = 2u * r + h;
@@ -434,7 +438,7 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
     const bool inrow = i_reg + m <= 16u * w2;
     const uint32_t o = inrow ? 2u * (16u * w2 - i_reg - m) : 0u;
     const uint32_t hdr_v = n_hdr, f0 = n_f0, f1 = n_f1, f2 = n_f2;
-    if (r + gridDim.x < b.n) request_forms(r + gridDim.x);
+    if (!rlist && item + gridDim.x < n_items) request_forms(item + gridDim.x);
     (void)form;
     // the LDS structures are zeroed
     {
@@ -841,22 +845,22 @@ static uint32_t gm_bucket_grid(const GmDevParams& p, uint32_t max_reg) {
 }
 
 // seeds per strand the launch has to hold: max_reg = ceil((longest read - mer) / jump)
-int gmk_vote_bucket(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint32_t max_reg, void* stream) {
+int gmk_vote_bucket(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint32_t max_reg, const uint32_t* rlist, const uint32_t* n_rlist, void* stream) {
     if (b.n == 0) return 0;
     if (max_reg > 32 || (p.bucket_ctx && (p.mer <= p.bucket_T || p.mer - p.bucket_T > GMB_NX)) || (!p.bucket_ctx && p.mer != p.bucket_T)) return (int)hipErrorInvalidValue;
     // persistent waves, each taking every grid-th read: 4 x as many one-wave workgroups as the chip holds at once (measured at 10 M reads:
     // exactly resident 10.3 ms - the dispatcher's placement is then final and uneven -, 2 x 9.7, 4 x 9.25, one read per wave 9.65)
     const dim3 grid(std::min<uint32_t>(b.n, gm_bucket_grid(p, max_reg))), blk(64);
     if (!p.bucket_ctx) {
-        if (max_reg <= 8) hipLaunchKernelGGL((k_vote_bucket<2, false>), grid, blk, 0, S_(stream), ix, p, b);
-        else if (max_reg <= 16) hipLaunchKernelGGL((k_vote_bucket<4, false>), grid, blk, 0, S_(stream), ix, p, b);
-        else if (max_reg <= 24) hipLaunchKernelGGL((k_vote_bucket<6, false>), grid, blk, 0, S_(stream), ix, p, b);
-        else hipLaunchKernelGGL((k_vote_bucket<8, false>), grid, blk, 0, S_(stream), ix, p, b);
+        if (max_reg <= 8) hipLaunchKernelGGL((k_vote_bucket<2, false>), grid, blk, 0, S_(stream), ix, p, b, rlist, n_rlist);
+        else if (max_reg <= 16) hipLaunchKernelGGL((k_vote_bucket<4, false>), grid, blk, 0, S_(stream), ix, p, b, rlist, n_rlist);
+        else if (max_reg <= 24) hipLaunchKernelGGL((k_vote_bucket<6, false>), grid, blk, 0, S_(stream), ix, p, b, rlist, n_rlist);
+        else hipLaunchKernelGGL((k_vote_bucket<8, false>), grid, blk, 0, S_(stream), ix, p, b, rlist, n_rlist);
     } else {
-        if (max_reg <= 8) hipLaunchKernelGGL((k_vote_bucket<2, true>), grid, blk, 0, S_(stream), ix, p, b);
-        else if (max_reg <= 16) hipLaunchKernelGGL((k_vote_bucket<4, true>), grid, blk, 0, S_(stream), ix, p, b);
-        else if (max_reg <= 24) hipLaunchKernelGGL((k_vote_bucket<6, true>), grid, blk, 0, S_(stream), ix, p, b);
-        else hipLaunchKernelGGL((k_vote_bucket<8, true>), grid, blk, 0, S_(stream), ix, p, b);
+        if (max_reg <= 8) hipLaunchKernelGGL((k_vote_bucket<2, true>), grid, blk, 0, S_(stream), ix, p, b, rlist, n_rlist);
+        else if (max_reg <= 16) hipLaunchKernelGGL((k_vote_bucket<4, true>), grid, blk, 0, S_(stream), ix, p, b, rlist, n_rlist);
+        else if (max_reg <= 24) hipLaunchKernelGGL((k_vote_bucket<6, true>), grid, blk, 0, S_(stream), ix, p, b, rlist, n_rlist);
+        else hipLaunchKernelGGL((k_vote_bucket<8, true>), grid, blk, 0, S_(stream), ix, p, b, rlist, n_rlist);
     }
     return (int)hipGetLastError();
 }

@@ -177,7 +177,10 @@ int gmk_cand_gather(const GmDevBatch& b, void* stream);
 int gmk_shard_stats(const GmDevBatch& b, uint32_t* out /* {total, max} in device memory */, void* stream);
 // gm_bucket.hip: the bucket table and the one-wave-per-read vote kernel that looks its seeds up in it
 int gmk_build_bucket(const uint2* tab, const uint32_t* full_sa, const uint8_t* pac, uint4* bucket, int T, int ctx, void* stream);
-int gmk_vote_bucket(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint32_t max_reg, void* stream);
+// rlist / n_rlist (device memory) != null: only the reads of that list
+int gmk_vote_bucket(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint32_t max_reg, const uint32_t* rlist, const uint32_t* n_rlist, void* stream);
+// gm_pair.hip: two reads per wavefront for the common case; the reads it flags (fallback[r] = 1) are listed for gmk_vote_bucket
+int gmk_vote_pair(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint32_t max_reg, uint8_t* fallback, uint32_t* list, uint32_t* n_list, void* stream);
 int gmk_vote_list(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, int use_full_sa, void* stream);     // k_vote_fast_list over b.big_list
 // gm_heavy.hip: read x strands with more than heavy_min SA hits (sorted-key vote path)
 int gmk_heavy_collect(const GmDevBatch& b, uint32_t heavy_min, uint32_t* n_heavy, uint32_t* heavy_list /* {rs, n_seeds, SA hits} triples */, int sum_counters, void* stream);
