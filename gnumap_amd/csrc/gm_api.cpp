@@ -317,17 +317,7 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
         // ONE random 16-byte probe instead of a probe + two search steps
         int T = std::min(p->mer, ix->h.seq_len >= 50000000ull ? 16 : 12);
         if (const char* e = gm_opt("GM_KMER_TABLE")) { if (*e) T = std::min(std::min(atoi(e), p->mer), 16); }
-        // seeds longer than a direct-addressed table of whole seeds can be (-m 16 .. 20 at human scale): the bucket table of their last
-        // GM_BUCKET_T=<t> characters with context records (gm_bucket.hip) - the k-mer table is then the one of that length.  Opt-in:
-        // correct, but a 20-mer of the read's WRONG strand does not occur anywhere, so that strand fails at every regular position and all of
-        // its ~80 positions have to be asked about (a record cannot say after how many characters a k-mer dies, so nothing is skipped): one read
-        // per wavefront does that 3.5 x slower than k_seed's one read x strand per lane (84 against 23 ms per 10 M reads).
         const long long bucket_opt = gm_opt_ll("GM_SEED_BUCKET", -1);
-        int ctx_T = 0;
-        if (want_bucket && bucket_opt != 0 && ix->full_sa && ix->h.seq_len < 0xFFFFE000ull && !gm_opt("GM_KMER_TABLE")) {
-            const int t = (int)gm_opt_ll("GM_BUCKET_T", 0);
-            if (t >= 4 && t <= 15 && t < p->mer && p->mer - t <= 5) { ctx_T = t; T = t; }
-        }
         if (T >= 4) {
             std::lock_guard<std::mutex> lk(ix->mu);
             // the 15- / 16-character tables are bought with free HBM: step down while table + previous level + compact form (+ 8 GB
@@ -377,10 +367,9 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
             // and 128 bytes per code have to fit beside everything else: -m 14 = 34 GB of the 288.  GM_SEED_BUCKET=0 / 1: never /
             // whenever the table can be built.
             const double occ = (double)ix->h.seq_len / pow(4.0, (double)std::min(p->mer, 31));
-            const bool ctx = ctx_T != 0 && T == ctx_T;      // (T may have been stepped down for lack of memory: then no bucket table)
             if (want_bucket && bucket_opt != 0 && ix->full_sa && T <= 15 && ix->h.seq_len < 0xFFFFE000ull &&
-                (ctx || (ctx_T == 0 && T == p->mer && (bucket_opt > 0 || (occ >= 1.0 && occ <= 20.0))))) {
-                auto it = ix->buckets.find(T + (ctx ? 100 : 0));
+                T == p->mer && (bucket_opt > 0 || (occ >= 1.0 && occ <= 20.0))) {
+                auto it = ix->buckets.find(T);
                 if (it == ix->buckets.end()) {
                     DevBuf bb;
                     const size_t need = (((size_t)1 << (2 * T)) + 1) * 128;            // + the all-zero record behind the last code
@@ -388,18 +377,18 @@ static int sync_params(gm_index* ix, const gm_params* p, GmDevParams& dp, hipStr
                     if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr >= need + ((size_t)24 << 30) && bb.ensure(need) == GM_OK) {
                         const auto t0 = std::chrono::steady_clock::now();
                         // a failed build: the memory goes back and the empty entry is recorded, so that it is neither leaked nor tried again on every call
-                        if (gmk_build_bucket(tb.as<uint2>(), ix->d_full.as<uint32_t>(), ix->dev.pac, bb.as<uint4>(), T, ctx ? 1 : 0, st) != 0 || hipStreamSynchronize(st) != hipSuccess) {
+                        if (gmk_build_bucket(tb.as<uint2>(), ix->d_full.as<uint32_t>(), ix->dev.pac, bb.as<uint4>(), T, 0, st) != 0 || hipStreamSynchronize(st) != hipSuccess) {
                             bb.release();
-                            ix->buckets.emplace(T + (ctx ? 100 : 0), DevBuf());
+                            ix->buckets.emplace(T, DevBuf());
                             gm_set_error("k-mer -> positions table construction failed");
                             return GM_E_HIP;
                         }
                         ix->hbm_bytes += bb.cap;
-                        GM_TRACE("bucket table: %d-mers%s, %.1f GB, built in %.0f ms", T, ctx ? " + context" : "", need / 1e9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+                        GM_TRACE("bucket table: %d-mers%s, %.1f GB, built in %.0f ms", T, "", need / 1e9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
                     }
-                    it = ix->buckets.emplace(T + (ctx ? 100 : 0), bb).first;     // an empty entry = does not fit: not tried again
+                    it = ix->buckets.emplace(T, bb).first;     // an empty entry = does not fit: not tried again
                 }
-                dp.bucket = it->second.as<uint4>(); dp.bucket_T = T; dp.bucket_ctx = ctx ? 1 : 0;
+                dp.bucket = it->second.as<uint4>(); dp.bucket_T = T; dp.bucket_ctx = 0;
             }
         }
     }
@@ -851,7 +840,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
         // every seed is ONE random line
         const uint32_t lastmax = b->len_max > (uint32_t)p->mer ? b->len_max - (uint32_t)p->mer : 0;      // (the longest read of the block, not the row stride)
         const uint32_t max_reg = (lastmax + (uint32_t)p->jump - 1) / (uint32_t)p->jump;
-        use_bucket = dp.bucket && use_full && dp.kmer_tab && dp.kmer_T == dp.bucket_T && (dp.bucket_ctx ? p->mer > dp.bucket_T && p->mer - dp.bucket_T <= 5 : dp.bucket_T == p->mer) && p->min_seed_hits >= 2 && max_reg <= 32 && b->max_seeds <= 34 && !gm_opt("GM_VOTE_KERNEL") &&
+        use_bucket = dp.bucket && use_full && dp.kmer_tab && dp.kmer_T == dp.bucket_T && dp.bucket_T == p->mer && p->min_seed_hits >= 2 && max_reg <= 32 && b->max_seeds <= 34 && !gm_opt("GM_VOTE_KERNEL") &&
                      !gm_opt("GM_VOTE") && gm_opt_ll("GM_PIPELINE", 0) == 0 && !(dp.dbg & 128) && fused_env != 0;
         if (use_bucket) { dp.fused = 1; bucket_reg = max_reg; } else dp.bucket = nullptr;
         // ... two reads per wavefront (gm_pair.hip) where a strand has at most 16 seeds; GM_VOTE_PAIR=0: one read per wavefront always
@@ -873,7 +862,7 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
     }
     {
         char buf[224];
-        snprintf(buf, sizeof buf, "seeds=%s vote=%s locate=%s", use_bucket ? (dp.bucket_ctx ? "bucket-table with context records (in the vote kernel)" : "bucket-table (in the vote kernel)") : dp.fused ? "k-mer table (in the vote kernel)" : "k_seed",
+        snprintf(buf, sizeof buf, "seeds=%s vote=%s locate=%s", use_bucket ? "bucket-table (in the vote kernel)" : dp.fused ? "k-mer table (in the vote kernel)" : "k_seed",
                  use_pair ? (bucket_reg <= 8 ? "k_vote_pair<4> + k_vote_bucket<2>" : bucket_reg <= 14 ? "k_vote_pair<7> + k_vote_bucket<4>" : "k_vote_pair<8> + k_vote_bucket<4>")
                  : use_bucket ? (bucket_reg <= 8 ? "k_vote_bucket<2>" : bucket_reg <= 16 ? "k_vote_bucket<4>" : bucket_reg <= 24 ? "k_vote_bucket<6>" : "k_vote_bucket<8>")
                             : dense == 0 ? "sparse" : dense == 3 ? "k_vote_block" : dense == 2 ? "k_vote_slots<64>" : slots_hint == 0 ? "k_vote_tiny" : slots_hint < 0 ? "k_vote_tiny2" : "k_vote_slots",

@@ -18,21 +18,14 @@
 // strands that do not fit (too many hits, a record with an early position, a non-ACGT base) get their seed rows written and go to
 // the list / heavy kernels exactly as from k_vote_tiny.
 //
-// Seeds LONGER than the table's k-mers (-m 16 .. 20 on a 3.1 Gbp reference, where a table of the whole seed would have 4^20 codes):
-// "context records" (k_build_bucket_ctx).  The table is addressed with the LAST 15 characters of the seed; a record holds up to 21
-// positions of that 15-mer and, beside each, the 5 reference characters in front of it.  The hits of the seed are the positions whose
-// context equals the seed's first mer - 15 characters: still one line and one round trip per seed, no backward-search steps (k_seed
-// spends mer - 16 dependent occ probes per seed after its table lookup).  A 15-mer with more than 21 positions keeps its SA interval
-// in the record; the lane that holds the seed's header extends it by the context characters (gmb_extend) and the hits come from the
-// suffix array like those of any seed beyond the record's capacity.
+// (Round 3's "context records" - the table of the seed's last 15 characters with the 5 reference characters in front of every position,
+// for -m 16 .. 20 - were correct and 3.5 x slower than k_seed on reads with 1 % errors; removed in round 4, DESIGN.md has the numbers.)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include "gm_internal.h"
 #include "gm_device.h"
 
 #define GMB_C 28                         // positions per record
-#define GMB_CX 21                        // ... per context record
-#define GMB_NX 5                         // context characters kept per position: seeds of up to 15 + 5 characters
 #define GMB_EARLY 4096u                  // a record with a position below this may vote for the clamped window start b = 0 (:267): list kernel
 #define GMB_LCAP 32                      // second-or-later arrivals in a filter slot per strand (the keys of the sweeps)
 #define GMB_ECAP 384                     // SA hits per strand voted on here; more -> the list kernel
@@ -81,50 +74,6 @@ __global__ void __launch_bounds__(256) k_build_bucket(const uint2* __restrict__ 
     }
 }
 
-// Context records: the table of T-mers for seeds of T + nx characters, nx = 1 .. GMB_NX.
-//   lane 0       { header, first SA rank of the T-mer, its hit count, 0 }
-//   lane q = 1..7, register j = 0..2: text position p = 7 j + q - 1 of the T-mer's SA interval, stored + 1; 0 = none
-//                register 3: the contexts of the lane's three positions, 10 bits each (bits 10 j ..): the GMB_NX reference characters
-//                in front of the position, the nearest one in the lowest two bits (the order a k-mer code has: last character lowest)
-// header as above with a capacity of 21.  A T-mer with a position in the first GMB_NX characters of the text (no full context) is
-// stored as "more hits than fit": its seeds are then counted by backward search, which knows where the text begins.
-__global__ void __launch_bounds__(256) k_build_bucket_ctx(const uint2* __restrict__ tab, const uint32_t* __restrict__ full_sa, const uint8_t* __restrict__ pac,
-                                                          uint4* __restrict__ bucket, unsigned long long n_codes) {
-    for (unsigned long long t = (unsigned long long)blockIdx.x * 256 + threadIdx.x; t < (n_codes + 1ull) * 8ull; t += (unsigned long long)gridDim.x * 256) {
-        const unsigned long long code = t >> 3;
-        const uint32_t q = (uint32_t)t & 7u;
-        if (code == n_codes) { bucket[t] = make_uint4(0u, 0u, 0u, 0u); continue; }
-        const uint2 iv = tab[code];
-        const bool empty = iv.x == 0xFFFFFFFFu;
-        const uint32_t cnt = empty ? 0u : iv.y - iv.x + 1u;
-        bool early = false, head = false;
-        if (!empty) {
-            if (cnt <= 4096u) { for (uint32_t i = 0; i < cnt; ++i) { const uint32_t v = full_sa[iv.x + i]; early |= v < GMB_EARLY; head |= v < GMB_NX; } }
-            else early = true;
-        }
-        const bool inl = !empty && cnt <= GMB_CX && !head;
-        uint32_t w[4] = { 0u, 0u, 0u, 0u };
-        if (inl && q != 0u) {
-#pragma unroll
-            for (uint32_t j = 0; j < 3; ++j) {
-                const uint32_t pi = 7u * j + q - 1u;
-                if (pi < cnt) {
-                    const uint32_t pos = full_sa[iv.x + pi];
-                    uint32_t cx = 0;
-                    for (uint32_t c = 1; c <= GMB_NX; ++c) { const uint32_t x = pos - c; cx |= ((uint32_t)(pac[x >> 2] >> ((~x & 3u) << 1)) & 3u) << (2u * (c - 1u)); }
-                    w[j] = pos + 1u;
-                    w[3] |= cx << (10u * j);
-                }
-            }
-        }
-        if (q == 0u) {
-            w[0] = empty ? (0x40000000u | iv.y) : ((inl ? cnt : 0x80000000u) | (early ? 0x20000000u : 0u));
-            if (!empty) { w[1] = iv.x; w[2] = cnt; }
-        }
-        bucket[t] = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-}
-
 // ---- per-wave LDS -------------------------------------------------------------------------------------------------------------------
 struct GmBucketLds {
     uint4 filt[2 * GMB_FWORDS / 4];                              // filter [2][512 words]: 4 x 16 bytes per lane, zeroed by every wave
@@ -148,79 +97,39 @@ __device__ __forceinline__ uint32_t gmb_code_at(const uint32_t* form, uint32_t w
     return (uint32_t)((((unsigned long long)form[(o >> 5) + 1u] << 32) | form[o >> 5]) >> (o & 31u)) & cmask;
 }
 
-// the same for seeds of up to 20 characters: 2 m bits, of which the low 2 T are the table code and the rest the seed's context
-__device__ __forceinline__ unsigned long long gmb_window_at(const uint32_t* form, uint32_t w2, uint32_t m, uint32_t i) {
-    const uint32_t o = 2u * (16u * w2 - i - m), s = o & 31u;
-    unsigned long long v = (((unsigned long long)form[(o >> 5) + 1u] << 32) | form[o >> 5]) >> s;
-    if (s) v |= (unsigned long long)form[(o >> 5) + 2u] << (64u - s);          // (a word of the row or of its padding: bits beyond the read are masked off)
-    return v & ((1ull << (2u * m)) - 1ull);
-}
-
-// Backward search of nx more characters in front of a k-mer with SA interval [k, l] (bwt_match_exact src/bwt.c:183-200, the steps
-// after the table's): cx holds them, the nearest in its lowest two bits.  False: the longer k-mer does not occur.  (ix: the index
-// struct IN MEMORY - gm_kargs()->ix from a kernel: L2[c] with a per-lane c is then a load, not a copy of the by-value argument to scratch)
-__device__ __forceinline__ bool gmb_extend(const GmDevIndex& ix, uint32_t& k, uint32_t& l, const uint32_t cx, const uint32_t nx) {
-    for (uint32_t t = 0; t < nx; ++t) {
-        const uint32_t c = (cx >> (2u * t)) & 3u;
-        const uint32_t ok_ = gm_occ_plane(ix, k - 1u, c), ol_ = gm_occ_plane(ix, l, c);
-        k = gm_L2(ix, c) + ok_ + 1u;
-        l = gm_L2(ix, c) + ol_;
-        if (k > l) return false;
-    }
-    return true;
-}
-
 // The walk of the halves (strands) whose seeds do not all succeed; all 64 lanes call it, `need` = this lane's half walks.
 // Seeds p_0 = first position >= 0 whose k-mer occurs (and stays within -h), p_{n+1} = first such position >= p_n + jump
 // (inc/align_seq2_raw.cpp:200-231).  Which positions a seed lands on depends on every k-mer before it, but WHETHER a position can be a
 // seed does not: the half keeps two bit sets over the positions of the read, "asked" and "can be a seed" (in scr; they live from the
 // kernel's first call to its last), adds what the kernel has just learnt (ginfo: the positions of the records it fetched), walks over
 // them by bit arithmetic until it needs a position nobody asked about, asks about a SET of positions in one round trip, and walks on.
-// Which set:
-//   whole-seed records   every position from there to the end of the read not asked yet (a strand fails here because it lies in a
-//                        repeat - capped k-mers, position after position: one round trip, however many)
-//   context records      long seeds fail because of a sequencing error (a 20-mer with an error does not occur): the slide (:213-226)
-//                        ends right behind the error, at most 2 jump - 1 positions on, so those are asked (up to the first position
-//                        known to be good).  Behind it the walk is regular again: unless this is the last call (`final`), the
-//                        positions p + jump, p + 2 jump .. are ASSUMED good and handed to the kernel as seeds - it fetches their
-//                        records anyway, and comes back with the answers only if one of them fails (a second error).  A slide that
-//                        finds nothing in its window (the read's wrong strand: no 20-mer of it occurs), and the last call: everything
-//                        still open.
-// A position of a context-record table is asked about by 8 lanes (the record, one 16-byte load each; the matches of the seed's
-// context are counted with a ballot); a record that holds its k-mer's SA interval instead of positions goes to a list, and the
-// intervals of the list are extended by the context characters one lane each.
-// Codes, contexts and offsets of the seeds go to s_seed; returns the half's seed count (0 for a half that did not
+// Which set: every position from there to the end of the read not asked yet (a strand fails here because it lies in a repeat - capped
+// k-mers, position after position: one round trip, however many).
+// Codes and offsets of the seeds go to s_seed; returns the half's seed count (0 for a half that did not
 // walk).  scr: 4 KB of LDS.
 #define GMB_PL 96                        // positions asked about per half and round
 #define GMB_SCR_FAILED 930               // word of the scratch that holds the half's dropped k-mers
-template <bool CTX>
 static __device__ __attribute__((noinline)) uint32_t gm_bucket_rewalk(const GmKArgs* a, const uint32_t r, const int lane, const bool need, const uint32_t ginfo,
                                                                       const bool first, const bool final, uint2* s_seed /* [2][GMB_MAXS] */, uint32_t* scr /* [1024] */) {
-    const GmDevIndex& ix = a->ix;
     const GmDevParams& p = a->p;
     const GmDevBatch& b = a->b;
     const uint32_t m = (uint32_t)p.mer, jump = (uint32_t)p.jump, w2 = b.pack_w2;
-    const uint32_t TB = CTX ? (uint32_t)p.bucket_T : m, nx = m - TB;
-    const uint32_t h = (uint32_t)lane >> 5, jj = (uint32_t)lane & 31u, g = jj >> 3, q = (uint32_t)lane & 7u;
+    const uint32_t TB = m;
+    const uint32_t h = (uint32_t)lane >> 5, jj = (uint32_t)lane & 31u;
     const uint32_t* const row = b.pack + (size_t)r * b.pack_words;
     const uint32_t* const form = row + (h ? w2 + 2u : 1u);
     const uint32_t L = row[0] & 0xFFFFu, last = L - m;
-    const uint32_t cmask = TB >= 16u ? 0xFFFFFFFFu : ((1u << (2u * TB)) - 1u), cxm = (1u << (2u * nx)) - 1u;
+    const uint32_t cmask = TB >= 16u ? 0xFFFFFFFFu : ((1u << (2u * TB)) - 1u);
     const uint32_t zero_code = cmask + 1u;
     const uint4* const bucket = reinterpret_cast<const uint4*>(p.bucket);
     uint32_t* const s_ok = scr + h * 64u;              // [2][64]: one bit per position
     uint32_t* const s_seen = scr + 128u + h * 64u;     // [2][64]
     uint16_t* const s_list = reinterpret_cast<uint16_t*>(scr + 256u) + h * GMB_PL;     // [2][GMB_PL] positions asked about in this round
-    uint16_t* const s_ovp = reinterpret_cast<uint16_t*>(scr + 352u) + h * GMB_PL;      // [2][GMB_PL] ... of them, those whose record holds an interval: position,
-    uint16_t* const s_ovc = reinterpret_cast<uint16_t*>(scr + 448u) + h * GMB_PL;      //             context,
-    uint32_t* const s_ovk = scr + 544u + h * GMB_PL;                                      //             first SA rank,
-    uint32_t* const s_ovn = scr + 736u + h * GMB_PL;                                      //             count
-    uint32_t* const s_cnt = scr + 928u + h;                                               // [2] entries of that list
     uint32_t* const s_failed = scr + GMB_SCR_FAILED + h;                                  // [2] k-mers tried and dropped on the way (for the work counters)
     static_assert(GMB_SCR_FAILED + 2 <= 1024 && 2 * GMB_PL * 2 <= 96 * 4, "rewalk scratch fits the 4 KB it is given");
     if (first) {
         for (uint32_t w = jj; w < 64u; w += 32u) { s_ok[w] = 0u; s_seen[w] = 0u; }
-        if (jj == 0u) { *s_cnt = 0u; *s_failed = 0u; }
+        if (jj == 0u) *s_failed = 0u;
         __syncthreads();
     }
     auto answer = [&](const uint32_t pos, const bool ok) {
@@ -229,8 +138,7 @@ static __device__ __attribute__((noinline)) uint32_t gm_bucket_rewalk(const GmKA
     };
     if (ginfo & 1u) answer(ginfo >> 2, (ginfo & 2u) != 0u);
     __syncthreads();
-    uint32_t cur = 0, ns = 0, failed = 0, mypos = 0, tries = 0;
-    bool slid = false;
+    uint32_t cur = 0, ns = 0, failed = 0, mypos = 0;
     for (;;) {
         // the walk over what is known (the same in every lane of a half); lane n keeps seed n.  One step = one seed: the k-mers the
         // reference tries and drops in front of it (asked, cannot be seeds) are jumped over 32 positions at a time
@@ -242,26 +150,15 @@ static __device__ __attribute__((noinline)) uint32_t gm_bucket_rewalk(const GmKA
             uint32_t d = stop ? (uint32_t)__builtin_ctz(stop) : 32u;
             if (cur + d > last) d = last - cur;
             failed += d; cur += d;
-            if (d != 0u) slid = true;
             if (stop == 0u || cur >= last) continue;
-            if (!((sn >> d) & 1u) && !(CTX && !final && !slid)) break;           // not asked, and not a regular step behind a seed that may be assumed good
+            if (!((sn >> d) & 1u)) break;                                         // not asked yet
             if (jj == ns) mypos = cur;
-            ++ns; cur += jump; slid = false;
+            ++ns; cur += jump;
         }
         const bool more = need && cur < last && ns < GMB_MAXS;
         if (__builtin_amdgcn_ballot_w64(more) == 0ull) break;
         // the positions to ask about: cur, cur + stride, .. below hi, those not asked yet, at most GMB_PL
-        uint32_t stride = 1u, hi = last;
-        if (CTX && tries == 0u && slid) {
-            // up to the first position known to be good, at most 2 jump - 1 on (an error inside the first failing seed lies in its
-            // second half - the seed before it would hold it otherwise - and the first k-mer without it starts right behind it)
-            const uint32_t w = cur >> 5, sh = cur & 31u;
-            const unsigned long long okw = ((((unsigned long long)s_ok[(w + 1u) & 63u]) << 32) | s_ok[w]) >> sh;
-            uint32_t d = okw ? (uint32_t)__builtin_ctzll(okw) : 64u;
-            if (d > 2u * jump - 1u) d = 2u * jump - 1u;
-            hi = cur + d < last ? cur + d : last;
-            if (hi <= cur) hi = cur + 1u;
-        } else if (CTX && tries <= 1u && !slid) stride = jump;
+        const uint32_t stride = 1u, hi = last;
         uint32_t nl = 0;
         for (uint32_t t = 0; __builtin_amdgcn_ballot_w64(more && cur + 32u * t * stride < hi && nl < GMB_PL) != 0ull; ++t) {
             const uint32_t pos = cur + (32u * t + jj) * stride;
@@ -272,80 +169,29 @@ static __device__ __attribute__((noinline)) uint32_t gm_bucket_rewalk(const GmKA
             nl += (uint32_t)__popc(gmb_half_bits(wm, h));
         }
         if (nl > GMB_PL) nl = GMB_PL;
-        if (more) ++tries;
         __syncthreads();
-        if (CTX) {
-            const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)nl, 0), n1 = (uint32_t)__builtin_amdgcn_readlane((int)nl, 32);
-            const uint32_t nmax = n0 > n1 ? n0 : n1;
-            for (uint32_t t0 = 0; 4u * t0 < nmax; t0 += 4u) {                     // 4 positions per half and step, 8 lanes each; 4 steps in flight
-                uint4 rec[4];
-                uint32_t pos[4], cx[4];
-                bool act[4];
+        for (uint32_t t0 = 0; __builtin_amdgcn_ballot_w64(32u * t0 < nl) != 0ull; t0 += 4u) {      // one lane per position: lane 0's part of the record says it all
+            uint4 rec[4];
+            uint32_t pos[4];
+            bool act[4];
 #pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) {
-                    const uint32_t idx = 4u * (t0 + u) + g;
-                    act[u] = idx < nl;
-                    pos[u] = 0; cx[u] = 0; rec[u] = make_uint4(0u, 0u, 0u, 0u);
-                    if (4u * (t0 + u) >= nmax) continue;                             // (wave-uniform) a step nobody has a position for
-                    pos[u] = act[u] ? s_list[idx] : 0u;
-                    uint32_t key = zero_code;
-                    if (act[u]) { const unsigned long long v = gmb_window_at(form, w2, m, pos[u]); key = (uint32_t)v & cmask; cx[u] = (uint32_t)(v >> (2u * TB)) & cxm; }
-                    rec[u] = bucket[(size_t)key * 8u + q];
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) {
-                    if (__builtin_amdgcn_ballot_w64(act[u]) == 0ull) continue;
-                    const bool dl = act[u] && q != 0u;
-                    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(dl && rec[u].x != 0u && (rec[u].w & cxm) == cx[u]);
-                    const unsigned long long m1 = __builtin_amdgcn_ballot_w64(dl && rec[u].y != 0u && ((rec[u].w >> 10) & cxm) == cx[u]);
-                    const unsigned long long m2 = __builtin_amdgcn_ballot_w64(dl && rec[u].z != 0u && ((rec[u].w >> 20) & cxm) == cx[u]);
-                    const uint32_t cnt = (uint32_t)__popc(__builtin_amdgcn_ubfe(gmb_half_bits(m0, h), 8u * g, 8u)) + (uint32_t)__popc(__builtin_amdgcn_ubfe(gmb_half_bits(m1, h), 8u * g, 8u)) +
-                                         (uint32_t)__popc(__builtin_amdgcn_ubfe(gmb_half_bits(m2, h), 8u * g, 8u));
-                    if (act[u] && q == 0u) {
-                        if (rec[u].x & 0x80000000u) {  // the k-mer's SA interval instead of positions: extended below
-                            const uint32_t at = atomicAdd(s_cnt, 1u);
-                            s_ovp[at] = (uint16_t)pos[u]; s_ovc[at] = (uint16_t)cx[u]; s_ovk[at] = rec[u].y; s_ovn[at] = rec[u].z;
-                        } else answer(pos[u], !(rec[u].x & 0x40000000u) && cnt != 0u && !(p.hcap > 0 && cnt > p.hcap));
-                    }
-                }
+            for (uint32_t u = 0; u < 4u; ++u) {
+                const uint32_t idx = 32u * (t0 + u) + jj;
+                act[u] = idx < nl;
+                pos[u] = act[u] ? s_list[idx] : 0u;
+                rec[u] = bucket[(size_t)(act[u] ? gmb_code_at(form, w2, m, pos[u], cmask) : zero_code) * 8u];
             }
-            __syncthreads();
-            const uint32_t no = *s_cnt;
-            for (uint32_t t = 0; __builtin_amdgcn_ballot_w64(32u * t < no) != 0ull; ++t) {
-                const uint32_t idx = 32u * t + jj;
-                if (idx < no) {
-                    uint32_t k = s_ovk[idx], l = k + s_ovn[idx] - 1u;
-                    const bool okx = gmb_extend(ix, k, l, s_ovc[idx], nx);
-                    answer(s_ovp[idx], okx && !(p.hcap > 0 && l - k + 1u > p.hcap));
-                }
-            }
-            __syncthreads();
-            if (jj == 0u) *s_cnt = 0u;
-        } else {
-            for (uint32_t t0 = 0; __builtin_amdgcn_ballot_w64(32u * t0 < nl) != 0ull; t0 += 4u) {      // one lane per position: lane 0's part of the record says it all
-                uint4 rec[4];
-                uint32_t pos[4];
-                bool act[4];
 #pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) {
-                    const uint32_t idx = 32u * (t0 + u) + jj;
-                    act[u] = idx < nl;
-                    pos[u] = act[u] ? s_list[idx] : 0u;
-                    rec[u] = bucket[(size_t)(act[u] ? gmb_code_at(form, w2, m, pos[u], cmask) : zero_code) * 8u];
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) {
-                    const uint32_t cnt = (rec[u].x & 0x80000000u) ? rec[u].z : (rec[u].x & 0xFFFFu);
-                    if (act[u]) answer(pos[u], !(rec[u].x & 0x40000000u) && !(p.hcap > 0 && cnt > p.hcap));
-                }
+            for (uint32_t u = 0; u < 4u; ++u) {
+                const uint32_t cnt = (rec[u].x & 0x80000000u) ? rec[u].z : (rec[u].x & 0xFFFFu);
+                if (act[u]) answer(pos[u], !(rec[u].x & 0x40000000u) && !(p.hcap > 0 && cnt > p.hcap));
             }
         }
         __syncthreads();
     }
     // the seeds' codes
     if (need && jj < ns) {
-        if (CTX) { const unsigned long long v = gmb_window_at(form, w2, m, mypos); s_seed[h * GMB_MAXS + jj] = make_uint2((uint32_t)v & cmask, mypos | (((uint32_t)(v >> (2u * TB)) & cxm) << 16)); }
-        else s_seed[h * GMB_MAXS + jj] = make_uint2(gmb_code_at(form, w2, m, mypos, cmask), mypos);
+        s_seed[h * GMB_MAXS + jj] = make_uint2(gmb_code_at(form, w2, m, mypos, cmask), mypos);
     }
     if (need && jj == 0u) *s_failed = failed;
     __syncthreads();
@@ -391,22 +237,22 @@ __device__ __forceinline__ uint32_t gmb_half_scan_incl(uint32_t x) {
 //            the clamped b = 0 never occurs here - records with an early position go to the list kernel), so
 //            votes = popcount(tag mask), NW step = its -k-th lowest bit (inc/align_seq2_raw.cpp:262-274, process_hits :28-40).
 // A strand without a second arrival has no candidate with -k >= 2: the wrong strand of a read ends after pass 1.
-template <int STEPS, bool CTX>
-__global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucket(GmDevIndex ix, GmDevParams p, GmDevBatch b, const uint32_t* rlist, const uint32_t* n_rlist) {
+template <int STEPS>
+__global__ void __launch_bounds__(64, STEPS <= 6 ? 8 : 6) k_vote_bucket(GmDevIndex ix, GmDevParams p, GmDevBatch b, const uint32_t* rlist, const uint32_t* n_rlist) {
     __shared__ GmBucketLds S;
     uint32_t* const s_filt = reinterpret_cast<uint32_t*>(S.filt);          // [2][GMB_FWORDS]
     uint32_t* const s_keys = reinterpret_cast<uint32_t*>(S.small);         // [2][GMB_LCAP]
     uint32_t* const s_tagm = s_keys + 2 * GMB_LCAP;                          // [2]
     const uint32_t m = (uint32_t)p.mer, jump = (uint32_t)p.jump, w2 = b.pack_w2;
-    const uint32_t TB = CTX ? (uint32_t)p.bucket_T : m, nx = m - TB;      // the table's k-mer = the last TB characters of the seed; nx in front of it
-    const uint32_t cmask = TB >= 16u ? 0xFFFFFFFFu : ((1u << (2u * TB)) - 1u), cxm = (1u << (2u * nx)) - 1u;
+    const uint32_t TB = m;
+    const uint32_t cmask = TB >= 16u ? 0xFFFFFFFFu : ((1u << (2u * TB)) - 1u);
     const uint32_t zero_code = cmask + 1u;             // the all-zero record behind the table (TB <= 15)
     const uint4* const bucket = reinterpret_cast<const uint4*>(p.bucket);
     // PERSISTENT waves: a wave takes reads blockIdx.x, blockIdx.x + gridDim.x, ..  What that buys: the header + form words of the NEXT
     // read are requested at the top of an iteration and have a whole read's work to arrive (the first of the read's two dependent HBM
     // trips disappears from the wave's lifetime), and the candidate stores of a read are not waited for - the wave goes on with the
     // next read instead of holding its slot until they are acknowledged.
-    uint32_t n_hdr = 0, n_f0 = 0, n_f1 = 0, n_f2 = 0;
+    uint32_t n_hdr = 0, n_f0 = 0, n_f1 = 0;
     auto request_forms = [&](const uint32_t rr) {      // (the lane's word offsets are computed again each time: nothing per-lane lives across an iteration but these four words)
         const int ln = gmb_lane_again();
         const uint32_t hh = (uint32_t)ln >> 5, ireg = ((uint32_t)ln & 31u) * jump;
@@ -414,7 +260,6 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
         const uint32_t* const rw = b.pack + (size_t)rr * b.pack_words;
         const uint32_t* const fm_ = rw + (hh ? w2 + 2u : 1u);
         n_hdr = rw[0]; n_f0 = fm_[oo >> 5]; n_f1 = fm_[(oo >> 5) + 1u];
-        if (CTX) n_f2 = fm_[(oo >> 5) + 2u];           // (2 m bits from an even bit offset: up to three words)
     };
     // rlist: only the reads of this list (the ones k_vote_pair, gm_pair.hip, flagged and left alone): their words are requested when their turn comes
     const uint32_t n_items = rlist ? *n_rlist : b.n;
@@ -437,7 +282,7 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
     const uint32_t i_reg = jj * jump;
     const bool inrow = i_reg + m <= 16u * w2;
     const uint32_t o = inrow ? 2u * (16u * w2 - i_reg - m) : 0u;
-    const uint32_t hdr_v = n_hdr, f0 = n_f0, f1 = n_f1, f2 = n_f2;
+    const uint32_t hdr_v = n_hdr, f0 = n_f0, f1 = n_f1;
     if (!rlist && item + gridDim.x < n_items) request_forms(item + gridDim.x);
     (void)form;
     // the LDS structures are zeroed
@@ -459,10 +304,9 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
     uint32_t ns_h;                                    // seeds of this lane's half
     bool listed = false;                              // the half's seed row is in HBM (serial walk of a read with a non-ACGT base)
     uint32_t cd[STEPS], of1[STEPS];                   // code and read offset + 1 (of the table's k-mer) of the seed whose record this lane's group fetches in step st
-    uint32_t cx[STEPS];                               // (context records) ... the seed's characters in front of the table's k-mer
     uint4 rc[STEPS];
     uint4 hd4 = make_uint4(0u, 0u, 0u, 0u);           // lanes q < STEPS: lane 0's part of the record of seed 4 q + g {header, first SA rank, count, -}
-    uint32_t hcode = 0, hof1 = 0, hctx = 0;           // ... its code, read offset + 1 and context
+    uint32_t hcode = 0, hof1 = 0;                     // ... its code and read offset + 1
     if ((hdr >> 16) & 1u) {
         // a base that is not ACGT: the 2-bit forms cannot say where.  Lane 0 walks each strand like k_seed does, into the read x
         // strand's row in HBM, and the list kernel votes.
@@ -480,13 +324,11 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
         if (ns_h > 32u) ns_h = 32u;
         listed = true;
 #pragma unroll
-        for (int st = 0; st < STEPS; ++st) { cd[st] = 0; cx[st] = 0; of1[st] = 0; rc[st] = make_uint4(0u, 0u, 0u, 0u); }
+        for (int st = 0; st < STEPS; ++st) { cd[st] = 0; of1[st] = 0; rc[st] = make_uint4(0u, 0u, 0u, 0u); }
     } else {
         const bool act = strand_on && i_reg < last;
         unsigned long long win = (((unsigned long long)f1 << 32) | f0) >> (o & 31u);
-        if (CTX && (o & 31u)) win |= (unsigned long long)f2 << (64u - (o & 31u));
         const uint32_t code = act ? (uint32_t)win & cmask : 0u;
-        const uint32_t ctx = (CTX && act) ? (uint32_t)(win >> (2u * TB)) & cxm : 0u;
         ns_h = strand_on ? (last + jump - 1u) / jump : 0u;                       // regular positions 0, jump, .. < last
         if (ns_h > 4u * STEPS) ns_h = 4u * STEPS;                                // (the host launches a form with enough slots)
         // The records of the half's seeds: step st, group g -> seed 4 st + g; lanes q < STEPS also fetch lane 0's part of the record of
@@ -498,37 +340,6 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
 #pragma unroll
             for (int st = 0; st < STEPS; ++st) rc[st] = bucket[(size_t)((4u * st + g < ns_h && q != 0u) ? cd[st] : zero_code) * 8u + q];
             hd4 = bucket[(size_t)((q < (uint32_t)STEPS && hslot < ns_h) ? hcode : zero_code) * 8u];
-            if (CTX) {
-                // context records: a position is a hit of the seed when the characters in front of it are the seed's; from here on
-                // the records look like those of a table of whole seeds (header = the seed's own hit count)
-                uint32_t mine = 0;                 // lanes q < STEPS: hits of seed 4 q + g among the positions of its record
-#pragma unroll
-                for (int st = 0; st < STEPS; ++st) {
-                    const uint32_t w = rc[st].w;
-                    rc[st].x = (w & cxm) == cx[st] ? rc[st].x : 0u;
-                    rc[st].w = 0u;
-                    const unsigned long long mx = __builtin_amdgcn_ballot_w64(rc[st].x != 0u);
-                    uint32_t c = (uint32_t)__popc(__builtin_amdgcn_ubfe(gmb_half_bits(mx, h), 8u * g, 8u));
-                    if (__builtin_amdgcn_ballot_w64((rc[st].y | rc[st].z) != 0u) != 0ull) {          // positions 7 .. 20 of a record: rarely there
-                        rc[st].y = ((w >> 10) & cxm) == cx[st] ? rc[st].y : 0u;
-                        rc[st].z = ((w >> 20) & cxm) == cx[st] ? rc[st].z : 0u;
-                        const unsigned long long my = __builtin_amdgcn_ballot_w64(rc[st].y != 0u), mz = __builtin_amdgcn_ballot_w64(rc[st].z != 0u);
-                        c += (uint32_t)__popc(__builtin_amdgcn_ubfe(gmb_half_bits(my, h), 8u * g, 8u)) + (uint32_t)__popc(__builtin_amdgcn_ubfe(gmb_half_bits(mz, h), 8u * g, 8u));
-                    }
-                    if (q == (uint32_t)st) mine = c;
-                }
-                const bool hv = q < (uint32_t)STEPS && hslot < ns_h && !(hd4.x & 0x40000000u);
-                const bool ovf = hv && (hd4.x & 0x80000000u) != 0u;
-                if (__builtin_amdgcn_ballot_w64(ovf) != 0ull) {              // a k-mer with more positions than a record holds: its interval, extended
-                    if (ovf) {
-                        uint32_t k = hd4.y, l = k + hd4.z - 1u;
-                        const bool okx = gmb_extend(gm_kargs()->ix, k, l, hctx, nx);
-                        hd4.x = okx ? (hd4.x & 0xA0000000u) : 0x40000000u;
-                        hd4.y = k; hd4.z = l - k + 1u;
-                    }
-                }
-                if (hv && !ovf) hd4.x = mine != 0u ? ((hd4.x & 0x20000000u) | mine) : 0x40000000u;
-            }
             const bool empty = (hd4.x & 0x40000000u) != 0u;
             const uint32_t hc = (hd4.x & 0x80000000u) ? hd4.z : (hd4.x & 0xFFFFu);
             fail = empty || (p.hcap > 0 && hc > p.hcap);
@@ -541,11 +352,9 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
 #pragma unroll
             for (int st = 0; st < STEPS; ++st) {
                 cd[st] = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_base + 16 * st, (int)code);
-                if (CTX) cx[st] = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_base + 16 * st, (int)ctx);
-                of1[st] = of_g + (uint32_t)st * of_step + nx;              // (context records hold the position of the seed's LAST TB characters)
+                of1[st] = of_g + (uint32_t)st * of_step;
             }
             hcode = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_base + (int)(q << 4), (int)code);
-            if (CTX) hctx = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_base + (int)(q << 4), (int)ctx);
             hof1 = (4u * q + g) * jump + 1u;
         }
         tick(0);
@@ -558,7 +367,7 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
             // halves' records again, and nothing but the seed counts lives across a walk: the hot path above keeps its registers.
             // Context records: the first walk hands back seeds it only assumes good behind the slide; if one of them fails, the second
             // walk settles everything.
-            if (jj < ns_h) S.s_seed[h][jj] = make_uint2(code, i_reg | (ctx << 16));
+            if (jj < ns_h) S.s_seed[h][jj] = make_uint2(code, i_reg);
 #pragma nounroll
             for (int attempt = 1; attempt < 3; ++attempt) {
                 const int lane = gmb_lane_again();
@@ -567,7 +376,7 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
                 const bool walked = gmb_half_bits(fm, h) != 0u;
                 // what the half knows now: the answers at the positions of its records.  The filter's LDS is the walk's scratch.
                 const uint32_t ginfo = (q < (uint32_t)STEPS && hslot < ns_h) ? (((hof1 - 1u) << 2) | (fail ? 0u : 2u) | 1u) : 0u;
-                const uint32_t nw = gm_bucket_rewalk<CTX>(gm_kargs(), r, lane, walked, ginfo, attempt == 1, !CTX || attempt == 2, &S.s_seed[0][0], s_filt);
+                const uint32_t nw = gm_bucket_rewalk(gm_kargs(), r, lane, walked, ginfo, attempt == 1, true, &S.s_seed[0][0], s_filt);
                 if (prof && nw == 0xFFFFFFFFu) tck = 0;
                 if (attempt == 1) tick(2);
                 if (walked) ns_h = nw;
@@ -576,12 +385,11 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
                     const uint32_t slot = 4u * st + g;
                     const uint2 sd = slot < ns_h ? S.s_seed[h][slot] : make_uint2(0u, 0u);
                     cd[st] = sd.x;
-                    cx[st] = sd.y >> 16;
-                    of1[st] = (sd.y & 0xFFFFu) + 1u + nx;
+                    of1[st] = (sd.y & 0xFFFFu) + 1u;
                 }
                 {
                     const uint2 sd = (q < (uint32_t)STEPS && hslot < ns_h) ? S.s_seed[h][hslot] : make_uint2(0u, 0u);
-                    hcode = sd.x; hctx = sd.y >> 16; hof1 = (sd.y & 0xFFFFu) + 1u;
+                    hcode = sd.x; hof1 = (sd.y & 0xFFFFu) + 1u;
                 }
                 fm = fetch(h, g, q);
                 if (fm == 0ull) break;             // (the seeds of a last walk are all good)
@@ -660,10 +468,7 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
     auto write_rows = [&](const bool which) {
         if (which && !listed && q < (uint32_t)STEPS && 4u * q + g < ns_h && 4u * q + g < b.max_seeds) {
             uint2 iv;
-            if (CTX) {                                // the record's interval: the whole seed's where it was extended already, else the table k-mer's
-                iv.x = hd4.y; iv.y = hd4.y + hd4.z - 1u;
-                if (!(hd4.x & 0x80000000u)) gmb_extend(gm_kargs()->ix, iv.x, iv.y, hctx, nx);
-            } else iv = p.kmer_tab[hcode];
+            iv = p.kmer_tab[hcode];
             GmSeed sd; sd.k = iv.x; sd.l = iv.y; sd.pos = hof1 - 1u;
             b.seeds[(size_t)rs * b.max_seeds + 4u * q + g] = sd;
         }
@@ -826,10 +631,10 @@ __global__ void __launch_bounds__(64, CTX ? 5 : STEPS <= 6 ? 8 : 6) k_vote_bucke
 static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 int gmk_build_bucket(const uint2* tab, const uint32_t* full_sa, const uint8_t* pac, uint4* bucket, int T, int ctx, void* stream) {
+    (void)pac; (void)ctx;
     const unsigned long long n = 1ull << (2 * T);
     const dim3 grid((uint32_t)std::min<unsigned long long>((n * 8 + 255) / 256, 256ull * 64));
-    if (ctx) hipLaunchKernelGGL(k_build_bucket_ctx, grid, dim3(256), 0, S_(stream), tab, full_sa, pac, bucket, n);
-    else hipLaunchKernelGGL(k_build_bucket, grid, dim3(256), 0, S_(stream), tab, full_sa, bucket, n);
+    hipLaunchKernelGGL(k_build_bucket, grid, dim3(256), 0, S_(stream), tab, full_sa, bucket, n);
     return (int)hipGetLastError();
 }
 
@@ -840,27 +645,20 @@ static uint32_t gm_bucket_grid(const GmDevParams& p, uint32_t max_reg) {
     if (fixed > 0) return (uint32_t)fixed;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
-    const uint32_t per_simd = p.bucket_ctx ? 5u : max_reg <= 24 ? 8u : 6u;          // the kernels' launch bounds
+    const uint32_t per_simd = max_reg <= 24 ? 8u : 6u;          // the kernels' launch bounds
     return (uint32_t)cus * 4u * per_simd * 4u;
 }
 
 // seeds per strand the launch has to hold: max_reg = ceil((longest read - mer) / jump)
 int gmk_vote_bucket(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint32_t max_reg, const uint32_t* rlist, const uint32_t* n_rlist, void* stream) {
     if (b.n == 0) return 0;
-    if (max_reg > 32 || (p.bucket_ctx && (p.mer <= p.bucket_T || p.mer - p.bucket_T > GMB_NX)) || (!p.bucket_ctx && p.mer != p.bucket_T)) return (int)hipErrorInvalidValue;
+    if (max_reg > 32 || p.bucket_ctx || p.mer != p.bucket_T) return (int)hipErrorInvalidValue;
     // persistent waves, each taking every grid-th read: 4 x as many one-wave workgroups as the chip holds at once (measured at 10 M reads:
     // exactly resident 10.3 ms - the dispatcher's placement is then final and uneven -, 2 x 9.7, 4 x 9.25, one read per wave 9.65)
     const dim3 grid(std::min<uint32_t>(b.n, gm_bucket_grid(p, max_reg))), blk(64);
-    if (!p.bucket_ctx) {
-        if (max_reg <= 8) hipLaunchKernelGGL((k_vote_bucket<2, false>), grid, blk, 0, S_(stream), ix, p, b, rlist, n_rlist);
-        else if (max_reg <= 16) hipLaunchKernelGGL((k_vote_bucket<4, false>), grid, blk, 0, S_(stream), ix, p, b, rlist, n_rlist);
-        else if (max_reg <= 24) hipLaunchKernelGGL((k_vote_bucket<6, false>), grid, blk, 0, S_(stream), ix, p, b, rlist, n_rlist);
-        else hipLaunchKernelGGL((k_vote_bucket<8, false>), grid, blk, 0, S_(stream), ix, p, b, rlist, n_rlist);
-    } else {
-        if (max_reg <= 8) hipLaunchKernelGGL((k_vote_bucket<2, true>), grid, blk, 0, S_(stream), ix, p, b, rlist, n_rlist);
-        else if (max_reg <= 16) hipLaunchKernelGGL((k_vote_bucket<4, true>), grid, blk, 0, S_(stream), ix, p, b, rlist, n_rlist);
-        else if (max_reg <= 24) hipLaunchKernelGGL((k_vote_bucket<6, true>), grid, blk, 0, S_(stream), ix, p, b, rlist, n_rlist);
-        else hipLaunchKernelGGL((k_vote_bucket<8, true>), grid, blk, 0, S_(stream), ix, p, b, rlist, n_rlist);
-    }
+    if (max_reg <= 8) hipLaunchKernelGGL((k_vote_bucket<2>), grid, blk, 0, S_(stream), ix, p, b, rlist, n_rlist);
+    else if (max_reg <= 16) hipLaunchKernelGGL((k_vote_bucket<4>), grid, blk, 0, S_(stream), ix, p, b, rlist, n_rlist);
+    else if (max_reg <= 24) hipLaunchKernelGGL((k_vote_bucket<6>), grid, blk, 0, S_(stream), ix, p, b, rlist, n_rlist);
+    else hipLaunchKernelGGL((k_vote_bucket<8>), grid, blk, 0, S_(stream), ix, p, b, rlist, n_rlist);
     return (int)hipGetLastError();
 }

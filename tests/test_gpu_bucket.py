@@ -36,28 +36,6 @@ BUCKET_CONFIGS = {
     "fast_m8": dict(fast=1, mer=8, jump=8, min_seed_hits=2),
     "m12_j18": dict(mer=12, jump=18),                           # 8 seeds per strand at most -> k_vote_bucket<2>
 }
-# context records (seeds longer than the table's k-mers): _T = the table's k-mer length, the seed's other 1 .. 5 characters are
-# compared with the reference characters kept beside every position
-CTX_CONFIGS = {
-    "t8_m10": dict(_T=8, mer=10, jump=5),                       # 8-mers occur ~6 times: inline records, 2 context characters
-    "t7_m10": dict(_T=7, mer=10, jump=5),                       # 7-mers ~24 times: most records beyond 21 positions -> interval + backward search
-    "t6_m8": dict(_T=6, mer=8, jump=5),                         # 6-mers ~100 times: every seed through the backward search, ~6 hits each
-    "t8_m13_j6": dict(_T=8, mer=13, jump=6),                    # 5 context characters
-    "t9_m14_j7": dict(_T=9, mer=14, jump=7),
-    "t10_m12": dict(_T=10, mer=12, jump=6),
-    "t8_m9_h10": dict(_T=8, mer=9, jump=5, max_kmer_hits=10),   # 1 context character, capped seeds: the walk slides
-    "t7_m9_h31": dict(_T=7, mer=9, jump=5, max_kmer_hits=31),
-    "t5_m8_h12": dict(_T=5, mer=8, jump=5, max_kmer_hits=12),
-    "t8_m10_k3": dict(_T=8, mer=10, jump=5, min_seed_hits=3),
-    "t8_m10_no_nw": dict(_T=8, mer=10, jump=5, nw=0),
-    "t8_m10_down": dict(_T=8, mer=10, jump=5, pos_strand=0),
-    "t8_m12_j9": dict(_T=8, mer=12, jump=9),                    # <= 16 seeds per strand -> <4>
-    "t8_m12_j18": dict(_T=8, mer=12, jump=18),                  # <= 8 -> <2>
-    "t7_m8_j5": dict(_T=7, mer=8, jump=5),                      # ~6 hits per seed out of records of ~24: list kernel hand-overs
-    "t8_m13_fast": dict(_T=8, mer=13, jump=13, fast=1),
-}
-BUCKET_CONFIGS.update(CTX_CONFIGS)
-
 
 @pytest.fixture(scope="module")
 def ix_full(syn_fa):
@@ -84,20 +62,17 @@ def bucket_on():
 
 def _run(cfg, ix_full, oracle, oix, syn_reads, packed, expect_bucket=True):
     kw = dict(BUCKET_CONFIGS[cfg])
-    ctx_T = kw.pop("_T", None)
     p = g.Params(**kw)
     B, Q, Ln = packed
     # on a reference this small the k-mer table stops at 12 characters by default; the records need it as long as the seed
-    g.set_option("GM_KMER_TABLE", str(p.mer) if p.mer > 12 and ctx_T is None else None)
-    g.set_option("GM_BUCKET_T", str(ctx_T) if ctx_T else None)
+    g.set_option("GM_KMER_TABLE", str(p.mer) if p.mer > 12 else None)
     batch = g.Batch(ix_full, len(syn_reads), B.shape[1])
     res = batch.map(p, B, Q, Ln)
     path = batch.path()
     ctr = batch.counters()
     batch.destroy()
-    g.set_option("GM_KMER_TABLE", None); g.set_option("GM_BUCKET_T", None)
+    g.set_option("GM_KMER_TABLE", None)
     assert ("k_vote_bucket" in path) == expect_bucket, path
-    assert ("context records" in path) == (ctx_T is not None and expect_bucket), path
     ores = _oracle_results(oracle, oix, oracle.params(**kw), syn_reads)
     _compare(res, ores, syn_reads)
     return res, ores, ctr
@@ -108,15 +83,14 @@ def test_bucket_kernel_matches_oracle(cfg, bucket_on, ix_full, oracle, oix, syn_
     res, ores, ctr = _run(cfg, ix_full, oracle, oix, syn_reads, packed)
     # the work counters: every SA hit the oracle locates, at most the k-mers it searches one by one (configurations without the
     # reference's early exits: --fast, -T, -u stop a read's seed loop on the CPU, the device looks all seeds up)
-    if cfg in ("default", "h30", "k3", "m9_j5", "m8_j5", "m8_j5_h31", "m7_j9", "m12_j6", "m14_j7", "m12_j18", "t8_m10", "t7_m10", "t6_m8", "t8_m13_j6",
-               "t9_m14_j7", "t10_m12", "t7_m9_h31", "t8_m10_k3", "t8_m12_j9", "t8_m12_j18", "t7_m8_j5"):
+    if cfg in ("default", "h30", "k3", "m9_j5", "m8_j5", "m8_j5_h31", "m7_j9", "m12_j6", "m14_j7", "m12_j18"):
         assert ctr["sa_hits"] == sum(o["ctr"]["locates"] for o in ores)
         assert ctr["seeds_used"] <= ctr["kmers_searched"] <= sum(o["ctr"]["kmers"] for o in ores)
-    if cfg not in ("fast", "fast_m8", "T2", "unique", "m8_j5_h10", "t8_m13_fast", "t8_m9_h10", "t5_m8_h12", "m12_j18", "t8_m12_j18"):
+    if cfg not in ("fast", "fast_m8", "T2", "unique", "m8_j5_h10", "m12_j18"):
         assert len(res["matches"]) > 300
 
 
-@pytest.mark.parametrize("cfg", ["default", "m8_j5", "m7_j5", "m8_j5_h31", "t7_m10", "t7_m8_j5"])
+@pytest.mark.parametrize("cfg", ["default", "m8_j5", "m7_j5", "m8_j5_h31", "m7_j9", "m12_j18"])
 @pytest.mark.parametrize("opts", [dict(GM_HEAVY_MIN="64"), dict(GM_HEAVY_MIN="8", GM_HEAVY_BUDGET="200000"), dict(GM_VOTE_FIXED="0")],
                          ids=lambda o: ",".join(f"{k[3:]}={v}" for k, v in o.items()))
 def test_bucket_kernel_hand_overs(cfg, opts, bucket_on, ix_full, oracle, oix, syn_reads, packed):
@@ -157,24 +131,20 @@ def test_switches_are_read_on_every_call(ix_full, syn_reads, packed):
 
 @pytest.mark.parametrize("L,T,kw", [(250, None, dict(mer=12, jump=8)),                        # 30 seeds per strand: <8>; 12-mers with an error do not occur: both strands walk
                                     (330, None, dict(mer=12, jump=10, max_kmer_hits=3)),      # > 300 positions per strand: several rounds of 96 questions
-                                    (420, 14, dict(mer=14, jump=13)),
-                                    (250, None, dict(_T=8, mer=12, jump=8)),                  # context records over long reads
-                                    (330, None, dict(_T=7, mer=10, jump=10, max_kmer_hits=20))])
+                                    (420, 14, dict(mer=14, jump=13))])
 def test_bucket_kernel_on_long_reads(L, T, kw, bucket_on, ix_full, oracle, oix, syn_fa):
     """the walk of a strand asks about at most 96 positions per half and round: reads of 250 .. 420 bases need several"""
     kw = dict(kw)
-    ctx_T = kw.pop("_T", None)
     reads = _long_reads(syn_fa, L, 24, L + 7)
     B, Q, Ln = g.pack_reads([r[1] for r in reads], [r[2] for r in reads])
     p = g.Params(**kw)
     g.set_option("GM_KMER_TABLE", str(T) if T else None)
-    g.set_option("GM_BUCKET_T", str(ctx_T) if ctx_T else None)
     try:
         batch = g.Batch(ix_full, len(reads), B.shape[1])
         res = batch.map(p, B, Q, Ln)
         path = batch.path()
         batch.destroy()
     finally:
-        g.set_option("GM_KMER_TABLE", None); g.set_option("GM_BUCKET_T", None)
-    assert "k_vote_bucket" in path and ("context records" in path) == (ctx_T is not None), path
+        g.set_option("GM_KMER_TABLE", None)
+    assert "k_vote_bucket" in path, path
     _compare(res, _oracle_results(oracle, oix, oracle.params(**kw), reads), reads)

@@ -8,7 +8,6 @@ loaded into HBM; tools/scale_check.py is the same check as a command-line tool.
     configs[3]  3.1 Gbp, 150-bp reads, -b      -> k_vote_bucket<6> with bisulfite scoring, .gmp arrays (per-nucleotide track) checked
     configs[4]  3.1 Gbp, --no_nw               -> the hit-count-only path
     repeat-rich 3.1 Gbp, -m 14 -h 150          -> capped k-mers (the walk slides), seeds beyond 28 hits, read x strands handed to the list kernel
-    human flags 3.1 Gbp, -m 20 -j 10 -h 150    -> GM_BUCKET_T=15 (opt-in): k_vote_bucket<2> over context records (15-mer table + 5 context characters), i.i.d. and repeat-rich
 """
 import os
 import shutil
@@ -106,29 +105,3 @@ def test_repeat_rich_human_size_with_kmer_cap(workdir):
     _ok_output(out)
 
 
-def test_long_seeds_context_records_at_human_size(workdir):
-    """SURVEY 8(d)'s flags for a human reference, -m 20 -j 10 -h 150: the 15-mer bucket table with context records"""
-    import scale_check
-    import gnumap_amd as g
-    g.set_option("GM_BUCKET_T", "15")                            # opt-in: with 1 % errors most strands walk again, which k_seed does faster (DESIGN.md 4)
-    try:
-        out = scale_check.main(["--mbp", "3100", "--contigs", "24", "--mer", "20", "--jump", "10", "--max-kmer-hits", "150", "--reads", "200000", "--sample", "64",
-                                "--steps", "1", "--check-output", "32", "--keep", "--workdir", workdir])
-    finally:
-        g.set_option("GM_BUCKET_T", None)
-    assert "context records" in out["path"] and "k_vote_bucket<2>" in out["path"], out["path"]
-    _ok(out, 64); _ok_output(out)
-
-
-def test_long_seeds_context_records_repeat_rich(workdir):
-    import scale_check
-    import gnumap_amd as g
-    g.set_option("GM_BUCKET_T", "15")
-    try:
-        out = scale_check.main(["--mbp", "3100", "--contigs", "24", "--mer", "20", "--jump", "10", "--max-kmer-hits", "150", "--repeats", "--reads", "200000",
-                                "--sample", "64", "--steps", "1", "--check-output", "32", "--workdir", workdir])
-    finally:
-        g.set_option("GM_BUCKET_T", None)
-    assert "context records" in out["path"], out["path"]
-    assert out["oracle_sample"] == 64 and out["oracle_mismatches"] == 0, out
-    _ok_output(out)
