@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include "gm_internal.h"
@@ -3000,10 +3001,19 @@ int gmk_nw(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, uint
         // three cost more than the 13-way register pick it removes)
         const int rows_in_regs = (int)gm_opt_ll("GM_NW_ROWS", 1);
         const bool sparse = rows_in_regs && n_cands < 2.5 * b.n;
-        static const bool big_lds = [] {                      // 53 / 78 KB of rows + 12 KB of tables: beyond the 64 KB a launch gets by default
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nw_lane<13, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 13 * 256 * 8) == hipSuccess &&
-                   hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nw_lane<19, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 19 * 256 * 8) == hipSuccess;
-        }();
+        // 53 / 78 KB of rows + 12 KB of tables: beyond the 64 KB a launch gets by default.  The attribute is per DEVICE (--gpus=N): set once
+        // for each device this process launches the LDS-row form on
+        bool big_lds = true;
+        if (rows_in_regs == 2) {
+            static std::atomic<unsigned long long> lds_set{ 0 };
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+            if (!((lds_set.load() >> dev) & 1ull)) {
+                big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nw_lane<13, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 13 * 256 * 8) == hipSuccess &&
+                          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nw_lane<19, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 19 * 256 * 8) == hipSuccess;
+                if (big_lds) lds_set.fetch_or(1ull << dev);
+            }
+        }
         if (!big_lds && rows_in_regs == 2) return (int)hipErrorInvalidValue;
         if (sparse && rows_in_regs == 2 && b.stride <= 104) hipLaunchKernelGGL((k_nw_lane<13, true>), dim3(nw_grid), dim3(256), (size_t)2 * 13 * 256 * 8, S_(stream), ix, p, b);
         else if (sparse && rows_in_regs == 2 && b.stride <= 152) hipLaunchKernelGGL((k_nw_lane<19, true>), dim3(nw_grid), dim3(256), (size_t)2 * 19 * 256 * 8, S_(stream), ix, p, b);

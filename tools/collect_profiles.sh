@@ -41,9 +41,9 @@ if [ "${MATRIX:-1}" = "1" ] || [ "${MATRIX:-1}" = "only" ]; then
     run() { echo "[collect]   bench.py $*"; $B "$@" >> "$OUT/matrix.jsonl" 2>> "$OUT/matrix.log"; }
     if [ "${MATRIX_PART:-all}" != "2" ]; then
     # human scale, i.i.d.: the default run, --no_nw (configs[4] shape), the flags SURVEY 8(d) suggests for human
-    run $C --also="--no-nw $C" --also="--mer 20 --jump 10 --max-kmer-hits 150 $C" --also="--mer 20 --jump 10 --max-kmer-hits 150 --no-nw $C" --also="--max-kmer-hits 150 $C" --also="--mer 20 --jump 10 --max-kmer-hits 150 --opt GM_BUCKET_T=15 $C"
+    run $C --also="--no-nw $C" --also="--mer 20 --jump 10 --max-kmer-hits 150 $C" --also="--mer 20 --jump 10 --max-kmer-hits 150 --no-nw $C" --also="--max-kmer-hits 150 $C" --also="--opt GM_VOTE_PAIR=0 $C" --also="--opt GM_NW=lane $C"
     # human scale, repeat-rich: capped runs, NW and --no_nw
-    run --repeats --max-kmer-hits 150 $C --also="--max-kmer-hits 150 --no-nw $C" --also="--mer 20 --jump 10 --max-kmer-hits 150 $C" --also="--mer 20 --jump 10 --max-kmer-hits 150 --no-nw $C" --also="--mer 20 --jump 10 --max-kmer-hits 150 --opt GM_BUCKET_T=15 $C"
+    run --repeats --max-kmer-hits 150 $C --also="--max-kmer-hits 150 --no-nw $C" --also="--mer 20 --jump 10 --max-kmer-hits 150 $C" --also="--mer 20 --jump 10 --max-kmer-hits 150 --no-nw $C"
     fi
     if [ "${MATRIX_PART:-all}" != "1" ]; then
     run --read-len 150 --reads 4000000 $C                                        # configs[3] read length
