@@ -238,7 +238,7 @@ __device__ __forceinline__ uint32_t gmb_half_scan_incl(uint32_t x) {
 //            votes = popcount(tag mask), NW step = its -k-th lowest bit (inc/align_seq2_raw.cpp:262-274, process_hits :28-40).
 // A strand without a second arrival has no candidate with -k >= 2: the wrong strand of a read ends after pass 1.
 template <int STEPS>
-__global__ void __launch_bounds__(64, STEPS <= 6 ? 8 : 6) k_vote_bucket(GmDevIndex ix, GmDevParams p, GmDevBatch b, const uint32_t* rlist, const uint32_t* n_rlist) {
+__global__ void __launch_bounds__(64, STEPS <= 4 ? 8 : STEPS <= 6 ? 5 : 4) k_vote_bucket(GmDevIndex ix, GmDevParams p, GmDevBatch b, const uint32_t* rlist, const uint32_t* n_rlist) {
     __shared__ GmBucketLds S;
     uint32_t* const s_filt = reinterpret_cast<uint32_t*>(S.filt);          // [2][GMB_FWORDS]
     uint32_t* const s_keys = reinterpret_cast<uint32_t*>(S.small);         // [2][GMB_LCAP]
@@ -645,7 +645,7 @@ static uint32_t gm_bucket_grid(const GmDevParams& p, uint32_t max_reg) {
     if (fixed > 0) return (uint32_t)fixed;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
-    const uint32_t per_simd = max_reg <= 24 ? 8u : 6u;          // the kernels' launch bounds
+    const uint32_t per_simd = max_reg <= 16 ? 8u : max_reg <= 24 ? 5u : 4u;          // the kernels' launch bounds
     return (uint32_t)cus * 4u * per_simd * 4u;
 }
 

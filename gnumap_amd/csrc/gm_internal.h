@@ -169,6 +169,7 @@ int gmk_build_kmer_table(const GmDevIndex& ix, uint2* tab, int T, void* stream);
 int gmk_build_kmer_compact(const uint2* tab, uint4* ctab, int T, void* stream);
 int gmk_extend_kmer_table(const GmDevIndex& ix, const uint2* prev, uint2* next, int T, void* stream);
 int gmk_prep(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream);
+int gmk_prep_rows(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream);      // gm_prep.hip (stride <= 152)
 int gmk_seed(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream);
 int gmk_scan_entries(const GmDevBatch& b, void* stream);
 int gmk_locate_sampled(const GmDevIndex& ix, const GmDevBatch& b, unsigned long long n_entries /* SA hits of the block = entries of coords[] */, void* stream);

@@ -2812,6 +2812,8 @@ int gmk_build_kmer_compact(const uint2* tab, uint4* ctab, int T, void* stream) {
 
 int gmk_prep(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, void* stream) {
     if (b.n == 0) return 0;
+    // rows of up to 152 bytes: the form with the row in registers (gm_prep.hip); GM_PREP=tile keeps the LDS-tile form for A/B runs
+    if (b.stride <= 152 && !gm_opt_is("GM_PREP", "tile")) return gmk_prep_rows(ix, p, b, stream);
     // reads per LDS tile: 48 KB for bases + quals, whole waves; rows too long for at least one wave per tile are read directly
     uint32_t tr = (uint32_t)(49152 / (2 * (size_t)b.stride));
     tr = tr >= 256 ? 256 : (tr / 64) * 64;
