@@ -2565,15 +2565,17 @@ __global__ void __launch_bounds__(256) k_traceback(GmDevIndex ix, GmDevParams p,
 // CIGAR text length and the aligned length exactly like k_traceback (which stays for longer reads).  Same arithmetic, same
 // tie-breaks (max_flt(char&,...) src/bin_seq.cpp:989-1011), so the operations are identical.
 // ------------------------------------------------------------------------------------------------
+#define GM_TBV_ENTRIES (5u * 96u)            // k_traceback_lane's value table: codes 0..4 x quality characters 32..127
 template <int NT>
 __global__ void __launch_bounds__(NT) k_traceback_lane(GmDevIndex ix, GmDevParams p, GmDevBatch b, const GmCand* items, uint32_t n,
                                                        unsigned long long* ops, uint32_t ops_words, uint16_t* ops_len, uint32_t Lp,
-                                                       const uint8_t* emit, uint32_t* cig_cnt, uint32_t* max_span) {
+                                                       const uint8_t* emit, uint32_t* cig_cnt, uint32_t* max_span, uint32_t ntab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     uint16_t* s_mv = reinterpret_cast<uint16_t*>(s_dyn);                 // (Lp + 1) rows x NT lanes
-    __shared__ float2 s_lut[512];
+    // the four substitution values of a PWM row depend only on (called base, quality character): per-workgroup table built once with the
+    // reference's expression, as in k_nw_rows - [phred table][code 0..4][quality character 32..127] -> {val(a), val(c), val(g), val(t)}
+    float4* const s_val = reinterpret_cast<float4*>(s_dyn + (((size_t)(Lp + 1) * NT * 2 + 15) & ~(size_t)15));
     __shared__ uint32_t s_coff[GM_NW_NCOFF];
-    for (int q = threadIdx.x; q < 512; q += NT) s_lut[q] = p.lut[q];
     const bool lds_coff = ix.n_seqs + 1 <= GM_NW_NCOFF;
     if (lds_coff) for (uint32_t q = threadIdx.x; q <= ix.n_seqs; q += NT) s_coff[q] = ix.contig_off[q];
     const uint32_t* coff = lds_coff ? s_coff : ix.contig_off;
@@ -2583,6 +2585,12 @@ __global__ void __launch_bounds__(NT) k_traceback_lane(GmDevIndex ix, GmDevParam
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int k = 0; k < 4; ++k) sg[g][k] = p.S256[(size_t)("acgt"[g]) * 4 + k];
+    for (uint32_t e = threadIdx.x; e < ntab * GM_TBV_ENTRIES; e += NT) {
+        const uint32_t tab = e / GM_TBV_ENTRIES, code = (e % GM_TBV_ENTRIES) / 96u, q = 32u + e % 96u;
+        const float2 pq = p.lut[tab * 256u + q];
+        s_val[e] = make_float4(gm_get_val(code, pq.x, pq.y, sg[0]), gm_get_val(code, pq.x, pq.y, sg[1]), gm_get_val(code, pq.x, pq.y, sg[2]), gm_get_val(code, pq.x, pq.y, sg[3]));
+    }
+    __syncthreads();
     const float gap = p.gap, gap4 = __fmul_rn(p.gap, 4.0f);
     const uint32_t* pac32 = reinterpret_cast<const uint32_t*>(ix.pac);
     const int lane = gm_lane();
@@ -2598,7 +2606,9 @@ __global__ void __launch_bounds__(NT) k_traceback_lane(GmDevIndex ix, GmDevParam
         uint16_t outlen = 0;
         uint32_t ctext = 1;                                              // "*" when there is no path
         if (ok) {
-            const float2* lut = s_lut + ((r < b.illumina_until) ? 256 : 0);
+            const uint32_t tab = (r < b.illumina_until) ? 1u : 0u;
+            const float2* lut = p.lut + tab * 256u;
+            const float4* const vtab = s_val + (tab < ntab ? tab : 0u) * GM_TBV_ENTRIES;
             const uint8_t* rb = b.bases + (size_t)r * b.stride;
             const uint8_t* rq = b.quals + (size_t)r * b.stride;
             const int Li = (int)L;
@@ -2637,10 +2647,15 @@ __global__ void __launch_bounds__(NT) k_traceback_lane(GmDevIndex ix, GmDevParam
                 const uint32_t qc = (((src & 4) ? qw.y : qw.x) >> sh) & 255u;
                 uint32_t code = gm_nt4(ch);
                 if (strand && code < 4) code = 3 - code;
-                const float2 pq = lut[qc];
                 float v4[4];
+                if (tab < ntab && qc - 32u < 96u) {
+                    const float4 t4 = vtab[code * 96u + qc - 32u];
+                    v4[0] = t4.x; v4[1] = t4.y; v4[2] = t4.z; v4[3] = t4.w;
+                } else {                                                 // a character outside the table (or no table): the direct form
+                    const float2 pq = lut[qc];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) v4[g] = gm_get_val(code, pq.x, pq.y, sg[g]);
+                    for (int g = 0; g < 4; ++g) v4[g] = gm_get_val(code, pq.x, pq.y, sg[g]);
+                }
                 uint32_t mrow = 0;
 #pragma unroll
                 for (int d = 0; d < 7; ++d) {
@@ -3068,14 +3083,19 @@ int gmk_traceback(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& 
     uint32_t Lp = lp_of(b.stride);
     const bool group_form = gm_opt_is("GM_TRACEBACK", "group");   // GM_TRACEBACK=group: the 8-lane form for every length (tests)
     if (!group_form && Lp <= 511) {              // lane form: one lane per item, move rows in LDS
+        uint32_t ntab = gm_opt_is("GM_TRACEBACK", "direct") ? 0u : (b.illumina_until ? 2u : 1u);      // value tables in LDS (direct: none, A/B runs)
         if (Lp <= 255) {
-            const size_t lds = (size_t)(Lp + 1) * 128 * 2;
+            const size_t mv_bytes = ((size_t)(Lp + 1) * 128 * 2 + 15) & ~(size_t)15;
+            if (mv_bytes + (size_t)ntab * GM_TBV_ENTRIES * 16 > 65536) ntab = 0;          // (the default dynamic-LDS limit: long rows go without the table)
+            const size_t lds = mv_bytes + (size_t)ntab * GM_TBV_ENTRIES * 16;
             uint32_t grid = cdiv(n, 128); if (grid > 16384) grid = 16384;
-            hipLaunchKernelGGL((k_traceback_lane<128>), dim3(grid), dim3(128), lds, S_(stream), ix, p, b, items, n, ops, ops_words, ops_len, Lp, emit, cig_cnt, max_span);
+            hipLaunchKernelGGL((k_traceback_lane<128>), dim3(grid), dim3(128), lds, S_(stream), ix, p, b, items, n, ops, ops_words, ops_len, Lp, emit, cig_cnt, max_span, ntab);
         } else {
-            const size_t lds = (size_t)(Lp + 1) * 64 * 2;
+            const size_t mv_bytes = ((size_t)(Lp + 1) * 64 * 2 + 15) & ~(size_t)15;
+            if (mv_bytes + (size_t)ntab * GM_TBV_ENTRIES * 16 > 65536) ntab = 0;
+            const size_t lds = mv_bytes + (size_t)ntab * GM_TBV_ENTRIES * 16;
             uint32_t grid = cdiv(n, 64); if (grid > 16384) grid = 16384;
-            hipLaunchKernelGGL((k_traceback_lane<64>), dim3(grid), dim3(64), lds, S_(stream), ix, p, b, items, n, ops, ops_words, ops_len, Lp, emit, cig_cnt, max_span);
+            hipLaunchKernelGGL((k_traceback_lane<64>), dim3(grid), dim3(64), lds, S_(stream), ix, p, b, items, n, ops, ops_words, ops_len, Lp, emit, cig_cnt, max_span, ntab);
         }
         return (int)hipGetLastError();
     }
