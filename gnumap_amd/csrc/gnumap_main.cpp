@@ -10,6 +10,7 @@
 // Multi-GPU (--gpus N): one index replica per GPU, blocks dealt to whichever worker is free, coverage tracks combined
 // with one RCCL all-reduce (gm_coverage_allreduce).
 #include "gnumap_hip.h"
+#include "gm_fmt.h"
 #include <algorithm>
 #include <atomic>
 #include <charconv>
@@ -22,6 +23,7 @@
 #include <fstream>
 #include <iostream>
 #include <map>
+#include <memory>
 #include <set>
 #include <mutex>
 #include <sstream>
@@ -183,6 +185,25 @@ template <class T> struct PinVec {
     T& operator[](size_t i) { return p[i]; } const T& operator[](size_t i) const { return p[i]; }
 };
 
+// SAM text of one formatter slice: plain bytes that are never value-initialised (std::string::resize would write every byte of the
+// 8.7 GB of a 32 M-read run once before the formatter writes it again)
+struct TextBuf {
+    std::unique_ptr<char[]> p; size_t len = 0, cap = 0;
+    void clear() { len = 0; }
+    bool empty() const { return len == 0; }
+    size_t size() const { return len; }
+    const char* data() const { return p.get(); }
+    char* room(size_t extra) {                        // at least `extra` writable bytes at the end
+        if (len + extra > cap) {
+            const size_t nc = std::max(len + extra, cap + cap / 2 + 4096);
+            std::unique_ptr<char[]> q(new char[nc]);
+            if (len) memcpy(q.get(), p.get(), len);
+            p = std::move(q); cap = nc;
+        }
+        return p.get() + len;
+    }
+};
+
 // ---- blocks ------------------------------------------------------------------------------------------------------
 struct Block {
     uint64_t index = 0;
@@ -199,7 +220,7 @@ struct Block {
     size_t text_lo = 0, text_hi = 0; bool lazy = false;   // chunk mode: the byte range of the FASTQ text a worker still has to cut into records
     bool malformed = false;                 // chunk mode: a malformed record ended this block; the rest of the input is read again in file order with the reference's recovery
     int illumina = 0;                       // --illumina still in force when this block starts (the fallback is sticky, SeqReader.cpp:1171-1180)
-    std::vector<std::string> text;          // SAM text, one piece per formatter thread
+    std::vector<TextBuf> text;              // SAM text, one piece per formatter thread
     bool failed = false;
 };
 
@@ -421,22 +442,25 @@ static size_t reverse_cigar(const char* s, char* out) {  // SequenceOperations.h
     return used;
 }
 
-static inline char* put_u64(char* p, uint64_t v) {
-    char tmp[24]; int k = 0;
-    do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v);
-    while (k) *p++ = tmp[--k];
-    return p;
+static inline char* put_u64(char* p, uint64_t v) { return gm_put_u64(p, v); }
+
+static const struct CompLut { char t[256]; CompLut() { for (int c = 0; c < 256; ++c) t[c] = comp_char((char)c); } } g_comp;
+
+// dst[0..n) = src[n-1..0], 8 bytes at a time
+static inline void reverse_bytes(char* dst, const char* src, uint32_t n) {
+    uint32_t k = 0;
+    for (; k + 8 <= n; k += 8) { uint64_t x; memcpy(&x, src + n - 8 - k, 8); x = __builtin_bswap64(x); memcpy(dst + k, &x, 8); }
+    for (; k < n; ++k) dst[k] = src[n - 1 - k];
 }
 
-static void format_sam(std::string& out, const gm_index* ix, const gm_params& p, const gm_sam_rec& r, const char* cigar, const Block& b) {
+static void format_sam(TextBuf& out, const gm_index* ix, const gm_params& p, const gm_sam_rec& r, const char* cigar, const Block& b) {
     const uint32_t i = r.read;
     const uint32_t L = b.len[i], QL = b.qual_len[i];
     const uint32_t nl = std::min<uint32_t>(b.name_len[i], MAX_NAME_SZ - 1);
     const char* cn = gm_index_contig_name(ix, r.contig);
     const size_t cl = strlen(cn), gl = strlen(cigar);
-    const size_t old = out.size();
-    out.resize(old + nl + cl + gl + L + QL + 160);
-    char* w = &out[old];
+    char* const w0 = out.room(nl + cl + gl + L + QL + 160);
+    char* w = w0;
     memcpy(w, b.name[i], nl); w += nl;
     if (r.strand == GM_POS_STRAND) { memcpy(w, "\t0\t", 3); w += 3; } else { memcpy(w, "\t16\t", 4); w += 4; }
     memcpy(w, cn, cl); w += cl;
@@ -451,22 +475,21 @@ static void format_sam(std::string& out, const gm_index* ix, const gm_params& p,
     } else {
         w += reverse_cigar(cigar, w);
         memcpy(w, "\t*\t0\t0\t", 7); w += 7;
-        const char* s = b.seq[i];
-        for (uint32_t k = 0; k < L; ++k) w[k] = comp_char(s[L - 1 - k]);
+        reverse_bytes(w, b.seq[i], L);
+        for (uint32_t k = 0; k < L; ++k) w[k] = g_comp.t[(unsigned char)w[k]];
         w += L; *w++ = '\t';
-        const char* q = b.qual[i];
-        for (uint32_t k = 0; k < QL; ++k) w[k] = q[QL - 1 - k];
+        reverse_bytes(w, b.qual[i], QL);
         w += QL; *w++ = '\t';
     }
-    // "XA:f:%g\tXP:f:%g\tX0:i:%d\n": std::to_chars(general, 6) is specified as printf's %g and is ~4x faster than snprintf
+    // "XA:f:%g\tXP:f:%g\tX0:i:%d\n" (gm_fmt.h: exactly printf's %g)
     memcpy(w, "XA:f:", 5); w += 5;
-    w = std::to_chars(w, w + 40, (double)(float)r.a_score * (1.0 / p.adjust), std::chars_format::general, 6).ptr;
+    w = gm_put_g6(w, (double)(float)r.a_score * (1.0 / p.adjust));
     memcpy(w, "\tXP:f:", 6); w += 6;
-    w = std::to_chars(w, w + 40, (double)(float)r.post_prob, std::chars_format::general, 6).ptr;
+    if (r.post_prob == 1.0f) *w++ = '1'; else w = gm_put_g6(w, (double)(float)r.post_prob);
     memcpy(w, "\tX0:i:", 6); w += 6;
     if (r.sim_matches < 0) { *w++ = '-'; w = put_u64(w, (uint64_t)(-(int64_t)r.sim_matches)); } else w = put_u64(w, (uint64_t)r.sim_matches);
     *w++ = '\n';
-    out.resize((size_t)(w - out.data()));
+    out.len += (size_t)(w - w0);
 }
 
 // ---- per worker: the two batch calls ---------------------------------------------------------------------------------
@@ -615,6 +638,9 @@ int main(int argc, char** argv) {
         while (n) { ssize_t k = ::pwrite(ofd, p, n, (off_t)off); if (k <= 0) return false; p += k; n -= (size_t)k; off += (uint64_t)k; }
         return true;
     };
+    // (Tried in round 4: the pieces copied in through shared mappings of the file's byte ranges instead - no inode write lock, which is
+    // what holds buffered pwrite()s to ONE file to the rate of one thread, 8.4-8.8 GB/s whatever the number of writers.  4 x SLOWER on the
+    // GPU box's file system: 2.1 M first-touch page faults of a growing file cost more than the copies.  The write calls stay.)
     const size_t npos = ~(size_t)0;
     // One pass of the pipeline over the FASTQ text from fq.at on.  chunks = byte ranges cut into records by the workers in parallel
     // (well-formed records only); returns where a malformed record starts (npos: none) - everything before it has been mapped and
@@ -701,8 +727,8 @@ int main(int argc, char** argv) {
                     if ((int)b->text.size() < T) b->text.resize((size_t)T);
                     for (auto& s : b->text) s.clear();
                     run_slices(nr, T, 4096, [&](int s, uint32_t lo, uint32_t hi) {
-                        std::string& out = b->text[(size_t)s];
-                        out.reserve((size_t)(hi - lo) * 300);
+                        TextBuf& out = b->text[(size_t)s];
+                        out.room((size_t)(hi - lo) * 320);
                         for (uint32_t k = lo; k < hi; ++k) { const gm_sam_rec& r = b->recs[k]; format_sam(out, ix, o.p, r, b->pool.data() + r.cigar_off, *b); }
                     });
                     { std::lock_guard<std::mutex> lk(fmt_mu); t_fmt += secs_since(f0); }
