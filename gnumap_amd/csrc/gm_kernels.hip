@@ -355,22 +355,27 @@ __global__ void __launch_bounds__(256) k_scan_block_sums(const uint32_t* in, uin
     if (threadIdx.x == 0) block_sums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-__global__ void k_scan_sums(unsigned long long* block_sums, uint32_t nb) {
-    // one wavefront: running exclusive scan over the block sums, 64 at a time
-    int lane = gm_lane();
-    unsigned long long carry = 0;
-    for (uint32_t base = 0; base < nb; base += 64) {
-        uint32_t idx = base + lane;
-        unsigned long long v = idx < nb ? block_sums[idx] : 0, incl = v;
+__global__ void __launch_bounds__(1024) k_scan_sums(unsigned long long* block_sums, uint32_t nb) {
+    // one workgroup of 1024 threads, a contiguous run of the block sums each (10 at 10 M reads): all loads of the run are in flight at
+    // once.  (Round 1-3: one wavefront, 64 sums per dependent round trip - 82 us at 10 M reads for 80 KB.)
+    __shared__ unsigned long long s_w[16];
+    const uint32_t per = (nb + 1023u) / 1024u;
+    const uint32_t lo = min(nb, threadIdx.x * per), hi = min(nb, lo + per);
+    unsigned long long s = 0;
+    for (uint32_t i = lo; i < hi; ++i) s += block_sums[i];
+    const int lane = gm_lane(), wave = threadIdx.x >> 6;
+    unsigned long long incl = s;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            unsigned long long t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
-        }
-        if (idx < nb) block_sums[idx] = carry + incl - v;
-        carry += __shfl(incl, 63);
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
     }
-    if (lane == 0) block_sums[nb] = carry;
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    unsigned long long run = incl - s, total = 0;
+    for (int w = 0; w < 16; ++w) { if (w < wave) run += s_w[w]; total += s_w[w]; }
+    for (uint32_t i = lo; i < hi; ++i) { const unsigned long long v = block_sums[i]; block_sums[i] = run; run += v; }
+    if (threadIdx.x == 0) block_sums[nb] = total;
 }
 
 __global__ void __launch_bounds__(256) k_scan_final(const uint32_t* in, uint64_t n, const unsigned long long* block_sums, uint64_t* out) {
@@ -2853,7 +2858,7 @@ int gmk_seed(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, vo
 static int scan_u32(const uint32_t* in, uint64_t n, uint64_t* out, unsigned long long* tmp, void* stream) {
     uint32_t nb = cdiv(n, 1024);
     hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(256), 0, S_(stream), in, n, tmp);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, S_(stream), tmp, nb);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, S_(stream), tmp, nb);
     hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(256), 0, S_(stream), in, n, tmp, out);
     return (int)hipGetLastError();
 }
@@ -2955,6 +2960,7 @@ __global__ void __launch_bounds__(256) k_big_collect(GmDevBatch b) {
         for (uint32_t t = 0; t < left; ++t) c += (ws[t >> 2] >> (8u * (t & 3u))) & 1u;
     } else left = 16u;
     const uint32_t incl = gm_wave_scan_incl(c);
+    if (__builtin_amdgcn_readlane((int)incl, 63) == 0) return;                             // nothing flagged in this wavefront (the usual case): no atomic
     uint32_t at = 0;
     if (gm_lane() == 63) at = atomicAdd(b.n_big, incl);
     at = (uint32_t)__builtin_amdgcn_readlane((int)at, 63) + incl - c;

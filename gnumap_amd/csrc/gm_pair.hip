@@ -296,16 +296,28 @@ __global__ void __launch_bounds__(64, 4) k_vote_pair(GmDevIndex ix, GmDevParams 
     }
 }
 
-// the flagged reads, as a list for k_vote_bucket: one atomic per wavefront that has any
+// the flagged reads, as a list for k_vote_bucket (any order).  16 flags per thread, 4096 per workgroup, ONE atomic per workgroup that has
+// any: the first form (a thread per read, an atomic per wavefront) spent 116 us at 10 M reads on 150 000 atomics to one address
 __global__ void __launch_bounds__(256) k_pair_collect(const uint8_t* fallback, uint32_t n, uint32_t* list, uint32_t* n_list) {
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-    const bool f = r < n && fallback[r] != 0;
-    const unsigned long long fm = __builtin_amdgcn_ballot_w64(f);
-    if (fm == 0ull) return;
-    uint32_t base = 0;
-    if (gm_lane() == 0) base = atomicAdd(n_list, (uint32_t)__popcll(fm));
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    if (f) list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))] = r;
+    __shared__ uint32_t s_w[4], s_base;
+    const uint32_t r0 = blockIdx.x * 4096u + threadIdx.x * 16u;
+    uint32_t w[4] = { 0u, 0u, 0u, 0u };
+    if (r0 < n) { const uint4 v = *reinterpret_cast<const uint4*>(fallback + r0); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }      // (the buffer is padded: gm_api.cpp)
+    uint32_t mask = 0;                                   // bit t: read r0 + t is flagged
+#pragma unroll
+    for (uint32_t t = 0; t < 16; ++t) if (((w[t >> 2] >> ((t & 3u) << 3)) & 255u) != 0u && r0 + t < n) mask |= 1u << t;
+    const uint32_t c = (uint32_t)__popc(mask);
+    const uint32_t incl = gm_wave_scan_incl(c);
+    const int lane = gm_lane(), wave = (int)(threadIdx.x >> 6);
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t pre = incl - c, total = 0;
+    for (int q = 0; q < 4; ++q) { if (q < wave) pre += s_w[q]; total += s_w[q]; }
+    if (total == 0u) return;                             // workgroup-uniform
+    if (threadIdx.x == 0) s_base = atomicAdd(n_list, total);
+    __syncthreads();
+    uint32_t at = s_base + pre;
+    while (mask) { const uint32_t t = (uint32_t)__builtin_ctz(mask); mask &= mask - 1u; list[at++] = r0 + t; }
 }
 
 static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
@@ -326,6 +338,6 @@ int gmk_vote_pair(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& 
     if (max_reg <= 8) hipLaunchKernelGGL((k_vote_pair<4>), grid, blk, 0, S_(stream), ix, p, b, fallback, chunk);
     else if (max_reg <= 14) hipLaunchKernelGGL((k_vote_pair<7>), grid, blk, 0, S_(stream), ix, p, b, fallback, chunk);
     else hipLaunchKernelGGL((k_vote_pair<8>), grid, blk, 0, S_(stream), ix, p, b, fallback, chunk);
-    hipLaunchKernelGGL(k_pair_collect, dim3((b.n + 255u) / 256u), dim3(256), 0, S_(stream), fallback, b.n, list, n_list);
+    hipLaunchKernelGGL(k_pair_collect, dim3((b.n + 4095u) / 4096u), dim3(256), 0, S_(stream), fallback, b.n, list, n_list);
     return (int)hipGetLastError();
 }

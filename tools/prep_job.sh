@@ -1,12 +1,12 @@
 set -e
-python -m pytest tests/test_gpu_nw_rows.py tests/test_gpu_celgen.py tests/test_gpu_driver_golden.py -x -q > gpurun_out/r4_prep_t.log 2>&1 || { tail -30 gpurun_out/r4_prep_t.log; exit 1; }
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_bucket.py tests/test_gpu_celgen.py -x -q -k "not t5 and not t6 and not t7 and not t8 and not t9" > gpurun_out/r4_prep_t.log 2>&1 || { tail -30 gpurun_out/r4_prep_t.log; exit 1; }
 tail -2 gpurun_out/r4_prep_t.log
 C="--cpu-seconds 0 --abi-reads 0"
-python bench.py --steps 5 $C --also="--opt GM_PREP=tile $C" --also="--read-len 150 --reads 4000000 $C" --also="--read-len 150 --reads 4000000 --opt GM_PREP=tile $C" --also="--opt GM_VOTE_PAIR=0 $C" > gpurun_out/r4_prep_b.json 2> gpurun_out/r4_prep_b.err
+python bench.py --steps 10 $C --also="--no-nw $C" --also="--max-kmer-hits 150 $C" > gpurun_out/r4_prep_b.json 2> gpurun_out/r4_prep_b.err
+python bench.py --steps 5 --repeats --max-kmer-hits 150 $C > gpurun_out/r4_prep_c.json 2> gpurun_out/r4_prep_c.err
 python -c "
 import json
-for l in open('gpurun_out/r4_prep_b.json'):
+for f in ['r4_prep_b','r4_prep_c']:
+  for l in open('gpurun_out/'+f+'.json'):
     j=json.loads(l); print(round(j['value']/1e6,1), j['ms_per_step'], {k:v['ms_per_step'] for k,v in j['kernels'].items()}, j['parity_sample']['mismatches'], j['config'].get('options'))
 "
-GM_TRACE=1 python bench.py --steps 1 --warmup 0 --reads 1000000 --cpu-seconds 0 --parity-sample 0 --abi-reads 524288 --abi-threads 1 --abi-in-flight 1 > gpurun_out/abi_trace.json 2> gpurun_out/abi_trace.err || true
-grep -c gm_trace gpurun_out/abi_trace.err
