@@ -62,10 +62,20 @@ __global__ void __launch_bounds__(256) k_prep_rows(GmDevIndex ix, GmDevParams p,
         {
             const uint8_t* rb = b.bases + (size_t)(rv ? r : 0u) * b.stride;
             const uint8_t* rq = b.quals + (size_t)(rv ? r : 0u) * b.stride;
+            // 16 bytes per load where the read reaches into both halves (rows are 8-byte aligned, the loads need 4): half as many address
+            // cycles in the texture path, where a wavefront's 64 rows are 64 different lines for every load instruction
 #pragma unroll
-            for (int k = 0; k < NCH; ++k) {
+            for (int k = 0; k < NCH; k += 2) {
                 RB[k] = make_uint2(0u, 0u); RQ[k] = make_uint2(0u, 0u);
-                if ((uint32_t)(8 * k) < L) { RB[k] = *reinterpret_cast<const uint2*>(rb + 8 * k); RQ[k] = *reinterpret_cast<const uint2*>(rq + 8 * k); }
+                if (k + 1 < NCH) { RB[k + 1] = make_uint2(0u, 0u); RQ[k + 1] = make_uint2(0u, 0u); }
+                if (k + 1 < NCH && (uint32_t)(8 * k + 8) < L) {
+                    uint4 tb, tq;
+                    __builtin_memcpy(&tb, rb + 8 * k, 16); __builtin_memcpy(&tq, rq + 8 * k, 16);
+                    RB[k] = make_uint2(tb.x, tb.y); RQ[k] = make_uint2(tq.x, tq.y);
+                    if (k + 1 < NCH) { RB[k + 1] = make_uint2(tb.z, tb.w); RQ[k + 1] = make_uint2(tq.z, tq.w); }
+                } else if ((uint32_t)(8 * k) < L) {
+                    RB[k] = *reinterpret_cast<const uint2*>(rb + 8 * k); RQ[k] = *reinterpret_cast<const uint2*>(rq + 8 * k);
+                }
             }
         }
         if (pw) {                                         // the lane's row of the output stretch starts out zero

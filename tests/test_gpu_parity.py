@@ -462,7 +462,7 @@ def test_pipelined_sub_batches_equal_single_pass(ix_full, syn_reads, packed, mon
 _VARIANT_ORACLE = {}
 
 
-@pytest.mark.parametrize("env", [dict(GM_VOTE="block"),                                             # dense seeds: k_vote_slots (the default dense kernel)
+VARIANT_ENVS = [dict(GM_VOTE="block"),                                             # dense seeds: k_vote_slots (the default dense kernel)
                                  dict(GM_VOTE="big"), dict(GM_VOTE="rounds"),                      # its 64-slot form; rounds of the block form
                                  dict(GM_VOTE="block", GM_VOTE_SLOTS="10"), dict(GM_VOTE="block", GM_VOTE_SLOTS="20"), dict(GM_VOTE="block", GM_VOTE_SLOTS="40"),   # 16- / 24- / 40-slot forms (+ list kernel)
                                  dict(GM_VOTE="block", GM_VOTE_SLOTS="0"), dict(GM_VOTE="block", GM_VOTE_SLOTS="0", GM_TEST_SAMPLED="1"),   # k_vote_tiny (+ list kernel, retry kernel)
@@ -491,19 +491,31 @@ _VARIANT_ORACLE = {}
                                  dict(GM_VOTE="block", GM_VOTE_SLOTS="-1", GM_SEED_FUSED="1", GM_HEAVY_MIN="8", GM_HEAVY_BUDGET="200000"),
                                  # the same inside k_vote_slots (wave 0 of the workgroup looks the seeds up): every slot form, hand-over to the list / heavy kernels
                                  dict(GM_VOTE="block", GM_SEED_FUSED="1"), dict(GM_VOTE="big", GM_SEED_FUSED="1"), dict(GM_VOTE="block", GM_VOTE_SLOTS="10", GM_SEED_FUSED="1"),
-                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="20", GM_SEED_FUSED="1"), dict(GM_VOTE="block", GM_SEED_FUSED="1", GM_HEAVY_MIN="64")],
+                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="20", GM_SEED_FUSED="1"), dict(GM_VOTE="block", GM_SEED_FUSED="1", GM_HEAVY_MIN="64")]
+VARIANT_CFGS = ["default", "no_nw", "k3", "h30", "m6_j2", "m20_j2", "k1"]
+
+
+def _variant_skip(env, cfg):
+    # the whole grid is 50 x 7 processes; the non-default forms run on the configurations that reach their special cases
+    if "GM_SEED_FUSED" in env and cfg in ("no_nw", "k3", "m20_j2"):
+        return "fused seed lookup: covered by default / h30 / m6_j2 / k1 (m20_j2 is never fused: the table is shorter than the seed)"
+    if env.get("GM_VOTE_KERNEL") == "block" and cfg in ("no_nw", "h30", "k1", "m20_j2"):
+        return "block form of the dense kernel (not the default): default / k3 / m6_j2"
+    if env.get("GM_KMER_TABLE") in ("13", "15") and cfg in ("no_nw", "k3", "h30"):
+        return "odd table lengths matter for the long seeds"
+    return None
+
+
+@pytest.mark.parametrize("env", VARIANT_ENVS,
                          ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()))
-@pytest.mark.parametrize("cfg", ["default", "no_nw", "k3", "h30", "m6_j2", "m20_j2", "k1"])
+@pytest.mark.parametrize("cfg", VARIANT_CFGS)
 def test_every_kernel_variant_matches_oracle(env, cfg, syn_fa, oracle, oix, syn_reads, packed, tmp_path):
     """the dispatch heuristics pick kernels by seed density; force each variant on the same inputs and compare the result of
     gm_map_batch (status, self / top score, denominator, matches in key order, position sets) with the ORACLE, read by read"""
-    # the whole grid is 50 x 7 processes; the non-default forms run on the configurations that reach their special cases
-    if "GM_SEED_FUSED" in env and cfg in ("no_nw", "k3", "m20_j2"):
-        pytest.skip("fused seed lookup: covered by default / h30 / m6_j2 / k1 (m20_j2 is never fused: the table is shorter than the seed)")
-    if env.get("GM_VOTE_KERNEL") == "block" and cfg in ("no_nw", "h30", "k1", "m20_j2"):
-        pytest.skip("block form of the dense kernel (not the default): default / k3 / m6_j2")
-    if env.get("GM_KMER_TABLE") in ("13", "15") and cfg in ("no_nw", "k3", "h30"):
-        pytest.skip("odd table lengths matter for the long seeds")
+    why = _variant_skip(env, cfg)
+    if why:
+        pytest.skip(why)
+    _prefetch_variants(syn_fa)                        # the grid's processes, three at a time, started by the first case that gets here
     _run_variant(env, cfg, syn_fa, oracle, oix, syn_reads, tmp_path)
 
 
@@ -514,10 +526,17 @@ def test_big_grouping_path_matches_oracle(cfg, syn_fa, oracle, oix, syn_reads, t
     _run_variant(dict(GM_GROUP_BIG_MIN="1"), cfg, syn_fa, oracle, oix, syn_reads, tmp_path)
 
 
-def _run_variant(env, cfg, syn_fa, oracle, oix, syn_reads, tmp_path):
+_VARIANT_JOBS = {}
+_VARIANT_POOL = []
+
+
+def _variant_key(env, cfg):
+    return (tuple(sorted(env.items())), cfg)
+
+
+def _variant_process(env, cfg, syn_fa, out):
     import subprocess, sys
     # kernel-variant switches are cached in static locals on first use, so each combination runs in its own process
-    out = str(tmp_path / "res.npz")
     code = f"""
 import sys, os, numpy as np
 sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
@@ -532,7 +551,37 @@ res = b.map(p, B, Q, Ln)
 ctr = b.counters()
 np.savez({out!r}, **{{k: v for k, v in res.items() if not k.startswith('_')}}, **{{'ctr_' + k: np.int64(v) for k, v in ctr.items()}})
 """
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=300)
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
+
+
+def _prefetch_variants(syn_fa):
+    """the ~220 processes of test_every_kernel_variant_matches_oracle (1.5 s each, mostly start-up) run three at a time in the background -
+    with the pytest process that is 4 on the card, under the box's limit of 6; a case waits for its own process only"""
+    if _VARIANT_POOL:
+        return
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=3)
+    _VARIANT_POOL.append(pool)
+    import atexit
+    atexit.register(lambda: pool.shutdown(wait=True, cancel_futures=True))       # a run that stops early does not start the rest of the grid
+    d = tempfile.mkdtemp(prefix="gm_variants_")
+    k = 0
+    for cfg in VARIANT_CFGS:                          # pytest's order for the stacked parametrisations: the one next to the function varies slowest
+        for env in VARIANT_ENVS:
+            if _variant_skip(env, cfg):
+                continue
+            out = os.path.join(d, f"v{k}.npz"); k += 1
+            _VARIANT_JOBS[_variant_key(env, cfg)] = (pool.submit(_variant_process, env, cfg, syn_fa, out), out)
+
+
+def _run_variant(env, cfg, syn_fa, oracle, oix, syn_reads, tmp_path):
+    job = _VARIANT_JOBS.pop(_variant_key(env, cfg), None)
+    if job is not None:
+        r, out = job[0].result(), job[1]
+    else:
+        out = str(tmp_path / "res.npz")
+        r = _variant_process(env, cfg, syn_fa, out)
     assert r.returncode == 0, r.stderr[-1500:]
     res = dict(np.load(out))
     if cfg not in _VARIANT_ORACLE:
