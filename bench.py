@@ -16,7 +16,7 @@ BASELINE.json quotes its metric on ("reads/sec (100 bp, -a 0.9) vs human ref"):
 over the whole read set, resident in HBM before the timed region starts.  `abi_reads_per_s` (same JSON line) is the rate of the
 path the ABI actually exports to a host driver: gm_map_batch + gm_output_batch on HOST buffers (upload, device path, unique-map
 grouping, fp64 posterior pass on the host, traceback, CIGAR, SAM rows, coverage deposit, download), blocks of 1 M reads
-driven by `--abi-threads` (2) host threads that keep `--abi-in-flight` (3) blocks queued each, one gm_batch + one HIP stream per
+driven by `--abi-threads` (2) host threads that keep `--abi-in-flight` (4) blocks queued each, one gm_batch + one HIP stream per
 block in flight.  GPU_MAX_HW_QUEUES is raised to 16 for the process (unless the caller set it): the HIP runtime maps streams onto
 4 hardware queues by default, where the kernels of blocks that share a queue run strictly one after another behind each other's
 27-MB copies (measured on one box: 125 -> 140 M reads/s at 262 144-read blocks).
@@ -592,7 +592,7 @@ def build_parser():
     ap.add_argument("--abi-block", type=int, default=1048576)
     ap.add_argument("--abi-threads", type=int, default=2)
     ap.add_argument("--abi-passes", type=int, default=3, help="times the ABI leg goes through its blocks (more = a longer, steadier measurement)")
-    ap.add_argument("--abi-in-flight", type=int, default=3, help="blocks each caller thread keeps queued (enqueue / wait forms); 1 = the synchronous calls")
+    ap.add_argument("--abi-in-flight", type=int, default=4, help="blocks each caller thread keeps queued (enqueue / wait forms); 1 = the synchronous calls")
     ap.add_argument("--parity-sample", type=int, default=64, help="reads of the benchmark compared with the oracle outside the timed region (0 = skip)")
     ap.add_argument("--parity-reference", type=int, default=1, help="compare the reference program's SAM of the CPU-baseline run with the driver binary's, byte for byte (0 = skip)")
     ap.add_argument("--workdir", default=os.environ.get("GM_BENCH_DIR", "/tmp/gnumap_bench"))
