@@ -37,7 +37,7 @@ fi
 if [ "${MATRIX:-1}" = "1" ] || [ "${MATRIX:-1}" = "only" ]; then
     echo "[collect] bench matrix over the BASELINE configurations (10 M reads per step, CPU baseline 5 s each; rows that share a reference and its reads run in one process: --also)"
     : > "$OUT/matrix.jsonl"
-    C="--cpu-seconds 5 --abi-reads 2097152"
+    C="--cpu-seconds 5 --abi-reads 4194304"
     run() { echo "[collect]   bench.py $*"; $B "$@" >> "$OUT/matrix.jsonl" 2>> "$OUT/matrix.log"; }
     if [ "${MATRIX_PART:-all}" != "2" ]; then
     # human scale, i.i.d.: the default run, --no_nw (configs[4] shape), the flags SURVEY 8(d) suggests for human
