@@ -84,10 +84,17 @@ def test_window_validity_flags(ix_full, golden, packed):
     assert (~expect).sum() >= 2
 
 
-def test_traceback_cigars(ix_full, golden, packed):
+@pytest.mark.parametrize("form", ["table", "direct"])
+def test_traceback_cigars(ix_full, golden, packed, form):
+    """k_traceback_lane with the substitution values from its LDS table (default) and computed per row (GM_TRACEBACK=direct, also the form
+    of rows too long to leave room for the table) against the reference's CIGARs"""
     B, Q, Ln = packed
     p = g.Params()
-    ops = ix_full.dev_traceback(p, B, Q, Ln, golden["nw_read"], golden["nw_rc"].astype(np.uint8), golden["nw_begin"])
+    g.set_option("GM_TRACEBACK", "direct" if form == "direct" else None)
+    try:
+        ops = ix_full.dev_traceback(p, B, Q, Ln, golden["nw_read"], golden["nw_rc"].astype(np.uint8), golden["nw_begin"])
+    finally:
+        g.set_option("GM_TRACEBACK", None)
     for i, o in enumerate(ops):
         assert len(o) == golden["tb_len"][i]
         assert rle(o) == bytes(golden["tb_cigar"][i]), i
@@ -476,7 +483,7 @@ VARIANT_ENVS = [dict(GM_VOTE="block"),                                          
                                  dict(GM_KMER_TABLE="15"), dict(GM_KMER_TABLE="16"),           # 2^30 / 2^32 codes (64-bit code arithmetic), 43 GB of HBM at 16
                                  dict(GM_VOTE="block", GM_VOTE_SLOTS="-1"), dict(GM_VOTE="block", GM_VOTE_SLOTS="-1", GM_TEST_SAMPLED="1"),   # k_vote_tiny2
                                  dict(GM_VOTE="block", GM_VOTE_SLOTS="0", GM_VOTE_FIXED="0"), dict(GM_VOTE="block", GM_VOTE_SLOTS="-1", GM_VOTE_FIXED="0"),   # candidates through the bump counters instead of own slots + k_cand_gather
-                                 dict(GM_NW_ROWS="0"),
+                                 dict(GM_NW_ROWS="0"), dict(GM_PREP="tile"),                          # k_nw_lane without the row registers; k_prep (LDS tiles) instead of k_prep_rows
                                  dict(GM_HEAVY_MIN="64"), dict(GM_HEAVY_MIN="8", GM_HEAVY_BUDGET="200000"),      # sorted-key path for read x strands with many SA hits (several chunks)
                                  dict(GM_HEAVY_MIN="64", GM_TEST_SAMPLED="1"),
                                  # the one-wave kernels look their seeds up themselves on the full SA (fused form: chosen when every k-mer is expected
