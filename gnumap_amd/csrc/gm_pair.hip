@@ -205,9 +205,11 @@ __global__ void __launch_bounds__(64, 4) k_vote_pair(GmDevIndex ix, GmDevParams 
         }
         {   // register 2 (positions 14 .. 20: a fifth of the records has some) of every step in ONE round trip as well - a branch and a
             // dependent LDS trip per step is what a wavefront's iteration time is made of here, not the instructions
-            unsigned long long anyz = 0ull, anyw = 0ull;
+            // (is there any such register in the wavefront: the OR of the steps' words, one compare each - not a compare per step)
+            uint32_t orz = 0u, orw = 0u;
 #pragma unroll
-            for (int st = 0; st < STEPS; ++st) { anyz |= __builtin_amdgcn_uicmp(vote ? rc[st].z : 0u, 0u, 33); anyw |= __builtin_amdgcn_uicmp(vote ? rc[st].w : 0u, 0u, 33); }
+            for (int st = 0; st < STEPS; ++st) { orz |= rc[st].z; orw |= rc[st].w; }
+            const unsigned long long anyz = __builtin_amdgcn_uicmp(vote ? orz : 0u, 0u, 33), anyw = __builtin_amdgcn_uicmp(vote ? orw : 0u, 0u, 33);
             if (anyz != 0ull) {
                 uint32_t bz[STEPS], oz[STEPS], tz[STEPS];
 #pragma unroll
