@@ -53,7 +53,7 @@ __device__ __forceinline__ uint4 gmp_zero4() {        // (made here: a hoisted z
 __device__ __forceinline__ uint32_t gmp_qbits(unsigned long long m, uint32_t qsh) { return (uint32_t)(m >> qsh) & 0xFFFFu; }
 
 template <int STEPS>
-__global__ void __launch_bounds__(64, STEPS >= 8 ? 3 : 4) k_vote_pair(GmDevIndex ix, GmDevParams p, GmDevBatch b, uint8_t* fallback, const uint32_t chunk /* pairs per workgroup, a multiple of 16 */) {
+__global__ void __launch_bounds__(64, 4) k_vote_pair(GmDevIndex ix, GmDevParams p, GmDevBatch b, uint8_t* fallback, const uint32_t chunk /* pairs per workgroup, a multiple of 16 */) {
     __shared__ GmPairLds S;
     const uint32_t m = (uint32_t)p.mer, jump = (uint32_t)p.jump, w2 = b.pack_w2;
     const uint32_t cmask = m >= 16u ? 0xFFFFFFFFu : ((1u << (2u * m)) - 1u);
@@ -79,7 +79,8 @@ __global__ void __launch_bounds__(64, STEPS >= 8 ? 3 : 4) k_vote_pair(GmDevIndex
     // state of the pair whose records are in flight (N) / being voted on (C)
     uint32_t N_hdr = 0, N_ns = 0; bool N_fb = false; uint4 N_rc[STEPS]; uint4 N_hd4 = make_uint4(0u, 0u, 0u, 0u);
     // codes of the pair from its words (which must have been requested before), its record loads, and the request of the words two pairs on
-    auto issue = [&](const uint32_t prn, const int lane) {
+    auto issue = [&](const uint32_t prn) {
+        const int lane = gmp_lane_again();
         const uint32_t sd = ((uint32_t)lane >> 4) & 1u, qt = (uint32_t)lane >> 4, jj = (uint32_t)lane & 15u, g = ((uint32_t)lane >> 3) & 1u,
                        q = (uint32_t)lane & 7u, qbase = (uint32_t)lane & 48u, qsh = 16u * qt;
         const uint32_t hdr = n_hdr, f0 = n_f0, f1 = n_f1;
@@ -109,7 +110,7 @@ __global__ void __launch_bounds__(64, STEPS >= 8 ? 3 : 4) k_vote_pair(GmDevIndex
         // of the old values makes the wavefront wait for the new loads right away)
         request_forms(prn + 1u);
     };
-    if (pr0 < pend) { request_forms(pr0); issue(pr0, gmp_lane_again()); }
+    if (pr0 < pend) { request_forms(pr0); issue(pr0); }
     for (uint32_t pr = pr0; pr < pend; ++pr) {
         const int lane = gmp_lane_again();
         const uint32_t rd = (uint32_t)lane >> 5, sd = ((uint32_t)lane >> 4) & 1u, qt = (uint32_t)lane >> 4, jj = (uint32_t)lane & 15u, g = ((uint32_t)lane >> 3) & 1u,
@@ -122,7 +123,7 @@ __global__ void __launch_bounds__(64, STEPS >= 8 ? 3 : 4) k_vote_pair(GmDevIndex
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) rc[st] = N_rc[st];
         const uint4 hd4 = N_hd4;
-        issue(pr + 1u, lane);                         // (unconditional: beyond the last pair it loads the zero record - a branch here makes the compiler copy the
+        issue(pr + 1u);                               // (unconditional: beyond the last pair it loads the zero record - a branch here makes the compiler copy the
                                                       //  freshly loaded words at the join, i.e. wait for them at once)
         {
             const uint4 z = gmp_zero4();
