@@ -862,10 +862,12 @@ extern "C" int gm_map_batch_device(gm_index* ix, const gm_params* p, gm_batch* b
     }
     {
         char buf[224];
+        const int pp_env = (int)gm_opt_ll("GM_SLOTS_PIPE", -1);                                               // (gmk_vote's condition for the pipelined form of k_vote_slots)
+        const bool slots_pp = use_full && !gm_opt("GM_VOTE_KERNEL") && (pp_env < 0 ? dense == 2 : pp_env != 0) && !(dp.dbg & 64);
         snprintf(buf, sizeof buf, "seeds=%s vote=%s locate=%s", use_bucket ? "bucket-table (in the vote kernel)" : dp.fused ? "k-mer table (in the vote kernel)" : "k_seed",
                  use_pair ? (bucket_reg <= 8 ? "k_vote_pair<4> + k_vote_bucket<2>" : bucket_reg <= 14 ? "k_vote_pair<7> + k_vote_bucket<4>" : "k_vote_pair<8> + k_vote_bucket<4>")
                  : use_bucket ? (bucket_reg <= 8 ? "k_vote_bucket<2>" : bucket_reg <= 16 ? "k_vote_bucket<4>" : bucket_reg <= 24 ? "k_vote_bucket<6>" : "k_vote_bucket<8>")
-                            : dense == 0 ? "sparse" : dense == 3 ? "k_vote_block" : dense == 2 ? "k_vote_slots<64>" : slots_hint == 0 ? "k_vote_tiny" : slots_hint < 0 ? "k_vote_tiny2" : "k_vote_slots",
+                            : dense == 0 ? "sparse" : dense == 3 ? "k_vote_block" : dense == 2 ? (slots_pp ? "k_vote_slots_pp<64>" : "k_vote_slots<64>") : slots_hint == 0 ? "k_vote_tiny" : slots_hint < 0 ? "k_vote_tiny2" : slots_pp ? "k_vote_slots_pp" : "k_vote_slots",
                  use_full ? "full-SA" : "sampled-SA");
         b->path = buf;
         GM_TRACE("path: %s", buf);

@@ -1316,6 +1316,9 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
     uint32_t wcount = 0;                             // wave-uniform fill of this wave's list segment
     uint32_t nnz = 0;                                // non-zero window starts of this wave (scalar)
     const int lorg = wave ? LCAP - 1 : 0, ldir = wave ? -1 : 1;       // the list is two stacks (see below)
+    uint32_t lorg4 = (uint32_t)lorg * 4u, wbase = 0;                  // (lorg4: in a vector register, see pass 2a)
+    asm volatile("" : "+v"(lorg4));
+    const int ldir4 = ldir * 4;
     if (filter) {
         // ---- pass 1: one non-returning ds_add per hit into the counting filter
 #pragma unroll
@@ -1324,11 +1327,14 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
             // spread evenly; positions a multiple of 8192 apart share a slot, which only sends them on to the second filter):
             // the add needs the word and a shift, the test in pass 2a is one byte load.  No branch around the lanes without a
             // hit: they add 0 to a word of their own (s_cnt0[lane], which stays what it is).
+            // (round 4: the kernel issues vector instructions 89 % of the time, so the lanes without a hit are masked off instead: one
+            // compare - the one the popcount needs anyway - against a compare and two selects)
+            asm volatile("" : "+v"(bpv[j]));            // (the compare is made HERE: folded into the subtraction above it leaves twenty lane masks in scalar registers)
             const uint32_t h = bpv[j];
             const bool nz = h != 0u;
             nnz += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(nz));
-            uint32_t* const word = nz ? reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(s_r0) + (h & 0x1FFCu)) : &s_cnt0[lane];
-            atomicAdd(word, nz ? 1u << ((h & 3u) << 3) : 0u);
+            asm volatile("" : "+s"(nnz));               // (counted here, not from twenty masks kept until the end of the loop)
+            if (nz) atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(s_r0) + (h & 0x1FFCu)), 1u << ((h & 3u) << 3));
         }
     } else {
 #pragma unroll
@@ -1351,21 +1357,29 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
         __syncthreads();
         tick(2);
         // ---- pass 2a: hits whose slot counted >= kmin -> list (ballot + plain stores)
+        // every lane reads its counter byte (lanes without a hit read byte 0 - a broadcast).  ALL the slots' bytes are requested before the
+        // first is looked at: read and test slot by slot, the wave waits out one LDS round trip per slot (twenty in a row; the phase clocks
+        // of GM_DBG=64 had this pass at 280 cycles per slot)
+        uint32_t cnts[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) cnts[j] = reinterpret_cast<const unsigned char*>(s_r0)[bpv[j] & 8191u];
+#pragma unroll
+        for (int j = 0; j < U; ++j) asm volatile("" : "+v"(cnts[j]));
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            // every lane reads its counter byte (lanes without a hit read byte 0 - a broadcast) so that `pass` is the AND of two
-            // compares, not a value merged across a branch; a list index past the end is clamped onto the last entry (the read
-            // x strand goes to the retry kernel then, see lfull) instead of being branched around
-            const uint32_t cnt = reinterpret_cast<const unsigned char*>(s_r0)[bpv[j] & 8191u];
-            const bool pass = (bpv[j] != 0u) & (cnt >= thr1);
+            const uint32_t cnt = cnts[j];
+            const uint32_t c2 = bpv[j] != 0u ? cnt : 0u;                           // (one select + ONE compare that feeds the ballot and the branch)
+            const bool pass = c2 >= thr1;
             const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
             if (pass) {
-                uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, wcount));
-                at = at < (uint32_t)LCAP ? at : (uint32_t)LCAP - 1u;
-                const uint32_t li = (uint32_t)(lorg + ldir * (int)at);
-                s_lbp[li] = bpv[j]; s_lt[li] = (uint8_t)(j * NW + wave);            // slot id; its seed's step is looked up later, for the few that survive
+                // wbase = min(wcount, LCAP - 64) (scalar), so the index needs no clamp; past the end the read x strand goes to the retry kernel (lfull)
+                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, wbase));
+                const uint32_t li4 = (uint32_t)((int)lorg4 + ldir4 * (int)at);     // byte address of the entry (one multiply-add: lorg4 lives in a vector register)
+                *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(s_lbp) + li4) = bpv[j];
+                s_lt[li4 >> 2] = (uint8_t)(j * NW + wave);                         // slot id; its seed's step is looked up later, for the few that survive
             }
             wcount += (uint32_t)__popcll(m);
+            wbase = wcount < (uint32_t)(LCAP - 64) ? wcount : (uint32_t)(LCAP - 64);
         }
     } else {
 #pragma unroll
@@ -1548,6 +1562,436 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
     }
     tick(7);
     if (prof) atomicAdd(&b.counters[GMK_DBG8], 1ull);
+}
+
+// ---- k_vote_slots_pp: k_vote_slots (full SA, seeds looked up in the kernel) with the loads of the read x strands to come in flight -------
+// k_vote_slots spends a third of a workgroup's life in three dependent round trips before its first vote (the 2-bit row, the k-mer
+// table record, the SA ranks: profiles/r04_slots_phase_clocks_100Mbp.txt), and its LDS leaves no room for more workgroups to wait them
+// out.  Here a workgroup takes `chunk` consecutive read x strands and keeps three of them on the way at once: while it votes on read x
+// strand c, the SA ranks of c + 1 are landing in a second register set, the table record of c + 2 and the 2-bit words of c + 3 are in
+// flight.  Every load is issued one iteration before its use and is unconditional (an address clamped onto the chunk's last read x
+// strand instead of a branch around the load: a branch makes the compiler merge registers at the join, i.e. wait at once); both waves
+// issue the (identical) seed loads so that no wave-dependent branch surrounds them, wave 0 alone turns records into slot descriptors.
+// The slot descriptors are double-buffered; the filter / table memory is zeroed at the END of a vote (wave 1 its first half while wave
+// 0 emits from the second), so an iteration starts with one barrier.  Votes, hand-overs and results are those of k_vote_slots.
+#ifndef GMS_PP_WAVES
+#define GMS_PP_WAVES 5                   // wavefronts per SIMD the pipelined form is compiled for (its 40-slot form: 96 registers)
+#endif
+template <bool MASK64, int SMAX, bool SEED>
+__global__ void __launch_bounds__(128, SMAX == 64 ? 4 : GMS_PP_WAVES) k_vote_slots_pp(GmDevIndex ix, GmDevParams p, GmDevBatch b, const uint32_t chunk) {
+    constexpr bool BIG = SMAX == 64;
+    constexpr int LCAP = BIG ? 1280 : SMAX == 16 ? 320 : GMS_LCAP;
+    static_assert(SMAX == 16 || SMAX == 24 || SMAX == GMS_SMAX || SMAX == 64, "instantiated forms");
+    constexpr int NT = 128, NW = 2, U = SMAX / NW, ZK = 512 / NT;
+    __shared__ uint4 s_r0v[512];                     // as in k_vote_slots
+    __shared__ uint32_t s_lbp[LCAP];
+    __shared__ uint8_t s_lt[LCAP];
+    __shared__ uint2 s_desc[2][SMAX];                // [read x strand parity within the chunk]
+    __shared__ uint32_t s_cnt0[64];
+    __shared__ uint4 s_tabv[BIG ? 256 : 1];          // BIG: the exact table (256 x key | votes | low mask | high mask)
+    __shared__ uint32_t s_nslots[2], s_E[2], s_nkeys, s_full, s_any0, s_lcnt[NW];
+    uint32_t* const s_r0 = reinterpret_cast<uint32_t*>(s_r0v);
+    uint32_t* const s_tab = reinterpret_cast<uint32_t*>(s_tabv);
+    const int tid = threadIdx.x, lane0 = gm_lane();
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t n2 = 2u * b.n, rs0 = blockIdx.x * chunk;
+    if (rs0 >= n2) return;
+    const int n_it = (int)(n2 - rs0 < chunk ? n2 - rs0 : chunk);
+    const uint32_t rs_last = rs0 + (uint32_t)n_it - 1u;
+    // the seed lookup of gm_tiny_seeds<true>, cut into its three round trips; what does not depend on the read x strand:
+    const uint32_t m = (uint32_t)p.mer, w2 = b.pack_w2;
+    const uint32_t cmask = m >= 16u ? 0xFFFFFFFFu : ((1u << (2u * m)) - 1u);
+#pragma unroll
+    for (int k = 0; k < ZK; ++k) s_r0v[tid + NT * k] = make_uint4(0u, 0u, 0u, 0u);
+    if (BIG) { s_tabv[tid] = make_uint4(0u, 0u, 0u, 0u); s_tabv[tid + NT] = make_uint4(0u, 0u, 0u, 0u); }
+    uint32_t vz = 0;                                 // zero, opaque: the header is loaded per lane and stays in a vector register until stage A makes
+    asm volatile("" : "+v"(vz));                     // it scalar (loaded from a uniform address it is made scalar at once, i.e. waited for at once)
+    uint32_t F_hdr = 0, F_f0 = 0, F_f1 = 0;          // c + 3: header and the two words that hold this lane's k-mer
+    uint32_t P_hdr = 0, P_code = 0;                  // c + 2: its header, this lane's code and the table record of the code
+    uint4 P_rec = make_uint4(0u, 0u, 0u, 0u);
+    GmSeed R_sd; R_sd.k = 0; R_sd.l = 0; R_sd.pos = 0;      // SEED = false (seed rows of k_seed): the lane's seed of c + 2 and the row's length
+    uint32_t R_ns = 0;
+    uint32_t bpv[U];                                 // SA ranks of c + 1 on their way (from the point where c's have gone into the list) -> window starts of c
+#pragma unroll
+    for (int j = 0; j < U; ++j) bpv[j] = 0;
+    for (int it = -3; it < n_it; ++it) {
+        const uint32_t cb = (uint32_t)it & 1u, nb = cb ^ 1u;
+        // the wave number as a value the compiler cannot see through: what is derived from it (the 20 slot numbers j * NW + wave of the list
+        // entries) is then computed where it is used instead of being kept in 20 registers across the loop
+        uint32_t wv = (uint32_t)wave, lv = (uint32_t)lane0;
+        asm volatile("" : "+v"(wv), "+v"(lv));
+        const int lane = (int)lv;                        // (likewise: the lane's seed offset, shift and word index are three instructions, not three registers)
+        const uint32_t si = lv * (uint32_t)p.jump;
+        const uint32_t o = si + m <= 16u * w2 ? 2u * (16u * w2 - si - m) : 0u;
+        if (wave == 0) {
+            // ---- c + 1: record -> seeds -> slot descriptors (gm_tiny_seeds<true> from its probe on, then wave 0's part of k_vote_slots)
+            const uint32_t rs = rs0 + (uint32_t)(it + 1);
+            uint32_t S0 = 0, E0 = 0;
+            if (it + 1 >= 0 && it + 1 < n_it) {          // wave-uniform
+                GmSeed sd; sd.k = 0; sd.l = 0; sd.pos = 0;
+                uint32_t ns = 0, ie_all = 0xFFFFFFFFu;
+                if (!SEED) {                             // the seed row has arrived: nothing to look up, n_seeds / n_entries are k_seed's
+                    ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)R_ns);
+                    if ((uint32_t)lane < b.max_seeds) sd = R_sd;
+                }
+                const uint32_t hdr = (uint32_t)__builtin_amdgcn_readfirstlane((int)P_hdr), strand = rs & 1u;
+                const uint32_t L = hdr & 0xFFFFu;
+                const bool on = SEED && !((hdr >> 17) & 1u) && (strand ? p.neg_strand : p.pos_strand);      // wave-uniform
+                if (on) {
+                    const bool act = si + m < L;
+                    const uint32_t nreg = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(act));
+                    bool bad = act && ((hdr >> 16) & 1u);
+                    uint32_t k = 0, cnt = 0;
+                    if (act && !bad) {
+                        const uint32_t code = P_code;
+                        const uint4 rec = P_rec;
+                        bool answered = false;
+                        const uint32_t sub = code & 7u, sh = (sub & 3u) << 3;
+                        const uint32_t own = sub < 4u ? rec.y : rec.z;
+                        cnt = (own >> sh) & 255u;
+                        if (rec.w == 0u && cnt >= 224u) { bad = true; answered = true; }
+                        else if (rec.w == 0u) {
+                            const uint32_t part = own & ((1u << sh) - 1u);
+                            uint32_t lo = sub < 4u ? part : rec.y, hi = sub < 4u ? 0u : part;
+                            lo &= ~(((lo & (lo << 1) & (lo << 2) & 0x80808080u) >> 7) * 0xFFu);
+                            hi &= ~(((hi & (hi << 1) & (hi << 2) & 0x80808080u) >> 7) * 0xFFu);
+                            k = rec.x + __builtin_amdgcn_sad_u8(lo, 0u, __builtin_amdgcn_sad_u8(hi, 0u, 0u));
+                            answered = true;
+                        }
+                        if (!answered) {                 // an escaped record (a count that does not fit a byte): the full table, now
+                            const uint2 iv = p.kmer_tab[code];
+                            if (iv.x == 0xFFFFFFFFu) bad = true;
+                            else { k = iv.x; cnt = iv.y - iv.x + 1u; }
+                        }
+                        if (p.hcap > 0 && cnt > p.hcap) bad = true;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(bad) == 0ull) {
+                        ns = nreg;
+                        if (act) { sd.k = k; sd.l = k + cnt - 1u; sd.pos = si; }
+                    } else {                             // rare: walked again round by round; a non-ACGT base: the serial walk, by lane 0
+                        GmSeed* const scratch = reinterpret_cast<GmSeed*>(s_lbp);      // (the list of the vote before is dead, this one's not begun)
+                        uint32_t nseed = 0;
+                        if ((hdr >> 16) & 1u) { if (lane == 0) nseed = gm_seed_walk_ool(gm_kargs(), rs, scratch, 1); }
+                        else nseed = gm_seed_rewalk_ool(gm_kargs(), rs, lane, scratch);
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                        ns = (uint32_t)__builtin_amdgcn_readlane((int)nseed, 0);
+                        if ((uint32_t)lane < ns) sd = scratch[lane];
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    }
+                }
+                if (SEED) {
+                const uint32_t c_all = (uint32_t)lane < ns ? sd.l - sd.k + 1u : 0u;
+                uint32_t e_all;
+                if (__builtin_amdgcn_ballot_w64(c_all > (1u << 24)) != 0ull) {
+                    const unsigned long long e64 = gm_wave_sum((unsigned long long)c_all);
+                    e_all = e64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)e64;
+                    if (lane == 0 && e64 > 0xFFFFFFFFull) atomicAdd(&b.counters[GMK_SA_HITS], e64 - 0xFFFFFFFFull);
+                } else {
+                    ie_all = gm_wave_scan_incl(c_all);
+                    e_all = (uint32_t)__builtin_amdgcn_readlane((int)ie_all, 63);
+                }
+                if (lane == 0) { b.n_seeds[rs] = (uint16_t)ns; b.n_entries[rs] = e_all; }
+                if (ns != 0 && e_all > p.heavy_min) {    // sorted-key path: it reads the seed row
+                    if ((uint32_t)lane < ns) b.seeds[(size_t)rs * b.max_seeds + lane] = sd;
+                    ns = 0;
+                }
+                }
+                if (p.nw && p.fast && ns > 1) ns = 1;
+                const uint32_t cnt = (uint32_t)lane < ns ? sd.l - sd.k + 1 : 0u;
+                const uint32_t nsl = (cnt + 63u) >> 6;
+                const uint32_t ie = gm_wave_scan_incl(cnt), is = gm_wave_scan_incl(nsl);
+                E0 = __builtin_amdgcn_readlane(ie, 63); S0 = __builtin_amdgcn_readlane(is, 63);
+                if (S0 > SMAX) {                         // wave-uniform: hand over to the list kernel
+                    if (SEED && (uint32_t)lane < b.max_seeds) b.seeds[(size_t)rs * b.max_seeds + lane] = sd;
+                    if (lane == 0) { const uint32_t at = atomicAdd(b.n_big, 1u); b.big_list[at] = rs; }
+                    S0 = 0; E0 = 0;
+                } else {
+                    const uint32_t s0 = is - nsl;
+                    for (uint32_t j = 0; j < nsl; ++j) {
+                        const uint32_t left = cnt - 64u * j;
+                        s_desc[nb][s0 + j] = make_uint2(sd.k + 64u * j, sd.pos | ((uint32_t)lane << 16) | ((left < 64u ? left : 64u) << 24));
+                    }
+                }
+            }
+            if ((uint32_t)lane >= S0 && lane < SMAX) s_desc[nb][lane] = make_uint2(0u, 0u);      // unused slots: no valid lane
+            s_cnt0[lane] = 0;                             // (the state of THIS iteration's vote)
+            if (lane == 0) { s_nslots[nb] = S0; s_E[nb] = E0; s_nkeys = 0; s_full = 0; s_any0 = 0; }
+        }
+        if (!SEED) {   // ---- c + 2: the lane's seed of the row k_seed wrote, and the row's length (as a lane value: see vz)
+            const uint32_t lo = rs0 + (uint32_t)(it + 2 > 0 ? it + 2 : 0);
+            const uint32_t rs = lo < rs_last ? lo : rs_last;
+            R_sd = b.seeds[(size_t)rs * b.max_seeds + ((uint32_t)lane < b.max_seeds ? (uint32_t)lane : 0u)];
+            R_ns = b.n_seeds[(size_t)rs + vz];
+        }
+        if (SEED) {   // ---- c + 2: this lane's code from the words that have arrived -> its table record (one 16-byte load)
+            const uint32_t code = (uint32_t)((((unsigned long long)F_f1 << 32) | F_f0) >> (o & 31u)) & cmask;
+            P_hdr = F_hdr; P_code = code;
+            P_rec = p.kmer_ctab[code >> 3];          // (no use here: it is wanted one iteration on)
+        }
+        if (SEED) {   // ---- c + 3: the row's header and the two words that hold this lane's k-mer
+            const uint32_t rs = rs0 + (uint32_t)(it + 3) < rs_last ? rs0 + (uint32_t)(it + 3) : rs_last;
+            const uint32_t* const row = b.pack + (size_t)(rs >> 1) * b.pack_words;
+            const uint32_t* const form = row + ((rs & 1u) ? w2 + 2u : 1u);
+            F_hdr = row[vz]; F_f0 = form[o >> 5]; F_f1 = form[(o >> 5) + 1u];
+        }
+        gm_lds_barrier();
+        // ---- c: the vote of k_vote_slots
+        const uint32_t rs = rs0 + (uint32_t)it;
+        const uint32_t nslots = it >= 0 ? s_nslots[cb] : 0u, E = s_E[cb];
+        const bool voting = nslots != 0;                 // block-uniform; false: nothing to vote on, or handed over (the filter memory is still zero)
+        uint32_t nvalid = 0;
+        uint32_t wcount = 0, nnz = 0;
+        const bool filter = p.kmin >= 2 && E > 256;
+        const uint32_t thr1 = (uint32_t)(p.kmin < 100 ? p.kmin : 100);
+        const int lorg = wave ? LCAP - 1 : 0, ldir = wave ? -1 : 1;
+        uint32_t lorg4 = (uint32_t)lorg * 4u + (lv & 0u), wbase = 0;      // (per lane on purpose: a vector register for the list address' multiply-add)
+        const int ldir4 = ldir * 4;
+        if (voting) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const uint32_t mt = __builtin_amdgcn_readfirstlane(s_desc[cb][j * NW + wave].y);
+            const uint32_t pos = mt & 0xFFFFu, nl = mt >> 24;
+            nvalid += nl;
+            bpv[j] = (uint32_t)lane < nl ? __builtin_elementwise_sub_sat(bpv[j], pos) : 0u;      // :267
+        }
+        if (filter) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                asm volatile("" : "+v"(bpv[j]));
+                const uint32_t h = bpv[j];
+                const bool nz = h != 0u;
+                nnz += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(nz));
+                asm volatile("" : "+s"(nnz));
+                if (nz) atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(s_r0) + (h & 0x1FFCu)), 1u << ((h & 3u) << 3));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < U; ++j) nnz += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(bpv[j] != 0u));
+        }
+        if (nnz != nvalid) {                             // wave-uniform, rare: votes for b = 0, counted per step
+            if (lane == 0) s_any0 = 1;
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const uint32_t mt = __builtin_amdgcn_readfirstlane(s_desc[cb][j * NW + wave].y);
+                const uint32_t nl = mt >> 24, t = (mt >> 16) & 63u;
+                const unsigned long long z = __builtin_amdgcn_ballot_w64((uint32_t)lane < nl && bpv[j] == 0u);
+                if (lane == 0 && z != 0ull) atomicAdd(&s_cnt0[t], (uint32_t)__popcll(z));
+            }
+        }
+        if (filter) {
+            gm_lds_barrier();
+            // (the counter bytes of half the slots requested before the first is looked at: see k_vote_slots)
+            constexpr int HB = U / 2;
+            static_assert(U % 2 == 0, "two batches of filter bytes");
+#pragma unroll
+            for (int j0 = 0; j0 < U; j0 += HB) {
+            uint32_t cnts[HB];
+#pragma unroll
+            for (int j = 0; j < HB; ++j) cnts[j] = reinterpret_cast<const unsigned char*>(s_r0)[bpv[j0 + j] & 8191u];
+#pragma unroll
+            for (int j = 0; j < HB; ++j) asm volatile("" : "+v"(cnts[j]));
+#pragma unroll
+            for (int jj = 0; jj < HB; ++jj) {
+                const int j = j0 + jj;
+                const uint32_t cnt = cnts[jj];
+                const uint32_t c2 = bpv[j] != 0u ? cnt : 0u;
+                const bool pass = c2 >= thr1;
+                const unsigned long long mk = __builtin_amdgcn_ballot_w64(pass);
+                if (pass) {
+                    const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, wbase));
+                    const uint32_t li4 = (uint32_t)((int)lorg4 + ldir4 * (int)at);
+                    *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(s_lbp) + li4) = bpv[j];
+                    s_lt[li4 >> 2] = (uint8_t)((uint32_t)(j * NW) + wv);
+                }
+                wcount += (uint32_t)__popcll(mk);
+                wbase = wcount < (uint32_t)(LCAP - 64) ? wcount : (uint32_t)(LCAP - 64);
+            }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const bool pass = bpv[j] != 0;
+                const unsigned long long mk = __builtin_amdgcn_ballot_w64(pass);
+                if (pass) {
+                    const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, wcount));
+                    if (at < (uint32_t)LCAP) { const uint32_t li = (uint32_t)(lorg + ldir * (int)at); s_lbp[li] = bpv[j]; s_lt[li] = (uint8_t)((uint32_t)(j * NW) + wv); }
+                }
+                wcount += (uint32_t)__popcll(mk);
+            }
+        }
+        if (lane == 0) s_lcnt[wave] = wcount;
+        }
+        // ---- c + 1: its SA ranks into the registers whose window starts have just gone into the list: slot s = j * NW + wave (scalar base
+        // + 4 * lane; an unused slot reads rank 0.., harmless); they land during the table phases and the emit
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const uint32_t r0 = __builtin_amdgcn_readfirstlane(s_desc[nb][j * NW + wave].x);
+            bpv[j] = (ix.full_sa + r0)[lane];
+        }
+        if (!voting) continue;
+        gm_lds_barrier();
+        if (filter) {                                    // the filter is dead: check it for saturation and zero it - that is the empty table
+            uint32_t acc = 0;
+#pragma unroll
+            for (int k = 0; k < ZK; ++k) {
+                const uint4 v = s_r0v[tid + NT * k];
+                acc |= v.x | v.y | v.z | v.w;
+                s_r0v[tid + NT * k] = make_uint4(0u, 0u, 0u, 0u);
+            }
+            if (acc & 0x80808080u) s_full = 1;
+            gm_lds_barrier();
+        }
+        constexpr int T2 = 256;
+        constexpr uint32_t F2W = BIG ? 2047u : 1023u;
+        constexpr int F2S = BIG ? 11 : 10;
+        uint32_t* const keys = BIG ? s_tab : s_r0 + 1024; uint32_t* const vals = keys + T2; uint32_t* const mlo = keys + 2 * T2; uint32_t* const mhi = keys + 3 * T2;
+        const bool lfull = s_lcnt[0] + s_lcnt[1] > (uint32_t)LCAP;       // block-uniform
+        const uint32_t n_l = lfull ? 0u : s_lcnt[wave];
+        const uint32_t thr = (uint32_t)(p.kmin < 1 ? 1 : p.kmin);
+        for (uint32_t i0 = 0; i0 < n_l; i0 += 256) {     // four wave steps at a time: their list reads are in flight together
+            uint32_t bp4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t i = i0 + 64u * q + (uint32_t)lane;
+                bp4[q] = i < n_l ? s_lbp[wave ? LCAP - 1 - i : i] : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (bp4[q] != 0u) {
+                    // two bits per slot, seen / seen again (as in k_vote_tiny): 16 384 (BIG: 32 768) slots in the words that held 2048
+                    // (4096) 16-bit counters - 8 x fewer entries reach the CAS loop of the table by sharing a slot
+                    const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> (BIG ? 17 : 18), sh = (h2 >> F2S) << 1;
+                    const uint32_t old = atomicOr(&s_r0[h2 & F2W], 1u << sh);
+                    if ((old >> sh) & 1u) atomicOr(&s_r0[h2 & F2W], 2u << sh);
+                }
+        }
+        gm_lds_barrier();
+        {
+            bool full = false;
+            uint32_t nfresh = 0;
+            for (uint32_t i0 = 0; i0 < n_l; i0 += 256) {
+                uint32_t bp4[4], c4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t i = i0 + 64u * q + (uint32_t)lane;
+                    bp4[q] = i < n_l ? s_lbp[wave ? LCAP - 1 - i : i] : 0u;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> (BIG ? 17 : 18);
+                    c4[q] = (s_r0[h2 & F2W] >> ((h2 >> F2S) << 1)) & (thr >= 2u ? 2u : 1u);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bool fresh = false;
+                    if (bp4[q] != 0u && c4[q] != 0u) {
+                        const uint32_t i = i0 + 64u * q + (uint32_t)lane;
+                        const uint32_t bp = bp4[q], t = (s_desc[cb][s_lt[wave ? LCAP - 1 - i : i]].y >> 16) & 63u;
+                        uint32_t slot = (bp * 0x9E3779B1u) >> 24;
+                        uint32_t old;
+                        int probes = 0;
+                        // one exit test per probe (the table is kept under 3/4 full, so an empty slot always turns up)
+                        while ((old = atomicCAS(&keys[slot], 0u, bp)) != 0u && old != bp && ++probes < T2) slot = (slot + 1) & (T2 - 1);
+                        fresh = old == 0u;
+                        const bool found = old == 0u || old == bp;
+                        if (!found) full = true;
+                        else {
+                            atomicAdd(&vals[slot], 1u);
+                            if (t < 32) atomicOr(&mlo[slot], 1u << t);
+                            else if (MASK64) atomicOr(&mhi[slot], 1u << (t - 32));
+                        }
+                    }
+                    nfresh += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(fresh));
+                }
+            }
+            if (lane == 0 && nfresh) atomicAdd(&s_nkeys, nfresh);
+            if (full) s_full = 1;
+        }
+        gm_lds_barrier();
+        const bool failed = lfull || s_full || s_nkeys > (uint32_t)(T2 * 3 / 4);      // block-uniform
+        if (wave != 0) {                                 // wave 1 is done with this vote: it zeroes what wave 0 does not emit from
+#pragma unroll
+            for (int k = 0; k < (BIG ? 8 : 4); ++k) s_r0v[lane + 64 * k] = make_uint4(0u, 0u, 0u, 0u);
+            continue;
+        }
+        if (failed) {                                    // hand this read x strand to the global-table kernel
+            if (lane == 0) {
+                if (SEED) (void)gm_seed_walk_ool(gm_kargs(), rs, nullptr, 0);      // the retry kernel reads the seed row
+                b.rs_overflow[rs] = 1;
+                const uint32_t j = atomicAdd(b.n_retry, 1u);
+                const uint32_t need = 2 * E; uint32_t sz = 1024; while (sz < need && sz < 0x80000000u) sz <<= 1;
+                const unsigned long long off = atomicAdd(&b.counters[GMK_HEAVY_SLOTS], (unsigned long long)sz);
+                b.retry_list[j] = rs;
+                b.retry_off[j] = off;
+                atomicAdd(&b.counters[GMK_OVERFLOW_RS], 1ull);
+            }
+        } else {
+            // ---- emit (wave 0): as k_vote_slots
+            static_assert(T2 == 256, "four table slots per lane of wave 0");
+            bool em[4]; uint32_t ky[4], st[4], nbs[4];
+            unsigned long long mk[4];
+            uint32_t total = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t slot = (uint32_t)(q * 64 + lane);
+                const uint32_t key = keys[slot], v = vals[slot];
+                em[q] = key != 0u && v >= (uint32_t)p.kmin;
+                ky[q] = key; st[q] = 0;
+                if (em[q]) {
+                    if (p.nw) {
+                        unsigned long long mm = (unsigned long long)mlo[slot] | (MASK64 ? ((unsigned long long)mhi[slot] << 32) : 0ull);
+                        for (int r = 1; r < p.kmin; ++r) mm &= mm - 1;
+                        st[q] = mm ? (uint32_t)(__ffsll((long long)mm) - 1) : 0u;
+                    } else st[q] = v > 65535u ? 65535u : v;
+                }
+                mk[q] = __builtin_amdgcn_ballot_w64(em[q]);
+                nbs[q] = total;
+                total += (uint32_t)__popcll(mk[q]);
+            }
+            if (total != 0u && b.fixed_cands && total <= GM_FIXED_C) {            // wave-uniform
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (em[q]) {
+                        const uint32_t idx = nbs[q] + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk[q] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk[q], 0u));
+                        GmCand c;
+                        c.rs = rs; c.b = ky[q]; c.step = (uint16_t)st[q]; c.flags = 4; c.pad = 0; c.score = 0.0f;
+                        b.fixed_cands[GM_FIXED_AT(b, rs, idx)] = c;
+                    }
+                if (lane == 0) b.fixed_cnt[rs] = (uint8_t)total;
+            } else if (total != 0u) {                    // wave-uniform
+                const uint32_t shard = rs & (GM_NSHARD - 1);
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&b.shard_cnt[shard * GM_SHARD_STRIDE], total);
+                base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (em[q]) {
+                        const uint32_t idx = base + nbs[q] + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk[q] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk[q], 0u));
+                        if (idx < b.cand_region) {
+                            GmCand c;
+                            c.rs = rs; c.b = ky[q]; c.step = (uint16_t)st[q]; c.flags = 4; c.pad = 0; c.score = 0.0f;
+                            b.cands[(size_t)shard * b.cand_region + idx] = c;
+                        }
+                    }
+            }
+            if (s_any0) {                                // b = 0 (only if some wave saw such a vote): cumulative per-step counts
+                const uint32_t run = gm_wave_scan_incl(s_cnt0[lane]);
+                const uint32_t total0 = __builtin_amdgcn_readlane(run, 63);
+                const unsigned long long reached = __builtin_amdgcn_ballot_w64(run >= (uint32_t)p.kmin);
+                const bool emit = lane == 0 && total0 >= (uint32_t)p.kmin;
+                const uint32_t step = p.nw ? (uint32_t)(__ffsll((long long)reached) - 1) : (total0 > 65535u ? 65535u : total0);
+                gm_emit<GmLdsTable>(b, emit, rs, 0u, step, 4);
+            }
+        }
+        // wave 0 zeroes the half it emitted from (BIG: the table)
+        if (BIG) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s_tabv[lane + 64 * k] = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s_r0v[256 + lane + 64 * k] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
 }
 
 // ---- k_vote_tiny: one WAVEFRONT per read x strand, for at most 256 SA hits in at most 32 groups of 16 ranks ----------------
@@ -2899,7 +3343,16 @@ int gmk_vote(const GmDevIndex& ix, const GmDevParams& p, const GmDevBatch& b, in
         if (slots_form) {                           // default: wave-uniform seed slots + the list kernel for what it hands over
             const int slot_form = dense == 2 ? 64 : slots_hint == 0 ? 0 : slots_hint < 0 ? -1 : slots_hint <= 14 ? 16 : slots_hint <= 22 ? 24 : GMS_SMAX;      // 0 = k_vote_tiny, -1 = k_vote_tiny2
             const uint32_t lgrid = (uint32_t)std::min<uint64_t>(cdiv(2ull * b.n, 4), 256 * 20);
-#define GM_LAUNCH_VSL1(M, F, S) do { if (F && p.fused) hipLaunchKernelGGL((k_vote_slots<M, true, S, true>), dim3(2 * b.n), dim3(128), 0, S_(stream), ix, p, b); \
+            // the fused form as persistent workgroups with the next read x strands' loads in flight (k_vote_slots_pp): `pp_chunk` consecutive read x
+            // strands per workgroup - the pipeline's fill (three round trips) against ~64 votes.  Default for the 64-slot form only (its 20 KB of LDS
+            // leave 8 workgroups per CU to hide the three round trips: 133.9 -> 112.8 ms at the chrX shape); the smaller forms have 13 - 16
+            // workgroups per CU and lose them to the pipelined form's registers (40 slots: 59.9 against 68.1 ms at configs[1]).
+            // GM_SLOTS_PIPE=0 / 1: never / every form.  GM_DBG=64 (phase clocks) runs k_vote_slots.
+            const int pp_env = (int)gm_opt_ll("GM_SLOTS_PIPE", -1);
+            const uint32_t pp_chunk = ((pp_env < 0 ? slot_form == 64 : pp_env != 0) && !(p.dbg & 64)) ? (uint32_t)std::max<long long>(2, gm_opt_ll("GM_SLOTS_CHUNK", 64)) : 0u;
+#define GM_LAUNCH_VSL1(M, F, S) do { if (F && p.fused && pp_chunk) hipLaunchKernelGGL((k_vote_slots_pp<M, S, true>), dim3((uint32_t)cdiv(2ull * b.n, pp_chunk)), dim3(128), 0, S_(stream), ix, p, b, pp_chunk); \
+                                     else if (F && pp_chunk) hipLaunchKernelGGL((k_vote_slots_pp<M, S, false>), dim3((uint32_t)cdiv(2ull * b.n, pp_chunk)), dim3(128), 0, S_(stream), ix, p, b, pp_chunk); \
+                                     else if (F && p.fused) hipLaunchKernelGGL((k_vote_slots<M, true, S, true>), dim3(2 * b.n), dim3(128), 0, S_(stream), ix, p, b); \
                                      else hipLaunchKernelGGL((k_vote_slots<M, F, S, false>), dim3(2 * b.n), dim3(128), 0, S_(stream), ix, p, b); } while (0)
 #define GM_LAUNCH_VSL(M, F) do { if (slot_form == 0 && F && p.fused) hipLaunchKernelGGL((k_vote_tiny<M, true, true>), dim3(2 * b.n), dim3(64), 0, S_(stream), ix, p, b); \
                                  else if (slot_form == -1 && F && p.fused) hipLaunchKernelGGL((k_vote_tiny2<M, true, true>), dim3(2 * b.n), dim3(64), 0, S_(stream), ix, p, b); \

@@ -498,7 +498,20 @@ VARIANT_ENVS = [dict(GM_VOTE="block"),                                          
                                  dict(GM_VOTE="block", GM_VOTE_SLOTS="-1", GM_SEED_FUSED="1", GM_HEAVY_MIN="8", GM_HEAVY_BUDGET="200000"),
                                  # the same inside k_vote_slots (wave 0 of the workgroup looks the seeds up): every slot form, hand-over to the list / heavy kernels
                                  dict(GM_VOTE="block", GM_SEED_FUSED="1"), dict(GM_VOTE="big", GM_SEED_FUSED="1"), dict(GM_VOTE="block", GM_VOTE_SLOTS="10", GM_SEED_FUSED="1"),
-                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="20", GM_SEED_FUSED="1"), dict(GM_VOTE="block", GM_SEED_FUSED="1", GM_HEAVY_MIN="64")]
+                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="20", GM_SEED_FUSED="1"), dict(GM_VOTE="block", GM_SEED_FUSED="1", GM_HEAVY_MIN="64"),
+                                 # the 64-slot form of those runs k_vote_slots_pp by default (persistent workgroups, the next read x strands' loads in
+                                 # flight), GM_SLOTS_PIPE=1 puts every form on it; here: chunks of 2, of an odd number and one chunk for everything
+                                 # (pipeline fill and drain, a chunk that ends inside a read), the hand-over to the heavy path from inside the pipeline,
+                                 # and the one-workgroup-per-read-x-strand kernel of the 64-slot form (GM_SLOTS_PIPE=0)
+                                 dict(GM_VOTE="block", GM_SEED_FUSED="1", GM_SLOTS_PIPE="1"), dict(GM_VOTE="block", GM_SEED_FUSED="1", GM_SLOTS_PIPE="1", GM_SLOTS_CHUNK="2"),
+                                 dict(GM_VOTE="big", GM_SEED_FUSED="1", GM_SLOTS_CHUNK="7"),
+                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="10", GM_SEED_FUSED="1", GM_SLOTS_PIPE="1", GM_SLOTS_CHUNK="100000"),
+                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="20", GM_SEED_FUSED="1", GM_SLOTS_PIPE="1"),
+                                 dict(GM_VOTE="block", GM_SEED_FUSED="1", GM_HEAVY_MIN="64", GM_SLOTS_PIPE="1"),
+                                 dict(GM_VOTE="big", GM_SEED_FUSED="1", GM_SLOTS_PIPE="0"),
+                                 # ... and its form that takes k_seed's seed rows (what GM_VOTE=big alone runs by now)
+                                 dict(GM_VOTE="big", GM_SLOTS_PIPE="0"), dict(GM_VOTE="big", GM_SLOTS_CHUNK="3"), dict(GM_VOTE="block", GM_SLOTS_PIPE="1"),
+                                 dict(GM_VOTE="block", GM_VOTE_SLOTS="10", GM_SLOTS_PIPE="1"), dict(GM_VOTE="block", GM_VOTE_SLOTS="20", GM_SLOTS_PIPE="1", GM_SLOTS_CHUNK="100000")]
 VARIANT_CFGS = ["default", "no_nw", "k3", "h30", "m6_j2", "m20_j2", "k1"]
 
 
