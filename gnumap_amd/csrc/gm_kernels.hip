@@ -1231,7 +1231,7 @@ __device__ __forceinline__ bool gm_tiny_seeds(const GmDevIndex& ix, const GmDevP
 }
 
 #define GMS_SMAX 40                      // slots (64 lanes each) a read x strand may take in this kernel
-#define GMS_LCAP 540                     // compacted list entries per workgroup (more -> retry kernel)
+#define GMS_LCAP 540                     // compacted list entries per workgroup (more -> retry kernel); 488 / 440 (11.0 / 10.7 KB of LDS) measured: no change
 // SMAX = slots a read x strand may take: 16 / 24 / 40 for few seeds or few hits per seed (every slot of the form is walked,
 // used or not, so the small forms are the fast ones there), 64 = BIG, the form for 41..64 slots (e.g. 10-mers on a 150 Mbp
 // reference: ~150 hits per seed): 32 slots per wave, a longer list, the second filter takes the whole zeroed region
