@@ -1231,6 +1231,9 @@ __device__ __forceinline__ bool gm_tiny_seeds(const GmDevIndex& ix, const GmDevP
 }
 
 #define GMS_SMAX 40                      // slots (64 lanes each) a read x strand may take in this kernel
+#ifndef GMS_QS
+#define GMS_QS 4                         // wave steps of the list walked per round of the second filter / the table
+#endif
 #define GMS_LCAP 540                     // compacted list entries per workgroup (more -> retry kernel); 488 / 440 (11.0 / 10.7 KB of LDS) measured: no change
 // SMAX = slots a read x strand may take: 16 / 24 / 40 for few seeds or few hits per seed (every slot of the form is walked,
 // used or not, so the small forms are the fast ones there), 64 = BIG, the form for 41..64 slots (e.g. 10-mers on a 150 Mbp
@@ -1424,15 +1427,15 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
     const bool lfull = s_lcnt[0] + s_lcnt[1] > (uint32_t)LCAP;       // block-uniform
     const uint32_t n_l = lfull ? 0u : s_lcnt[wave];
     const uint32_t thr = (uint32_t)(p.kmin < 1 ? 1 : p.kmin);
-    for (uint32_t i0 = 0; i0 < n_l; i0 += 256) {     // four wave steps at a time: their list reads are in flight together
-        uint32_t bp4[4];
+    for (uint32_t i0 = 0; i0 < n_l; i0 += 64 * GMS_QS) {     // GMS_QS wave steps at a time: their list reads are in flight together
+        uint32_t bp4[GMS_QS];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < GMS_QS; ++q) {
             const uint32_t i = i0 + 64u * q + (uint32_t)lane;
             bp4[q] = i < n_l ? s_lbp[wave ? LCAP - 1 - i : i] : 0u;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < GMS_QS; ++q)
             if (bp4[q] != 0u) {
                 // two bits per slot, seen / seen again (as in k_vote_tiny): 16 384 (BIG: 32 768) slots in the words that held 2048
                 // (4096) 16-bit counters - 8 x fewer entries reach the CAS loop of the table by sharing a slot
@@ -1446,20 +1449,20 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
     {
         bool full = false;
         uint32_t nfresh = 0;
-        for (uint32_t i0 = 0; i0 < n_l; i0 += 256) {
-            uint32_t bp4[4], c4[4];
+        for (uint32_t i0 = 0; i0 < n_l; i0 += 64 * GMS_QS) {
+            uint32_t bp4[GMS_QS], c4[GMS_QS];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < GMS_QS; ++q) {
                 const uint32_t i = i0 + 64u * q + (uint32_t)lane;
                 bp4[q] = i < n_l ? s_lbp[wave ? LCAP - 1 - i : i] : 0u;
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < GMS_QS; ++q) {
                 const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> (BIG ? 17 : 18);
                 c4[q] = (s_r0[h2 & F2W] >> ((h2 >> F2S) << 1)) & (thr >= 2u ? 2u : 1u);
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < GMS_QS; ++q) {
                 bool fresh = false;
                 if (bp4[q] != 0u && c4[q] != 0u) {
                     const uint32_t i = i0 + 64u * q + (uint32_t)lane;
@@ -1848,15 +1851,15 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 4 : GMS_PP_WAVES) k_vote_slo
         const bool lfull = s_lcnt[0] + s_lcnt[1] > (uint32_t)LCAP;       // block-uniform
         const uint32_t n_l = lfull ? 0u : s_lcnt[wave];
         const uint32_t thr = (uint32_t)(p.kmin < 1 ? 1 : p.kmin);
-        for (uint32_t i0 = 0; i0 < n_l; i0 += 256) {     // four wave steps at a time: their list reads are in flight together
-            uint32_t bp4[4];
+        for (uint32_t i0 = 0; i0 < n_l; i0 += 64 * GMS_QS) {     // GMS_QS wave steps at a time: their list reads are in flight together
+            uint32_t bp4[GMS_QS];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < GMS_QS; ++q) {
                 const uint32_t i = i0 + 64u * q + (uint32_t)lane;
                 bp4[q] = i < n_l ? s_lbp[wave ? LCAP - 1 - i : i] : 0u;
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < GMS_QS; ++q)
                 if (bp4[q] != 0u) {
                     // two bits per slot, seen / seen again (as in k_vote_tiny): 16 384 (BIG: 32 768) slots in the words that held 2048
                     // (4096) 16-bit counters - 8 x fewer entries reach the CAS loop of the table by sharing a slot
@@ -1869,20 +1872,20 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 4 : GMS_PP_WAVES) k_vote_slo
         {
             bool full = false;
             uint32_t nfresh = 0;
-            for (uint32_t i0 = 0; i0 < n_l; i0 += 256) {
-                uint32_t bp4[4], c4[4];
+            for (uint32_t i0 = 0; i0 < n_l; i0 += 64 * GMS_QS) {
+                uint32_t bp4[GMS_QS], c4[GMS_QS];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < GMS_QS; ++q) {
                     const uint32_t i = i0 + 64u * q + (uint32_t)lane;
                     bp4[q] = i < n_l ? s_lbp[wave ? LCAP - 1 - i : i] : 0u;
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < GMS_QS; ++q) {
                     const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> (BIG ? 17 : 18);
                     c4[q] = (s_r0[h2 & F2W] >> ((h2 >> F2S) << 1)) & (thr >= 2u ? 2u : 1u);
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < GMS_QS; ++q) {
                     bool fresh = false;
                     if (bp4[q] != 0u && c4[q] != 0u) {
                         const uint32_t i = i0 + 64u * q + (uint32_t)lane;
