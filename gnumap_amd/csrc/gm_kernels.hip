@@ -1577,12 +1577,23 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 5 : SMAX == 16 ? 8 : 7) k_vo
 // issue the (identical) seed loads so that no wave-dependent branch surrounds them, wave 0 alone turns records into slot descriptors.
 // The slot descriptors are double-buffered; the filter / table memory is zeroed at the END of a vote (wave 1 its first half while wave
 // 0 emits from the second), so an iteration starts with one barrier.  Votes, hand-overs and results are those of k_vote_slots.
+// the 64-slot form of the pipelined kernel keeps its exact table in the upper half of the filter memory, as the smaller forms do (0; 1: in 4 KB
+// of its own, as k_vote_slots<64>): 15.9 instead of 20 KB of LDS = 10 workgroups per CU where the registers allow them (seed rows from
+// k_seed: 91 registers, vote 94.9 -> 90.0 ms at the chrX shape with -h 150; seeds looked up in the kernel: 96 + 11 spilled at 5 waves per
+// SIMD, 112.1 ms either way)
+#ifndef GMS_BIG_TAB
+#define GMS_BIG_TAB 0
+#endif
+#ifndef GMS_PP_WAVES64
+#define GMS_PP_WAVES64 5
+#endif
 #ifndef GMS_PP_WAVES
 #define GMS_PP_WAVES 5                   // wavefronts per SIMD the pipelined form is compiled for (its 40-slot form: 96 registers)
 #endif
 template <bool MASK64, int SMAX, bool SEED>
-__global__ void __launch_bounds__(128, SMAX == 64 ? 4 : GMS_PP_WAVES) k_vote_slots_pp(GmDevIndex ix, GmDevParams p, GmDevBatch b, const uint32_t chunk) {
+__global__ void __launch_bounds__(128, SMAX == 64 ? GMS_PP_WAVES64 : GMS_PP_WAVES) k_vote_slots_pp(GmDevIndex ix, GmDevParams p, GmDevBatch b, const uint32_t chunk) {
     constexpr bool BIG = SMAX == 64;
+    constexpr bool BIGT = BIG && GMS_BIG_TAB != 0;      // the 64-slot form's exact table in 4 KB of its own (second filter: 32 768 slots) or, as in the smaller forms, in the upper half of the filter memory
     constexpr int LCAP = BIG ? 1280 : SMAX == 16 ? 320 : GMS_LCAP;
     static_assert(SMAX == 16 || SMAX == 24 || SMAX == GMS_SMAX || SMAX == 64, "instantiated forms");
     constexpr int NT = 128, NW = 2, U = SMAX / NW, ZK = 512 / NT;
@@ -1591,7 +1602,7 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 4 : GMS_PP_WAVES) k_vote_slo
     __shared__ uint8_t s_lt[LCAP];
     __shared__ uint2 s_desc[2][SMAX];                // [read x strand parity within the chunk]
     __shared__ uint32_t s_cnt0[64];
-    __shared__ uint4 s_tabv[BIG ? 256 : 1];          // BIG: the exact table (256 x key | votes | low mask | high mask)
+    __shared__ uint4 s_tabv[BIGT ? 256 : 1];          // BIG: the exact table (256 x key | votes | low mask | high mask)
     __shared__ uint32_t s_nslots[2], s_E[2], s_nkeys, s_full, s_any0, s_lcnt[NW];
     uint32_t* const s_r0 = reinterpret_cast<uint32_t*>(s_r0v);
     uint32_t* const s_tab = reinterpret_cast<uint32_t*>(s_tabv);
@@ -1606,7 +1617,7 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 4 : GMS_PP_WAVES) k_vote_slo
     const uint32_t cmask = m >= 16u ? 0xFFFFFFFFu : ((1u << (2u * m)) - 1u);
 #pragma unroll
     for (int k = 0; k < ZK; ++k) s_r0v[tid + NT * k] = make_uint4(0u, 0u, 0u, 0u);
-    if (BIG) { s_tabv[tid] = make_uint4(0u, 0u, 0u, 0u); s_tabv[tid + NT] = make_uint4(0u, 0u, 0u, 0u); }
+    if (BIGT) { s_tabv[tid] = make_uint4(0u, 0u, 0u, 0u); s_tabv[tid + NT] = make_uint4(0u, 0u, 0u, 0u); }
     uint32_t vz = 0;                                 // zero, opaque: the header is loaded per lane and stays in a vector register until stage A makes
     asm volatile("" : "+v"(vz));                     // it scalar (loaded from a uniform address it is made scalar at once, i.e. waited for at once)
     uint32_t F_hdr = 0, F_f0 = 0, F_f1 = 0;          // c + 3: header and the two words that hold this lane's k-mer
@@ -1845,9 +1856,9 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 4 : GMS_PP_WAVES) k_vote_slo
             gm_lds_barrier();
         }
         constexpr int T2 = 256;
-        constexpr uint32_t F2W = BIG ? 2047u : 1023u;
-        constexpr int F2S = BIG ? 11 : 10;
-        uint32_t* const keys = BIG ? s_tab : s_r0 + 1024; uint32_t* const vals = keys + T2; uint32_t* const mlo = keys + 2 * T2; uint32_t* const mhi = keys + 3 * T2;
+        constexpr uint32_t F2W = BIGT ? 2047u : 1023u;
+        constexpr int F2S = BIGT ? 11 : 10;
+        uint32_t* const keys = BIGT ? s_tab : s_r0 + 1024; uint32_t* const vals = keys + T2; uint32_t* const mlo = keys + 2 * T2; uint32_t* const mhi = keys + 3 * T2;
         const bool lfull = s_lcnt[0] + s_lcnt[1] > (uint32_t)LCAP;       // block-uniform
         const uint32_t n_l = lfull ? 0u : s_lcnt[wave];
         const uint32_t thr = (uint32_t)(p.kmin < 1 ? 1 : p.kmin);
@@ -1863,7 +1874,7 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 4 : GMS_PP_WAVES) k_vote_slo
                 if (bp4[q] != 0u) {
                     // two bits per slot, seen / seen again (as in k_vote_tiny): 16 384 (BIG: 32 768) slots in the words that held 2048
                     // (4096) 16-bit counters - 8 x fewer entries reach the CAS loop of the table by sharing a slot
-                    const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> (BIG ? 17 : 18), sh = (h2 >> F2S) << 1;
+                    const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> (BIGT ? 17 : 18), sh = (h2 >> F2S) << 1;
                     const uint32_t old = atomicOr(&s_r0[h2 & F2W], 1u << sh);
                     if ((old >> sh) & 1u) atomicOr(&s_r0[h2 & F2W], 2u << sh);
                 }
@@ -1881,7 +1892,7 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 4 : GMS_PP_WAVES) k_vote_slo
                 }
 #pragma unroll
                 for (int q = 0; q < GMS_QS; ++q) {
-                    const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> (BIG ? 17 : 18);
+                    const uint32_t h2 = (bp4[q] * 0x85EBCA6Bu) >> (BIGT ? 17 : 18);
                     c4[q] = (s_r0[h2 & F2W] >> ((h2 >> F2S) << 1)) & (thr >= 2u ? 2u : 1u);
                 }
 #pragma unroll
@@ -1914,7 +1925,7 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 4 : GMS_PP_WAVES) k_vote_slo
         const bool failed = lfull || s_full || s_nkeys > (uint32_t)(T2 * 3 / 4);      // block-uniform
         if (wave != 0) {                                 // wave 1 is done with this vote: it zeroes what wave 0 does not emit from
 #pragma unroll
-            for (int k = 0; k < (BIG ? 8 : 4); ++k) s_r0v[lane + 64 * k] = make_uint4(0u, 0u, 0u, 0u);
+            for (int k = 0; k < (BIGT ? 8 : 4); ++k) s_r0v[lane + 64 * k] = make_uint4(0u, 0u, 0u, 0u);
             continue;
         }
         if (failed) {                                    // hand this read x strand to the global-table kernel
@@ -1987,7 +1998,7 @@ __global__ void __launch_bounds__(128, SMAX == 64 ? 4 : GMS_PP_WAVES) k_vote_slo
             }
         }
         // wave 0 zeroes the half it emitted from (BIG: the table)
-        if (BIG) {
+        if (BIGT) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) s_tabv[lane + 64 * k] = make_uint4(0u, 0u, 0u, 0u);
         } else {
