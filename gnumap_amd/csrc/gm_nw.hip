@@ -12,8 +12,10 @@
 //     2-bit window bit-reversed and funnel-shifted), so that DP row t of EVERY lane - whatever its strand and window start - finds its
 //     base, its quality and its new window column at the same register and bit position: compile-time shifts in rows unrolled 8 at a
 //     time, no per-row address arithmetic, no 13-way register pick, no strand-dependent indexing;
-//   * a band column's base is kept as two per-lane booleans (lane masks in scalar registers) that pick among the row's four values with
-//     three v_cndmask; sliding the band is register renaming inside the unrolled rows;
+//   * a band column's base is kept as its byte offset inside a value record (4 x its 2-bit code); a cell's value is ONE ds_read_b32 at
+//     record + column offset (the first form picked it out of the row's float4 with three v_cndmask on two lane masks per column: 21 of
+//     the 57 instructions of a row; as LDS reads the row is 45 and the kernel 5 % faster - the LDS has the room);
+//     sliding the band is register renaming inside the unrolled rows;
 //   * the first 8 and the last 9 .. 16 rows (which touch row L, column L or column -1) run a generic row; the rows between them test nothing.
 // The host launches it only for blocks it has checked: one read length L (24 <= L <= 8 NCH), no quality character above 127, -M 3.
 #include <hip/hip_runtime.h>
@@ -121,27 +123,25 @@ __global__ void __launch_bounds__(256, NCH <= 13 ? 4 : 3) k_nw_rows(GmDevIndex i
             float P[7];
 #pragma unroll
             for (int d = 0; d < 7; ++d) P[d] = d <= 3 ? __fmul_rn(gap, (float)(3 - d)) : GM_NEG_INF;
-            // the base of band column d as two booleans (bit 0 / bit 1 of its 2-bit code); row L - 1: columns j = L-4+d, valid for d <= 3
-            bool m1[7], m2[7];
+            // the base of band column d as 4 x its 2-bit code (its byte offset in a value record); row L - 1: columns j = L-4+d, valid for d <= 3
+            uint32_t cc[7];
 #pragma unroll
-            for (int d = 0; d < 7; ++d) { m1[d] = d <= 3 ? ((HW[0] >> (2 * (3 - d))) & 1u) != 0u : false; m2[d] = d <= 3 ? ((HW[0] >> (2 * (3 - d) + 1)) & 1u) != 0u : false; }
-            auto row_vals = [&](uint32_t bword, uint32_t qword, uint32_t shift) -> float4 {
+            for (int d = 0; d < 7; ++d) cc[d] = d <= 3 ? ((HW[0] >> (2 * (3 - d))) & 3u) << 2 : 0u;
+            // a row's value record {val(a), val(c), val(g), val(t)} as its LDS byte offset
+            auto row_vals = [&](uint32_t bword, uint32_t qword, uint32_t shift) -> uint32_t {
                 const uint32_t chv = (bword >> shift) & 255u;
                 const uint32_t co = clsrow[chv];
                 const uint32_t qv = (qword >> shift) & 255u;
-                return *reinterpret_cast<const float4*>(s_tab + qv * GM_NWR_QSTRIDE + co);
+                return qv * GM_NWR_QSTRIDE + co;
             };
-            auto cell_val = [&](const float4& v, int d) -> float {
-                const float lo = m1[d] ? v.y : v.x, hi = m1[d] ? v.w : v.z;
-                return m2[d] ? hi : lo;
-            };
+            auto cell_val = [&](const uint32_t v, int d) -> float { return *reinterpret_cast<const float*>(s_tab + v + cc[d]); };
             auto slide = [&](uint32_t hw, uint32_t pos) {                       // band columns of the next row; the new one is H[t + 4] (j = i - 4)
 #pragma unroll
-                for (int d = 6; d >= 1; --d) { m1[d] = m1[d - 1]; m2[d] = m2[d - 1]; }
-                m1[0] = ((hw >> pos) & 1u) != 0u; m2[0] = ((hw >> (pos + 1u)) & 1u) != 0u;
+                for (int d = 6; d >= 1; --d) cc[d] = cc[d - 1];
+                cc[0] = ((hw >> pos) & 3u) << 2;
             };
             // an interior row (4 <= i <= L - 5): every cell inside the matrix, band edges are NEG_INF
-            auto row_int = [&](const float4& v, uint32_t hw, uint32_t pos) {
+            auto row_int = [&](const uint32_t v, uint32_t hw, uint32_t pos) {
                 float val[7], mm[7], g1[7];
 #pragma unroll
                 for (int d = 0; d < 7; ++d) val[d] = cell_val(v, d);
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256, NCH <= 13 ? 4 : 3) k_nw_rows(GmDevIndex i
                 slide(hw, pos);
             };
             // a row near a matrix edge: exactly k_nw_lane's EDGE row
-            auto row_edge = [&](const int t, const float4& v, uint32_t hw, uint32_t pos) {
+            auto row_edge = [&](const int t, const uint32_t v, uint32_t hw, uint32_t pos) {
                 const int i = Li - 1 - t;
                 const float lastcol = __fmul_rn(gap, (float)(unsigned)(Li - i));                  // nm[i][L] = gGAP * (L - i)
 #pragma unroll
@@ -198,15 +198,14 @@ __global__ void __launch_bounds__(256, NCH <= 13 ? 4 : 3) k_nw_rows(GmDevIndex i
                 const uint2 bw = pick2(XB, k), qw = pick2(XQ, k);
                 for (int t = t0; t < t1; ++t) {
                     const uint32_t bsel = (t & 4) ? bw.y : bw.x, qsel = (t & 4) ? qw.y : qw.x;
-                    const float4 v = row_vals(bsel, qsel, (uint32_t)(t & 3) << 3);
+                    const uint32_t v = row_vals(bsel, qsel, (uint32_t)(t & 3) << 3);
                     const int u = t + 4;
                     if (EDGE) row_edge(t, v, pick_hw(u >> 4), 2u * (uint32_t)(u & 15));
                     else row_int(v, pick_hw(u >> 4), 2u * (uint32_t)(u & 15));
                 }
             };
             // interior rows [B0, 8) of chunk k at compile-time positions; PAR = k & 1 fixes where the rows' new columns sit in the window
-            // stream.  The class offsets of all rows are requested first (one LDS round trip for the chunk), the value record of row
-            // bb + 1 before the arithmetic of row bb
+            // stream.  The class offsets of all rows are requested first (one LDS round trip for the chunk)
             auto rows8 = [&](const int k, auto par_tag, auto b0_tag) {
                 constexpr int PAR = decltype(par_tag)::value, B0 = decltype(b0_tag)::value;
                 const uint2 bw = pick2(XB, k), qw = pick2(XQ, k);
@@ -215,15 +214,9 @@ __global__ void __launch_bounds__(256, NCH <= 13 ? 4 : 3) k_nw_rows(GmDevIndex i
                 uint32_t co[8];
 #pragma unroll
                 for (int bb = B0; bb < 8; ++bb) co[bb] = clsrow[((bb < 4 ? bw.x : bw.y) >> ((bb & 3) << 3)) & 255u];
-                auto rec = [&](int bb) -> float4 {
-                    const uint32_t qv = ((bb < 4 ? qw.x : qw.y) >> ((bb & 3) << 3)) & 255u;
-                    return *reinterpret_cast<const float4*>(s_tab + qv * GM_NWR_QSTRIDE + co[bb]);
-                };
-                float4 vn = rec(B0);
 #pragma unroll
                 for (int bb = B0; bb < 8; ++bb) {
-                    const float4 v = vn;
-                    if (bb < 7) vn = rec(bb + 1);
+                    const uint32_t v = (((bb < 4 ? qw.x : qw.y) >> ((bb & 3) << 3)) & 255u) * GM_NWR_QSTRIDE + co[bb];
                     if (PAR) { if (bb < 4) row_int(v, hw_lo, 2u * (12u + bb)); else row_int(v, hw_hi, 2u * (bb - 4u)); }
                     else row_int(v, hw_lo, 2u * (4u + bb));
                 }
